@@ -1,0 +1,358 @@
+"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of RIV-SLAM's APD-GICP.
+
+PARITY UNPINNED: the reference (fast_gicp::FastAPDGICP) needs PCL + Eigen + FLANN, none of which
+exist in the build image, and the reference's own tests never instantiate FastAPDGICP
+(fast_apdgicp/src/test/gicp_test.cpp:103-124).  Parity is therefore pinned by two independent
+restatements that must agree with each other: this file (brute-force fp32 nearest neighbours,
+numpy.linalg) and oracle/apdgicp_ref.cpp (kd-tree, hand-rolled linear algebra, OpenMP).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Every function cites the reference lines it follows; paths are relative to
+/root/reference/fast_apdgicp/include/fast_gicp/.
+
+Third-party arithmetic restated here (not vendored by the reference, versions unpinned there):
+  * FLANN L2_Simple<float> distance as used by pcl::search::KdTree: result += (a[i]-b[i])^2 for
+    i = 0,1,2 accumulated in fp32, no FMA (reference builds with -msse4.2 only,
+    fast_apdgicp/CMakeLists.txt:11-16); exact k-NN.  Ties are broken towards the LOWER index here
+    (FLANN's choice depends on tree layout and is not specified).
+  * Eigen Isometry3f * Vector4f: row_i = ((m_i0*x + m_i1*y) + m_i2*z) + m_i3*w in fp32.
+  * Eigen JacobiSVD of a symmetric PSD 3x3 == symmetric eigendecomposition, values descending.
+  * Eigen Matrix4d::inverse() of blkdiag(C,1) == blkdiag(inv(C),1).
+  * Eigen LDLT<6x6>::solve == any backward-stable SPD solve (agreement ~1e-12 relative).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+F32 = np.float32
+
+# gicp/gicp_settings.hpp:6
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = 0, 1, 2, 3, 4
+OPT_LM, OPT_GN = 0, 1
+
+
+@dataclass
+class Params:
+    # gicp/impl/fast_apdgicp_impl.hpp:14-28, gicp/fast_apdgicp.hpp:107-109,
+    # gicp/impl/lsq_registration_impl.hpp:11-24
+    k_correspondences: int = 20
+    max_iterations: int = 64
+    lm_max_iterations: int = 10
+    optimizer: int = OPT_LM
+    regularization: int = REG_PLANE
+    max_correspondence_distance: float = float(np.finfo(np.float32).max)
+    transformation_epsilon: float = 5e-4
+    rotation_epsilon: float = 2e-3
+    lm_init_lambda_factor: float = 1e-9
+    distance_variance: float = 0.86
+    azimuth_variance_deg: float = 0.5
+    elevation_variance_deg: float = 1.0
+
+
+# ----------------------------------------------------------------------------- fp32 geometry
+def transform_points_f32(T: np.ndarray, pts: np.ndarray) -> np.ndarray:
+    """pt = trans.cast<float>() * p  (gicp/impl/fast_apdgicp_impl.hpp:137,149), fp32, no FMA."""
+    Tf = np.asarray(T, dtype=np.float64).astype(F32)
+    x, y, z = pts[:, 0].astype(F32), pts[:, 1].astype(F32), pts[:, 2].astype(F32)
+    out = np.empty((pts.shape[0], 3), dtype=F32)
+    for r in range(3):
+        acc = Tf[r, 0] * x
+        acc = acc + Tf[r, 1] * y
+        acc = acc + Tf[r, 2] * z
+        acc = acc + Tf[r, 3]
+        out[:, r] = acc
+    return out
+
+
+def sqdist_f32(q: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """[len(q), len(t)] fp32 squared distances in FLANN L2_Simple accumulation order."""
+    dx = q[:, None, 0] - t[None, :, 0]
+    d = dx * dx
+    dy = q[:, None, 1] - t[None, :, 1]
+    d = d + dy * dy
+    dz = q[:, None, 2] - t[None, :, 2]
+    d = d + dz * dz
+    return d
+
+
+def nn1(q: np.ndarray, t: np.ndarray, chunk: int = 512):
+    """Exact 1-NN (lowest index on ties).  Returns (idx int32, sqdist f32)."""
+    idx = np.empty(q.shape[0], dtype=np.int32)
+    sq = np.empty(q.shape[0], dtype=F32)
+    for s in range(0, q.shape[0], chunk):
+        d = sqdist_f32(q[s:s + chunk], t)
+        j = np.argmin(d, axis=1)
+        idx[s:s + chunk] = j
+        sq[s:s + chunk] = d[np.arange(d.shape[0]), j]
+    return idx, sq
+
+
+def knn(cloud: np.ndarray, k: int, chunk: int = 512) -> np.ndarray:
+    """Exact k-NN of every point within its own cloud, the point itself included
+    (gicp/impl/fast_apdgicp_impl.hpp:316).  Ordered by (sqdist, index)."""
+    n = cloud.shape[0]
+    out = np.empty((n, k), dtype=np.int32)
+    for s in range(0, n, chunk):
+        d = sqdist_f32(cloud[s:s + chunk], cloud)
+        out[s:s + chunk] = np.argsort(d, axis=1, kind="stable")[:, :k]
+    return out
+
+
+# ----------------------------------------------------------------------------- covariances
+def calculate_covariances(cloud: np.ndarray, k: int = 20, regularization: int = REG_PLANE) -> np.ndarray:
+    """gicp/impl/fast_apdgicp_impl.hpp:303-363.  Returns [n,3,3] fp64 (top-left block of the
+    reference's Matrix4d; its 4th row/column is identically zero)."""
+    cloud = np.ascontiguousarray(cloud, dtype=F32)
+    n = cloud.shape[0]
+    if n < k:
+        raise ValueError("need at least k points (reference reads uninitialised neighbours, :318-321)")
+    nbr = knn(cloud, k)
+    covs = np.empty((n, 3, 3), dtype=np.float64)
+    for i in range(n):
+        P = cloud[nbr[i]].astype(np.float64)           # :318-321
+        P = P - P.mean(axis=0)                          # :323
+        cov = (P.T @ P) / k                             # :324  (population, /k)
+        if regularization == REG_NONE:                  # :326-328
+            covs[i] = cov
+        elif regularization == REG_FROBENIUS:           # :329-335
+            C = cov + 1e-3 * np.eye(3)
+            Ci = np.linalg.inv(C)
+            covs[i] = np.linalg.inv(Ci / np.linalg.norm(Ci))
+        else:                                           # :337-357
+            w, U = np.linalg.eigh(cov)
+            w, U = w[::-1], U[:, ::-1]                  # singular values descending
+            w = np.maximum(w, 0.0)
+            if regularization == REG_PLANE:
+                vals = np.array([1.0, 1.0, 1e-3])
+            elif regularization == REG_MIN_EIG:
+                vals = np.maximum(w, 1e-3)
+            elif regularization == REG_NORMALIZED_MIN_EIG:
+                vals = np.maximum(w / w.max(), 1e-3)
+            else:
+                raise ValueError("unknown regularization (reference aborts, :341-343)")
+            covs[i] = (U * vals) @ U.T
+    return covs
+
+
+# ----------------------------------------------------------------------------- SO(3)
+def skewd(x):
+    """so3/so3.hpp:21-31"""
+    return np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]], dtype=np.float64)
+
+
+def so3_exp(omega: np.ndarray) -> np.ndarray:
+    """so3/so3.hpp:59-78 -> unit quaternion -> Eigen::Quaterniond::toRotationMatrix()."""
+    theta_sq = float(omega @ omega)
+    if theta_sq < 1e-10:
+        theta_quad = theta_sq * theta_sq
+        imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * theta_quad
+        real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * theta_quad
+    else:
+        theta = math.sqrt(theta_sq)
+        half = 0.5 * theta
+        imag = math.sin(half) / theta
+        real = math.cos(half)
+    w, x, y, z = real, imag * omega[0], imag * omega[1], imag * omega[2]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]], dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------- the registration
+@dataclass
+class Trace:
+    lambdas: list = field(default_factory=list)
+    rhos: list = field(default_factory=list)
+    y0s: list = field(default_factory=list)
+    yis: list = field(default_factory=list)
+    poses: list = field(default_factory=list)   # x0 after every outer iteration
+    n_linearize: int = 0
+    n_compute_error: int = 0
+
+
+class FastAPDGICP:
+    """Mirror of fast_gicp::FastAPDGICP + LsqRegistration (method names follow the reference)."""
+
+    def __init__(self, params: Params | None = None):
+        self.p = params or Params()
+        self.source = None
+        self.target = None
+        self.source_covs = None
+        self.target_covs = None
+        self.correspondences = None
+        self.sq_distances = None
+        self.mahalanobis = None
+        self.final_transformation = np.eye(4, dtype=F32)
+        self.final_hessian = np.eye(6)
+        self.converged = False
+        self.nr_iterations = 0
+        self.lm_lambda = -1.0
+        self.trace = Trace()
+
+    # gicp/impl/fast_apdgicp_impl.hpp:90-108 (pointer-equality caching is the adapter's business)
+    def setInputSource(self, cloud):
+        self.source = np.ascontiguousarray(cloud, dtype=F32)
+        self.source_covs = None
+
+    def setInputTarget(self, cloud):
+        self.target = np.ascontiguousarray(cloud, dtype=F32)
+        self.target_covs = None
+
+    # :133-194
+    def update_correspondences(self, T: np.ndarray):
+        p = self.p
+        pt = transform_points_f32(T, self.source)
+        idx, sq = nn1(pt, self.target)
+        thr2 = float(p.max_correspondence_distance) * float(p.max_correspondence_distance)
+        corr = np.where(sq.astype(np.float64) < thr2, idx, -1).astype(np.int32)  # :156
+        n = self.source.shape[0]
+        M = np.zeros((n, 3, 3))
+        R = np.asarray(T, dtype=np.float64)[:3, :3]
+        sin_az = math.sin(p.azimuth_variance_deg / 180 * math.pi)
+        sin_el = math.sin(p.elevation_variance_deg / 180 * math.pi)
+        for i in range(n):
+            j = corr[i]
+            if j < 0:
+                continue
+            x, y, z = pt[i, 0], pt[i, 1], pt[i, 2]               # fp32 scalars
+            dist = float(np.linalg.norm(pt[i].astype(np.float64)))            # :167
+            aoa = float(np.arctan2(x, np.sqrt(y * y + z * z)))               # :168 (float overloads)
+            s_x = dist * p.distance_variance / 400                             # :169
+            s_y = dist * sin_az / math.cos(aoa)                                # :170
+            s_z = dist * sin_el / math.cos(aoa)                                # :171
+            elevation = float(np.arctan2(np.sqrt(x * x + y * y), z))          # :172
+            azimuth = float(np.arctan2(y, x))                                  # :173
+            ce, se = math.cos(elevation), math.sin(elevation)
+            ca, sa = math.cos(azimuth), math.sin(azimuth)
+            Ry = np.array([[ce, 0, se], [0, 1, 0], [-se, 0, ce]])
+            Rz = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.0]])
+            A = (Rz @ Ry) @ np.diag([s_x, s_y, s_z])                           # :174-181
+            cov_r = A @ A.T                                                    # :182
+            RCR = (self.target_covs[j] + cov_r) + R @ (self.source_covs[i] + cov_r) @ R.T  # :188
+            M[i] = np.linalg.inv(RCR)                                          # :191-192
+        self.correspondences, self.sq_distances, self.mahalanobis = corr, sq, M
+
+    # :198-272
+    def linearize(self, T: np.ndarray, want_Hb: bool = True):
+        self.trace.n_linearize += 1
+        self.update_correspondences(T)
+        T = np.asarray(T, dtype=np.float64)
+        sel = np.nonzero(self.correspondences >= 0)[0]
+        a = self.source[sel].astype(np.float64)
+        b = self.target[self.correspondences[sel]].astype(np.float64)
+        Ta = a @ T[:3, :3].T + T[:3, 3]
+        e = b - Ta
+        M = self.mahalanobis[sel]
+        Me = np.einsum("nij,nj->ni", M, e)
+        cost = float(np.einsum("ni,ni->", e, Me))
+        if not want_Hb:
+            return cost, None, None
+        J = np.zeros((len(sel), 3, 6))
+        J[:, 0, 1], J[:, 0, 2] = -Ta[:, 2], Ta[:, 1]
+        J[:, 1, 0], J[:, 1, 2] = Ta[:, 2], -Ta[:, 0]
+        J[:, 2, 0], J[:, 2, 1] = -Ta[:, 1], Ta[:, 0]
+        J[:, 0, 3] = J[:, 1, 4] = J[:, 2, 5] = -1.0
+        MJ = np.einsum("nij,njk->nik", M, J)
+        H = np.einsum("nji,njk->ik", J, MJ)
+        bb = np.einsum("nji,nj->i", J, Me)
+        return cost, H, bb
+
+    # :275-298
+    def compute_error(self, T: np.ndarray) -> float:
+        self.trace.n_compute_error += 1
+        T = np.asarray(T, dtype=np.float64)
+        sel = np.nonzero(self.correspondences >= 0)[0]
+        a = self.source[sel].astype(np.float64)
+        b = self.target[self.correspondences[sel]].astype(np.float64)
+        e = b - (a @ T[:3, :3].T + T[:3, 3])
+        return float(np.einsum("ni,nij,nj->", e, self.mahalanobis[sel], e))
+
+    # gicp/impl/lsq_registration_impl.hpp:83-92
+    def is_converged(self, delta: np.ndarray) -> bool:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = np.abs(delta[:3, :3] - np.eye(3)) * (1.0 / self.p.rotation_epsilon)
+            t = np.abs(delta[:3, 3]) * (1.0 / self.p.transformation_epsilon)
+        return max(r.max(), t.max()) < 1
+
+    @staticmethod
+    def _delta(d: np.ndarray) -> np.ndarray:
+        delta = np.eye(4)
+        delta[:3, :3] = so3_exp(d[:3])
+        delta[:3, 3] = d[3:]
+        return delta
+
+    # lsq_registration_impl.hpp:107-123
+    def step_gn(self, x0):
+        y0, H, b = self.linearize(x0)
+        d = np.linalg.solve(H, -b)
+        delta = self._delta(d)
+        self.final_hessian = H
+        self.trace.y0s.append(y0)
+        return True, delta @ x0, delta
+
+    # lsq_registration_impl.hpp:127-173
+    def step_lm(self, x0):
+        y0, H, b = self.linearize(x0)
+        if self.lm_lambda < 0.0:
+            self.lm_lambda = self.p.lm_init_lambda_factor * np.abs(np.diag(H)).max()
+        nu = 2.0
+        delta = np.eye(4)
+        for _ in range(self.p.lm_max_iterations):
+            d = np.linalg.solve(H + self.lm_lambda * np.eye(6), -b)
+            delta = self._delta(d)
+            xi = delta @ x0
+            yi = self.compute_error(xi)
+            rho = (y0 - yi) / float(d @ (self.lm_lambda * d - b))
+            self.trace.lambdas.append(self.lm_lambda)
+            self.trace.rhos.append(rho)
+            self.trace.y0s.append(y0)
+            self.trace.yis.append(yi)
+            if rho < 0:
+                if self.is_converged(delta):
+                    return True, x0, delta
+                self.lm_lambda = nu * self.lm_lambda
+                nu = 2 * nu
+                continue
+            self.lm_lambda = self.lm_lambda * max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            self.final_hessian = H
+            return True, xi, delta
+        return False, x0, delta
+
+    # fast_apdgicp_impl.hpp:121-130 + lsq_registration_impl.hpp:55-80
+    def align(self, guess=None):
+        p = self.p
+        if self.source_covs is None:
+            self.source_covs = calculate_covariances(self.source, p.k_correspondences, p.regularization)
+        if self.target_covs is None:
+            self.target_covs = calculate_covariances(self.target, p.k_correspondences, p.regularization)
+        g = np.eye(4, dtype=F32) if guess is None else np.asarray(guess, dtype=F32)
+        x0 = g.astype(np.float64)
+        self.lm_lambda = -1.0
+        self.converged = False
+        self.trace = Trace()
+        self.nr_iterations = 0
+        for i in range(p.max_iterations):
+            if self.converged:
+                break
+            self.nr_iterations = i
+            ok, x0, delta = (self.step_lm if p.optimizer == OPT_LM else self.step_gn)(x0)
+            if not ok:
+                break  # "lm not converged!!"
+            self.converged = self.is_converged(delta)
+            self.trace.poses.append(x0.copy())
+        self.final_transformation = x0.astype(F32)
+        return self.final_transformation
+
+    def hasConverged(self):
+        return self.converged
+
+    def getFinalTransformation(self):
+        return self.final_transformation

@@ -1,0 +1,191 @@
+"""ORACLE loader (test infrastructure): ctypes binding of oracle/_build/libapdgicp_ref.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libapdgicp_ref.so")
+
+
+class RefParams(C.Structure):
+    _fields_ = [
+        ("k_correspondences", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("lm_max_iterations", C.c_int32),
+        ("optimizer", C.c_int32),
+        ("regularization", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_correspondence_distance", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("rotation_epsilon", C.c_double),
+        ("lm_init_lambda_factor", C.c_double),
+        ("distance_variance", C.c_double),
+        ("azimuth_variance_deg", C.c_double),
+        ("elevation_variance_deg", C.c_double),
+    ]
+
+
+def default_params(**kw) -> RefParams:
+    p = RefParams(20, 64, 10, 0, 3, 0, float(np.finfo(np.float32).max), 5e-4, 2e-3, 1e-9, 0.86, 0.5, 1.0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "apdgicp_ref.cpp")
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [C.POINTER(RefParams)]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_set_params.argtypes = [C.c_void_p, C.POINTER(RefParams)]
+        L.ref_set_num_threads.argtypes = [C.c_void_p, C.c_int]
+        for f in (L.ref_set_source, L.ref_set_target):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            f.restype = None
+        L.ref_compute_covariances.argtypes = [C.c_void_p, C.c_int]
+        L.ref_get_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.ref_compute_error.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.ref_get_correspondences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_get_mahalanobis.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_get_final_hessian.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_knn_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_knn_kdtree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class RefAPDGICP:
+    """The C++ restatement behind the reference's method names (matrices are numpy row-major
+    [4,4] / [6,6] views; the C side is column-major like Eigen)."""
+
+    def __init__(self, params: RefParams | None = None, num_threads: int = 0):
+        self.L = lib()
+        self.params = params or default_params()
+        self.h = C.c_void_p(self.L.ref_create(C.byref(self.params)))
+        self.num_threads = self.L.ref_set_num_threads(self.h, num_threads)
+        self.n_src = self.n_tgt = 0
+        self.converged = False
+        self.nr_iterations = 0
+        self.n_linearize = self.n_compute_error = 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.ref_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_params(self, params: RefParams):
+        self.params = params
+        self.L.ref_set_params(self.h, C.byref(params))
+
+    def setInputSource(self, cloud):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        self._src = c
+        self.n_src = c.shape[0]
+        self.L.ref_set_source(self.h, _ptr(c), c.shape[0], c.shape[1])
+
+    def setInputTarget(self, cloud):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        self._tgt = c
+        self.n_tgt = c.shape[0]
+        self.L.ref_set_target(self.h, _ptr(c), c.shape[0], c.shape[1])
+
+    def covariances(self, which: str) -> np.ndarray:
+        w = 0 if which == "source" else 1
+        n = self.n_src if w == 0 else self.n_tgt
+        rc = self.L.ref_compute_covariances(self.h, w)
+        if rc:
+            raise RuntimeError(f"calculate_covariances failed rc={rc}")
+        out = np.empty((n, 3, 3))
+        self.L.ref_get_covariances(self.h, w, _ptr(out))
+        return out
+
+    def linearize(self, T, want_Hb: bool = True):
+        Tc = np.asfortranarray(np.asarray(T, dtype=np.float64))
+        H = np.zeros((6, 6), order="F")
+        b = np.zeros(6)
+        cost = C.c_double()
+        rc = self.L.ref_linearize(self.h, _ptr(Tc), _ptr(H) if want_Hb else None, _ptr(b) if want_Hb else None, C.byref(cost))
+        if rc:
+            raise RuntimeError("ref_linearize failed")
+        return cost.value, (np.ascontiguousarray(H) if want_Hb else None), (b if want_Hb else None)
+
+    def compute_error(self, T) -> float:
+        Tc = np.asfortranarray(np.asarray(T, dtype=np.float64))
+        cost = C.c_double()
+        if self.L.ref_compute_error(self.h, _ptr(Tc), C.byref(cost)):
+            raise RuntimeError("ref_compute_error failed (no correspondences yet)")
+        return cost.value
+
+    def correspondences(self):
+        corr = np.empty(self.n_src, dtype=np.int32)
+        sqd = np.empty(self.n_src, dtype=np.float32)
+        self.L.ref_get_correspondences(self.h, _ptr(corr), _ptr(sqd))
+        return corr, sqd
+
+    def mahalanobis(self) -> np.ndarray:
+        out = np.empty((self.n_src, 3, 3))
+        self.L.ref_get_mahalanobis(self.h, _ptr(out))
+        return out
+
+    def align(self, guess=None) -> np.ndarray:
+        g = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, dtype=np.float32)
+        gc = np.asfortranarray(g)
+        out = np.zeros((4, 4), dtype=np.float32, order="F")
+        info = np.zeros(4, dtype=np.int32)
+        if self.L.ref_align(self.h, _ptr(gc), _ptr(out), _ptr(info)):
+            raise RuntimeError("ref_align failed")
+        self.converged = bool(info[0])
+        self.nr_iterations = int(info[1])
+        self.n_linearize, self.n_compute_error = int(info[2]), int(info[3])
+        self.final_transformation = np.ascontiguousarray(out)
+        return self.final_transformation
+
+    def final_hessian(self) -> np.ndarray:
+        H = np.zeros((6, 6), order="F")
+        self.L.ref_get_final_hessian(self.h, _ptr(H))
+        return np.ascontiguousarray(H)
+
+    def hasConverged(self):
+        return self.converged
+
+    def getFinalTransformation(self):
+        return self.final_transformation
+
+    def knn_kdtree(self, which: str, q, k: int):
+        idx = np.empty(k, dtype=np.int32)
+        d = np.empty(k, dtype=np.float32)
+        qq = np.ascontiguousarray(q, dtype=np.float32)
+        n = self.L.ref_knn_kdtree(self.h, 0 if which == "source" else 1, _ptr(qq), k, _ptr(idx), _ptr(d))
+        return idx[:n], d[:n]

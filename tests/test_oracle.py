@@ -1,0 +1,176 @@
+"""CPU tests (-m "not gpu"): the two oracle restatements against the committed golden vectors and
+against each other.  The reference holds no fixture for FastAPDGICP (parity unpinned)."""
+import numpy as np
+import pytest
+
+import apdgicp_np as O
+import ref as R
+from conftest import rel_err
+
+LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+REGS = (("none", 0), ("min_eig", 1), ("norm_min_eig", 2), ("plane", 3), ("frobenius", 4))
+
+
+@pytest.mark.parametrize("name,reg", REGS)
+def test_cov_golden_cpp(golden, name, reg):
+    r = R.RefAPDGICP(R.default_params(regularization=reg))
+    r.setInputSource(golden["cov_cloud"])
+    assert np.abs(r.covariances("source") - golden[f"cov_{name}"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name,reg", REGS)
+def test_cov_golden_numpy(golden, name, reg):
+    c = O.calculate_covariances(golden["cov_cloud"], 20, reg)
+    assert np.abs(c - golden[f"cov_{name}"]).max() <= 1e-12 * max(1.0, np.abs(c).max())
+
+
+def test_plane_cov_structure(golden):
+    """PLANE regularisation == I - (1-1e-3) n n^T: eigenvalues {1, 1, 1e-3} (fast_apdgicp_impl.hpp:344-357)."""
+    w = np.linalg.eigvalsh(golden["cov_plane"])
+    assert np.allclose(w, [1e-3, 1.0, 1.0], atol=1e-12)
+
+
+def test_kdtree_equals_bruteforce(golden):
+    cloud = golden["lin_target"]
+    r = R.RefAPDGICP()
+    r.setInputTarget(cloud)
+    rng = np.random.default_rng(3)
+    qs = np.concatenate([cloud[rng.integers(0, len(cloud), 64)], rng.uniform(-5, 100, size=(64, 3)).astype(np.float32)])
+    d = O.sqdist_f32(qs, cloud)
+    for k in (1, 20):
+        want = np.argsort(d, axis=1, kind="stable")[:, :k]
+        for i, q in enumerate(qs):
+            idx, dist = r.knn_kdtree("target", q, k)
+            assert np.array_equal(idx, want[i])
+            assert np.array_equal(dist, d[i, want[i]])
+
+
+def test_kdtree_ties_pick_lowest_index():
+    pts = np.zeros((64, 3), dtype=np.float32)
+    pts[:, 0] = np.repeat(np.arange(8), 8)  # 8 copies of each of 8 points
+    r = R.RefAPDGICP()
+    r.setInputTarget(pts)
+    idx, _ = r.knn_kdtree("target", np.array([3.0, 0, 0], dtype=np.float32), 3)
+    assert list(idx) == [24, 25, 26]
+
+
+@pytest.mark.parametrize("tag,kw", (("default", {}), ("launch", LAUNCH)))
+def test_linearize_golden_cpp(golden, tag, kw):
+    r = R.RefAPDGICP(R.default_params(**kw))
+    r.setInputSource(golden["lin_source"])
+    r.setInputTarget(golden["lin_target"])
+    for k in range(3):
+        cost, H, b = r.linearize(golden[f"lin_{tag}_{k}_T"])
+        corr, sqd = r.correspondences()
+        assert np.array_equal(corr, golden[f"lin_{tag}_{k}_corr"])
+        assert np.array_equal(sqd, golden[f"lin_{tag}_{k}_sqd"])
+        assert rel_err(H, golden[f"lin_{tag}_{k}_H"]) < 1e-10
+        assert rel_err(b, golden[f"lin_{tag}_{k}_b"]) < 1e-10
+        assert abs(cost - golden[f"lin_{tag}_{k}_cost"]) < 1e-10 * cost
+        assert rel_err(r.mahalanobis()[:128], golden[f"lin_{tag}_{k}_maha128"]) < 1e-12
+        err = r.compute_error(golden[f"lin_{tag}_{k}_errT"])
+        assert abs(err - golden[f"lin_{tag}_{k}_err"]) < 1e-10 * err
+        cost_only, _, _ = r.linearize(golden[f"lin_{tag}_{k}_T"], want_Hb=False)
+        assert abs(cost_only - cost) < 1e-12 * cost
+
+
+def test_linearize_golden_numpy(golden):
+    """Independent restatement: exact on the discrete outputs, 5e-6 on the smooth ones (fp32 atan2)."""
+    n = O.FastAPDGICP(O.Params(**LAUNCH))
+    n.setInputSource(golden["lin_source"])
+    n.setInputTarget(golden["lin_target"])
+    n.source_covs, n.target_covs = golden["lin_source_cov"], golden["lin_target_cov"]
+    k = 1
+    cost, H, b = n.linearize(golden[f"lin_launch_{k}_T"])
+    assert np.array_equal(n.correspondences, golden[f"lin_launch_{k}_corr"])
+    assert np.array_equal(n.sq_distances, golden[f"lin_launch_{k}_sqd"])
+    assert rel_err(H, golden[f"lin_launch_{k}_H"]) < 5e-6
+    assert rel_err(b, golden[f"lin_launch_{k}_b"]) < 5e-6
+    assert abs(cost - golden[f"lin_launch_{k}_cost"]) < 5e-6 * cost
+
+
+def test_serial_and_threaded_sums_agree(golden):
+    a, b = R.RefAPDGICP(num_threads=1), R.RefAPDGICP(num_threads=4)
+    for r in (a, b):
+        r.setInputSource(golden["lin_source"])
+        r.setInputTarget(golden["lin_target"])
+    ca, Ha, ba = a.linearize(golden["lin_default_1_T"])
+    cb, Hb, bb = b.linearize(golden["lin_default_1_T"])
+    assert rel_err(Ha, Hb) < 1e-12 and rel_err(ba, bb) < 1e-11 and abs(ca - cb) < 1e-12 * ca
+
+
+RUNS = {
+    "lm_default": {},
+    "lm_launch": LAUNCH,
+    "gn20": dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300),
+    "lm_loop": dict(max_correspondence_distance=2.5),
+}
+
+
+@pytest.mark.parametrize("tag", list(RUNS))
+def test_align_golden_cpp(golden, scene, tag):
+    r = R.RefAPDGICP(R.default_params(**RUNS[tag]))
+    pre = "lm_loop" if tag == "lm_loop" else "lin"
+    r.setInputSource(golden[f"{pre}_source"])
+    r.setInputTarget(golden[f"{pre}_target"])
+    T = r.align(golden[f"{pre}_guess"])
+    info = golden[f"{tag}_info"]
+    assert [int(r.converged), r.nr_iterations, r.n_linearize, r.n_compute_error] == list(info)
+    te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+    assert te < 1e-7 and re_ < 1e-7
+    assert rel_err(r.final_hessian(), golden[f"{tag}_final_hessian"]) < 1e-9
+
+
+def test_align_golden_numpy_launch(golden, scene):
+    n = O.FastAPDGICP(O.Params(**LAUNCH))
+    n.setInputSource(golden["lin_source"])
+    n.setInputTarget(golden["lin_target"])
+    T = n.align(golden["lin_guess"])
+    assert [int(n.converged), n.nr_iterations, n.trace.n_linearize, n.trace.n_compute_error] == list(golden["lm_launch_info"])
+    te, re_ = scene.pose_error(golden["lm_launch_T"], T)
+    assert te < 1e-5 and re_ < 1e-5
+
+
+def test_degenerate_golden_cpp(golden):
+    r = R.RefAPDGICP(R.default_params(max_correspondence_distance=2.0))
+    r.setInputSource(golden["deg_source"])
+    r.setInputTarget(golden["deg_target"])
+    cost, H, b = r.linearize(np.eye(4))
+    corr, sqd = r.correspondences()
+    assert np.array_equal(corr, golden["deg_corr"]) and corr[2] == -1
+    assert rel_err(H, golden["deg_H"]) < 1e-10 and rel_err(b, golden["deg_b"]) < 1e-10
+    M = r.mahalanobis()
+    assert np.all(M[2] == 0)
+    # +x-axis point: APD sigma_y,z ~ dist*sin(var)/cos(AoA) is huge -> tiny information in y/z
+    assert M[0][1, 1] < 1e-3 * M[0][0, 0] or M[0][1, 1] < 1e-2
+
+
+@pytest.mark.parametrize("tag,kw", (("rej", {}), ("fail", dict(lm_max_iterations=1))))
+def test_lm_rejection_paths_cpp(golden, scene, tag, kw):
+    r = R.RefAPDGICP(R.default_params(**kw))
+    r.setInputSource(golden["rej_source"])
+    r.setInputTarget(golden["rej_target"])
+    T = r.align(None)
+    assert [int(r.converged), r.nr_iterations, r.n_linearize, r.n_compute_error] == list(golden[f"{tag}_info"])
+    assert (golden[f"{tag}_trace_rho"] < 0).any()
+    te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+    assert te < 1e-6 and re_ < 1e-8
+    if tag == "fail":
+        assert not r.converged and r.nr_iterations < 63
+
+
+def test_too_few_points_is_an_error():
+    r = R.RefAPDGICP()
+    r.setInputSource(np.zeros((5, 3), dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        r.covariances("source")
+
+
+def test_scene_is_deterministic(scene):
+    a = scene.make_pair(512, 640, scene.pair_seed(9, 3), "odometry")
+    b = scene.make_pair(512, 640, scene.pair_seed(9, 3), "odometry")
+    assert a[0].shape == (512, 3) and a[1].shape == (640, 3) and a[0].dtype == np.float32
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    r = np.linalg.norm(a[0], axis=1)
+    assert r.min() > 1.5 and r.max() < 103
