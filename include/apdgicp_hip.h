@@ -1,0 +1,193 @@
+/*
+ * apdgicp_hip.h -- C ABI of libapdgicp_hip.so: RIV-SLAM's APD-GICP scan matcher on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of Wayne-DWA/RIV-SLAM: fast_gicp::FastAPDGICP
+ * behind pcl::Registration, as selected by select_registration_method()
+ * (radar_graph_slam/src/radar_graph_slam/registrations.cpp:38-50).  Each entry point names the
+ * reference member it replaces; "A:" = fast_apdgicp/include/fast_gicp/gicp/impl/fast_apdgicp_impl.hpp,
+ * "L:" = .../gicp/impl/lsq_registration_impl.hpp, "H:" = .../gicp/fast_apdgicp.hpp.
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, PODs.  No C++/torch types.  All functions return 0 on success and a
+ *     negative apdgicp_status on failure; apdgicp_last_error() gives the message (thread-local).
+ *     Nothing aborts or throws.  Registration failure is DATA (result.converged == 0), like
+ *     hasConverged() in the reference (L:71-75), not an error code.
+ *   - 4x4 matrices are COLUMN-MAJOR (Eigen::Matrix4f / Matrix4d memory layout): m[row + 4*col].
+ *     6x6 H is column-major too (symmetric anyway); b is [rot(3), trans(3)] as in A:248-250.
+ *   - Points: `xyz` is the address of the first x; consecutive points are `stride_bytes` apart
+ *     (12 for packed xyz, 16 for float4, 32 for pcl::PointXYZI).  Only x,y,z are read
+ *     (intensity is never touched on this path).  Points must be finite.
+ *   - `on_device` != 0 means `xyz` is a device (HIP) pointer on the handle's device; the data is
+ *     copied into the handle's own buffers either way, so the caller may free/reuse its buffer when
+ *     the call returns (host) / when the handle's stream has passed the call (device).
+ *   - A handle is single-caller (one thread at a time), owns one HIP stream and no global state;
+ *     any number of handles may live in one process and be used from different threads.
+ */
+#ifndef APDGICP_HIP_H
+#define APDGICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APDGICP_ABI_VERSION 1
+
+typedef enum {
+  APDGICP_OK = 0,
+  APDGICP_ERR_INVALID_ARG = -1,   /* null pointer, bad size, k out of range ... */
+  APDGICP_ERR_HIP = -2,           /* a HIP runtime call failed (no device, OOM, launch failure) */
+  APDGICP_ERR_NO_INPUT = -3,      /* source/target (or correspondences) not set yet */
+  APDGICP_ERR_TOO_FEW_POINTS = -4,/* cloud has fewer than k_correspondences points (reference: UB, A:318-321) */
+  APDGICP_ERR_UNSUPPORTED = -5,   /* e.g. k_correspondences > 32, unknown regularization (reference aborts, A:341-343) */
+  APDGICP_ERR_INTERNAL = -6
+} apdgicp_status;
+
+/* fast_gicp::RegularizationMethod, gicp/gicp_settings.hpp:6 (same numeric values) */
+typedef enum {
+  APDGICP_REG_NONE = 0,
+  APDGICP_REG_MIN_EIG = 1,
+  APDGICP_REG_NORMALIZED_MIN_EIG = 2,
+  APDGICP_REG_PLANE = 3,
+  APDGICP_REG_FROBENIUS = 4
+} apdgicp_regularization;
+
+/* fast_gicp::LSQ_OPTIMIZER_TYPE, gicp/lsq_registration.hpp:13 (reference default: LM, L:17) */
+typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
+
+/* Every tunable the reference object has.  Defaults (apdgicp_default_params) are the class
+ * defaults: A:14-28, H:107-109, L:11-24.  The ROS factory overrides some of them
+ * (registrations.cpp:41-48). */
+typedef struct {
+  int32_t k_correspondences;            /* setCorrespondenceRandomness, A:45 ; default 20 ; 3..32 */
+  int32_t max_iterations;               /* pcl setMaximumIterations ; default 64, L:13 */
+  int32_t lm_max_iterations;            /* L:19 ; default 10 */
+  int32_t optimizer;                    /* apdgicp_optimizer ; default LM */
+  int32_t regularization;               /* apdgicp_regularization ; default PLANE, A:25 */
+  int32_t reserved;
+  double max_correspondence_distance;   /* pcl setMaxCorrespondenceDistance ; default FLT_MAX, A:23 */
+  double transformation_epsilon;        /* pcl setTransformationEpsilon ; default 5e-4, L:15 */
+  double rotation_epsilon;              /* setRotationEpsilon, L:30 ; default 2e-3 */
+  double lm_init_lambda_factor;         /* setInitialLambdaFactor, L:35 ; default 1e-9 */
+  double distance_variance;             /* setDistVar, A:63 ; default 0.86 */
+  double azimuth_variance_deg;          /* setAzimuthVar, A:55 ; default 0.5 */
+  double elevation_variance_deg;        /* setElevationVar, A:59 ; default 1.0 */
+} apdgicp_params;
+
+/* What align() reports.  converged/iterations mirror pcl::Registration::converged_ /
+ * nr_iterations_ as written by L:59,68,75 ; T is final_transformation_ (L:78). */
+typedef struct {
+  float T[16];                 /* column-major source->target */
+  double final_cost;           /* last linearize() cost y0 (sum of e^T M e), for logging */
+  int32_t converged;
+  int32_t iterations;          /* nr_iterations_: zero-based index of the last outer iteration */
+  int32_t n_linearize;         /* number of linearize() evaluations (A:198) */
+  int32_t n_compute_error;     /* number of compute_error() evaluations (A:275) */
+  int32_t lm_failed;           /* 1 when step_lm exhausted lm_max_iterations ("lm not converged!!", L:71-74) */
+  int32_t n_matched;           /* correspondences inside the gate at the last linearize (A:156) */
+} apdgicp_result;
+
+typedef struct apdgicp_handle apdgicp_handle;   /* one registration object == one FastAPDGICP */
+typedef struct apdgicp_batch apdgicp_batch;     /* many independent registrations on one GPU */
+
+enum { APDGICP_SOURCE = 0, APDGICP_TARGET = 1 };
+
+/* ------------------------------------------------------------------ library */
+int apdgicp_abi_version(void);
+const char* apdgicp_last_error(void);
+int apdgicp_device_count(int* count);
+void apdgicp_default_params(apdgicp_params* p);                                  /* A:14-28, L:11-24 */
+
+/* ------------------------------------------------------------------ single registration object */
+/* FastAPDGICP::FastAPDGICP() (A:14).  `stream` may be NULL (the handle creates its own) or a
+ * hipStream_t the caller owns. */
+int apdgicp_create(const apdgicp_params* p, int device, void* stream, apdgicp_handle** out);
+int apdgicp_destroy(apdgicp_handle* h);                                           /* ~FastAPDGICP */
+int apdgicp_set_params(apdgicp_handle* h, const apdgicp_params* p);               /* the setters A:34-65, L:30-37 */
+int apdgicp_get_params(const apdgicp_handle* h, apdgicp_params* p);
+
+/* setInputSource / setInputTarget (A:90-108).  `token` is the caller's identity of the cloud
+ * (the adapter passes the shared_ptr's raw address): a call with the token already held is the
+ * reference's pointer-equality early return and keeps the cached covariances; token 0 never matches. */
+int apdgicp_set_source(apdgicp_handle* h, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token);
+int apdgicp_set_target(apdgicp_handle* h, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token);
+int apdgicp_clear_source(apdgicp_handle* h);                                      /* A:78-81 */
+int apdgicp_clear_target(apdgicp_handle* h);                                      /* A:84-87 */
+int apdgicp_swap_source_and_target(apdgicp_handle* h);                            /* A:68-75 */
+
+/* calculate_covariances (A:303-363), normally run lazily by align (A:122-127).  which = APDGICP_SOURCE/TARGET */
+int apdgicp_compute_covariances(apdgicp_handle* h, int which);
+/* getSourceCovariances / getTargetCovariances (H:67-73): n x 16 doubles, each a column-major 4x4
+ * with zero 4th row/column, exactly the reference's std::vector<Matrix4d> memory. */
+int apdgicp_get_covariances(apdgicp_handle* h, int which, double* out_n16, int64_t n);
+/* setSourceCovariances / setTargetCovariances (A:111-118) */
+int apdgicp_set_covariances(apdgicp_handle* h, int which, const double* in_n16, int64_t n);
+
+/* linearize (A:198-272) at pose T (the public probe is LsqRegistration::evaluateCost, L:50-52).
+ * H and b may both be NULL (cost only, A:242-244).  Updates the correspondences and Mahalanobis
+ * matrices held by the handle (update_correspondences, A:133-194). */
+int apdgicp_linearize(apdgicp_handle* h, const double T[16], double H[36], double b[6], double* cost);
+/* compute_error (A:275-298): frozen correspondences / Mahalanobis of the last linearize */
+int apdgicp_compute_error(apdgicp_handle* h, const double T[16], double* cost);
+/* correspondences_ / sq_distances_ (H:104-105) and mahalanobis_ (H:102; n x 16 doubles, zeros for
+ * unmatched points) after the last linearize; any pointer may be NULL */
+int apdgicp_get_correspondences(apdgicp_handle* h, int32_t* corr, float* sq_dist, int64_t n);
+int apdgicp_get_mahalanobis(apdgicp_handle* h, double* out_n16, int64_t n);
+
+/* pcl::Registration::align(output, guess) -> FastAPDGICP::computeTransformation (A:121-130) ->
+ * LsqRegistration::computeTransformation (L:55-80): the whole GN/LM loop runs on the device.
+ * guess may be NULL (identity, as align(output)). */
+int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out);
+/* same loop, but driven from the host through apdgicp_linearize / apdgicp_compute_error exactly
+ * like the reference's virtual calls (L:127-173): the bit-faithful debug path */
+int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_result* out);
+int apdgicp_get_final_hessian(apdgicp_handle* h, double H[36]);                   /* getFinalHessian, L:45 */
+/* pcl::transformPointCloud(*input_, output, final_transformation_) (L:79): writes n xyz triples
+ * `out_stride_bytes` apart into host memory */
+int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xyz, int64_t n, int64_t out_stride_bytes);
+/* pcl::Registration::getFitnessScore(max_range): mean squared 1-NN distance of the T-transformed
+ * source to the target over the points whose SQUARED distance is <= max_range (PCL compares the
+ * squared distance with max_range as is); DBL_MAX when no point qualifies.  Callers:
+ * loop_detector.cpp:229, scan_matching_odometry_nodelet.cpp:698.  n_inliers may be NULL */
+int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range, double* score, int64_t* n_inliers);
+int apdgicp_synchronize(apdgicp_handle* h);
+
+/* ------------------------------------------------------------------ batched registrations
+ * Independent (source, target) pairs -- loop-closure candidates (loop_detector.cpp:222-236,404-423)
+ * or one scan against several keyframes -- solved concurrently on one GPU.  Clouds are registered
+ * once and referenced by index, so a cloud shared by many pairs has its covariances computed once. */
+typedef struct {
+  int32_t source_cloud;
+  int32_t target_cloud;
+  float guess[16];            /* column-major */
+} apdgicp_pair;
+
+int apdgicp_batch_create(const apdgicp_params* p, int device, void* stream, apdgicp_batch** out);
+int apdgicp_batch_destroy(apdgicp_batch* b);
+int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p);
+/* drops all clouds (and their covariances) */
+int apdgicp_batch_clear(apdgicp_batch* b);
+/* returns the cloud's index (>= 0) or a negative status */
+int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
+/* covariances of every cloud that does not have them yet (align does this lazily as well) */
+int apdgicp_batch_compute_covariances(apdgicp_batch* b);
+/* aligns all pairs; results[i] belongs to pairs[i].  `results` is host memory. */
+int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, apdgicp_result* results);
+/* same, but results stay on the device (n_pairs x sizeof(apdgicp_result) bytes at *d_results,
+ * owned by the batch, valid until the next align) and the call does not wait: for callers that
+ * gather results with RCCL.  apdgicp_batch_synchronize() waits for the stream. */
+int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results);
+int apdgicp_batch_synchronize(apdgicp_batch* b);
+/* Measurement hooks (bench.py's roofline leg).  With profiling enabled every launch of the dominant
+ * kernel (brute-force nearest neighbour) is bracketed by HIP events on the batch's stream;
+ * last_nn_time returns their summed milliseconds and the launch count for the last align;
+ * last_ticks returns the number of state-machine ticks and the NN launch shape that was used. */
+int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable);
+int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches);
+int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APDGICP_HIP_H */

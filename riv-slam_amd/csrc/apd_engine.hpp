@@ -1,0 +1,471 @@
+// Host-side engine behind the C ABI: owns the device buffers of a set of clouds and a batch of
+// registrations ("pairs"), launches the kernels of apd_kernels.hpp on one HIP stream and drives the
+// per-pair GN/LM state machines until every pair is done.  No CPU compute path exists here: if HIP
+// is unavailable every entry point fails with APDGICP_ERR_HIP.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/apdgicp_hip.h"
+#include "apd_kernels.hpp"
+
+namespace apd {
+
+static_assert(sizeof(ResultRec) == sizeof(apdgicp_result), "ResultRec must mirror apdgicp_result");
+
+inline thread_local std::string g_last_error;
+inline int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define APD_HIP(expr)                                                                                         \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess)                                                                                     \
+      return fail(APDGICP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+#define APD_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ < 0) return rc_;   \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) {
+      hipError_t e = hipFree(p);
+      (void)e;
+      p = nullptr;
+      cap = 0;
+    }
+    const size_t want = (bytes + 255) & ~size_t(255);
+    APD_HIP(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) {
+      hipError_t e = hipFree(p);
+      (void)e;
+    }
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return (T*)p; }
+};
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+class Engine {
+ public:
+  struct Cloud {
+    DevBuf pts, cov;
+    int n = 0;
+    bool cov_valid = false;
+    uint64_t token = 0;
+  };
+
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  apdgicp_params params;
+  std::vector<Cloud> clouds;
+  bool desc_dirty = true;
+
+  // batch state
+  int npairs = 0, nmax_src = 0;
+  std::vector<PairDesc> h_pairs;
+  DevBuf d_desc, d_pairs, d_state, d_results, d_status, d_guess, d_ids, d_errflag, d_probe, d_stage, d_T;
+  DevBuf b_nnpart, b_corr, b_sqd, b_maha, b_blkpart, b_errpart;
+  Work work{};
+  int nn_S = 2;
+  int* h_status = nullptr;   // pinned
+  double* h_probe = nullptr; // pinned, 48 doubles
+  hipEvent_t ev_poll = nullptr;
+
+  // profiling of the dominant kernel (k_nn_partial)
+  bool profile_nn = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_events;
+  size_t nn_events_used = 0;
+  double last_nn_ms = 0;
+  long long last_nn_launches = 0;
+  int last_ticks = 0;
+
+  int init(const apdgicp_params* p, int dev, void* strm) {
+    int count = 0;
+    APD_HIP(hipGetDeviceCount(&count));
+    if (dev < 0 || dev >= count) return fail(APDGICP_ERR_INVALID_ARG, "device index out of range");
+    device = dev;
+    APD_HIP(hipSetDevice(device));
+    if (strm) {
+      stream = (hipStream_t)strm;
+    } else {
+      APD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      own_stream = true;
+    }
+    APD_HIP(hipHostMalloc((void**)&h_status, 65536 * sizeof(int), hipHostMallocDefault));
+    APD_HIP(hipHostMalloc((void**)&h_probe, 64 * sizeof(double), hipHostMallocDefault));
+    APD_HIP(hipEventCreateWithFlags(&ev_poll, hipEventDisableTiming));
+    APD_TRY(d_errflag.ensure(sizeof(int)));
+    APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+    APD_TRY(d_probe.ensure(64 * sizeof(double)));
+    APD_TRY(d_T.ensure(16 * sizeof(double)));
+    return set_params(p);
+  }
+
+  ~Engine() {
+    hipError_t e;
+    e = hipSetDevice(device);
+    if (stream) e = hipStreamSynchronize(stream);
+    for (auto& c : clouds) c.pts.release(), c.cov.release();
+    for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &b_nnpart,
+                      &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+      b->release();
+    if (h_status) e = hipHostFree(h_status);
+    if (h_probe) e = hipHostFree(h_probe);
+    if (ev_poll) e = hipEventDestroy(ev_poll);
+    for (auto& pr : nn_events) e = hipEventDestroy(pr.first), e = hipEventDestroy(pr.second);
+    if (own_stream && stream) e = hipStreamDestroy(stream);
+    (void)e;
+  }
+
+  int set_params(const apdgicp_params* p) {
+    if (!p) return fail(APDGICP_ERR_INVALID_ARG, "params is null");
+    if (p->k_correspondences < 1 || p->k_correspondences > KNN_NC)
+      return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
+    if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
+    if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
+    const bool cov_change = clouds.size() && (p->k_correspondences != params.k_correspondences || p->regularization != params.regularization);
+    params = *p;
+    if (cov_change)
+      for (auto& c : clouds) c.cov_valid = false;  // covariances depend on k and the regularisation mode
+    return 0;
+  }
+
+  Consts consts() const {
+    Consts c;
+    c.k = params.k_correspondences;
+    c.max_iterations = params.max_iterations;
+    c.lm_max_iterations = params.lm_max_iterations;
+    c.optimizer = params.optimizer;
+    c.regularization = params.regularization;
+    c.thr2 = params.max_correspondence_distance * params.max_correspondence_distance;
+    c.trans_eps = params.transformation_epsilon;
+    c.rot_eps = params.rotation_epsilon;
+    c.lm_init_lambda_factor = params.lm_init_lambda_factor;
+    c.dist_var = params.distance_variance;
+    c.sin_az = std::sin(params.azimuth_variance_deg / 180 * M_PI);   // A:170
+    c.sin_el = std::sin(params.elevation_variance_deg / 180 * M_PI); // A:171
+    return c;
+  }
+
+  // ------------------------------------------------------------------ clouds
+  int set_cloud(int slot, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token) {
+    if (slot < 0) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud slot");
+    if (!xyz || n <= 0) return fail(APDGICP_ERR_INVALID_ARG, "cloud is null or empty");
+    if (n > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud too large");
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
+    APD_HIP(hipSetDevice(device));
+    if ((int)clouds.size() <= slot) clouds.resize(slot + 1);
+    Cloud& c = clouds[slot];
+    // the previous contents may still be in use by queued kernels on this stream; stream order protects us
+    if ((size_t)n * 16 > c.pts.cap) APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(c.pts.ensure((size_t)n * 16));
+    const char* raw = (const char*)xyz;
+    if (!on_device) {
+      const size_t bytes = (size_t)(n - 1) * stride_bytes + 12;
+      APD_HIP(hipStreamSynchronize(stream));  // staging buffer reuse
+      APD_TRY(d_stage.ensure(bytes));
+      APD_HIP(hipMemcpyAsync(d_stage.p, xyz, bytes, hipMemcpyHostToDevice, stream));
+      raw = (const char*)d_stage.p;
+    }
+    hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.pts.as<float4>());
+    APD_HIP(hipGetLastError());
+    if (!on_device) APD_HIP(hipStreamSynchronize(stream));  // the host buffer may be released by the caller now
+    c.n = (int)n;
+    c.cov_valid = false;
+    c.token = token;
+    desc_dirty = true;
+    return 0;
+  }
+
+  void clear_cloud(int slot) {
+    if (slot < (int)clouds.size()) {
+      clouds[slot].n = 0;
+      clouds[slot].cov_valid = false;
+      clouds[slot].token = 0;
+      desc_dirty = true;
+    }
+  }
+
+  int upload_desc() {
+    if (!desc_dirty) return 0;
+    std::vector<CloudDesc> h(clouds.size());
+    for (size_t i = 0; i < clouds.size(); i++) {
+      if (clouds[i].n > 0) APD_TRY(clouds[i].cov.ensure((size_t)clouds[i].n * 6 * sizeof(double)));
+      h[i].pts = clouds[i].pts.as<float4>();
+      h[i].cov = clouds[i].cov.as<double>();
+      h[i].n = clouds[i].n;
+      h[i].pad_ = 0;
+    }
+    APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(d_desc.ensure(std::max<size_t>(1, h.size()) * sizeof(CloudDesc)));
+    APD_HIP(hipMemcpyAsync(d_desc.p, h.data(), h.size() * sizeof(CloudDesc), hipMemcpyHostToDevice, stream));
+    APD_HIP(hipStreamSynchronize(stream));
+    desc_dirty = false;
+    return 0;
+  }
+
+  int check_errflag(const char* what) {
+    int flag = 0;
+    APD_HIP(hipMemcpyAsync(h_status, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    APD_HIP(hipStreamSynchronize(stream));
+    flag = h_status[0];
+    if (flag) {
+      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+      return fail(APDGICP_ERR_INTERNAL, std::string(what) + ": device error flag " + std::to_string(flag));
+    }
+    return 0;
+  }
+
+  // calculate_covariances for every listed cloud that lacks them (A:122-127, A:303-363)
+  int compute_covariances(const std::vector<int>& ids_in, bool force = false) {
+    std::vector<int> ids;
+    int nmax = 0;
+    for (int id : ids_in) {
+      if (id < 0 || id >= (int)clouds.size() || clouds[id].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "cloud not set");
+      if (clouds[id].cov_valid && !force) continue;
+      if (clouds[id].n < params.k_correspondences)
+        return fail(APDGICP_ERR_TOO_FEW_POINTS, "cloud has fewer points than k_correspondences");
+      if (std::find(ids.begin(), ids.end(), id) == ids.end()) ids.push_back(id);
+      nmax = std::max(nmax, clouds[id].n);
+    }
+    if (ids.empty()) return 0;
+    APD_HIP(hipSetDevice(device));
+    APD_TRY(upload_desc());
+    APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(d_ids.ensure(ids.size() * sizeof(int)));
+    APD_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    static bool attr_set = false;
+    if (!attr_set) {
+      APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
+      attr_set = true;
+    }
+    const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)ids.size());
+    hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
+                       params.regularization, d_errflag.as<int>());
+    APD_HIP(hipGetLastError());
+    APD_TRY(check_errflag("k_knn_cov"));
+    for (int id : ids) clouds[id].cov_valid = true;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ batch set-up
+  int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess) {
+    if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
+    APD_HIP(hipSetDevice(device));
+    h_pairs.resize(n);
+    std::vector<float> guesses((size_t)n * 16);
+    std::vector<int> need;
+    nmax_src = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const int s = pairs[i].source_cloud, t = pairs[i].target_cloud;
+      if (s < 0 || t < 0 || s >= (int)clouds.size() || t >= (int)clouds.size() || clouds[s].n <= 0 || clouds[t].n <= 0)
+        return fail(APDGICP_ERR_NO_INPUT, "pair references a cloud that is not set");
+      h_pairs[i] = PairDesc{s, t};
+      memcpy(&guesses[(size_t)i * 16], pairs[i].guess, 16 * sizeof(float));
+      need.push_back(s), need.push_back(t);
+      nmax_src = std::max(nmax_src, clouds[s].n);
+    }
+    APD_TRY(compute_covariances(need));
+    APD_TRY(upload_desc());
+    npairs = (int)n;
+    APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(d_pairs.ensure(n * sizeof(PairDesc)));
+    APD_TRY(d_state.ensure(n * sizeof(PairState)));
+    APD_TRY(d_results.ensure(n * sizeof(ResultRec)));
+    APD_TRY(d_status.ensure(n * sizeof(int)));
+    APD_TRY(d_guess.ensure(n * 16 * sizeof(float)));
+    APD_HIP(hipMemcpyAsync(d_pairs.p, h_pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+    if (with_guess) APD_HIP(hipMemcpyAsync(d_guess.p, guesses.data(), guesses.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    APD_HIP(hipStreamSynchronize(stream));  // `guesses` is a local
+
+    // launch shape of the NN kernel: S sources per lane, T target splits (tunable for experiments)
+    const int nchunks_min = 1;
+    (void)nchunks_min;
+    int S = env_int("APDGICP_NN_S", 0);
+    if (S != 2 && S != 4 && S != 8) S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
+    nn_S = S;
+    const int src_blocks = (nmax_src + NN_BLK * S - 1) / (NN_BLK * S);
+    int T = env_int("APDGICP_NN_T", 0);
+    if (T <= 0) T = (512 + npairs * src_blocks - 1) / (npairs * src_blocks);
+    T = std::max(1, std::min(T, 64));
+    work.T = T;
+    work.nstride = (nmax_src + 255) & ~255;
+    work.nblk_max = (nmax_src + LIN_BLK - 1) / LIN_BLK;
+    const size_t ns = work.nstride;
+    APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
+    APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
+    APD_TRY(b_sqd.ensure((size_t)npairs * ns * 4));
+    APD_TRY(b_maha.ensure((size_t)npairs * 6 * ns * 8));
+    APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
+    APD_TRY(b_errpart.ensure((size_t)npairs * work.nblk_max * 8));
+    work.nnpart = b_nnpart.as<unsigned long long>();
+    work.corr = b_corr.as<int>();
+    work.sqd = b_sqd.as<float>();
+    work.maha = b_maha.as<double>();
+    work.blkpart = b_blkpart.as<double>();
+    work.errpart = b_errpart.as<double>();
+    return 0;
+  }
+
+  int launch_nn() {
+    const int src_blocks = (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
+    const dim3 grid((unsigned)src_blocks, (unsigned)work.T, (unsigned)npairs);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile_nn) {
+      if (nn_events_used == nn_events.size()) {
+        hipEvent_t a, b;
+        APD_HIP(hipEventCreate(&a));
+        APD_HIP(hipEventCreate(&b));
+        nn_events.emplace_back(a, b);
+      }
+      e0 = nn_events[nn_events_used].first, e1 = nn_events[nn_events_used].second;
+      nn_events_used++;
+      APD_HIP(hipEventRecord(e0, stream));
+    }
+    const CloudDesc* cd = d_desc.as<CloudDesc>();
+    const PairDesc* pd = d_pairs.as<PairDesc>();
+    const PairState* st = d_state.as<PairState>();
+    if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
+    else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
+    else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
+    if (profile_nn) APD_HIP(hipEventRecord(e1, stream));
+    return 0;
+  }
+
+  int launch_linearize(bool want_Hb) {
+    const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
+    hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                       consts(), want_Hb ? 1 : 0);
+    return 0;
+  }
+
+  int launch_error() {
+    const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
+    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work);
+    return 0;
+  }
+
+  // one tick of every pair's state machine
+  int launch_tick() {
+    const Consts c = consts();
+    APD_TRY(launch_nn());
+    APD_TRY(launch_linearize(true));
+    hipLaunchKernelGGL(k_lm_solve, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work, c);
+    if (params.optimizer == APDGICP_OPT_LM) {
+      APD_TRY(launch_error());
+      hipLaunchKernelGGL(k_lm_decide, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                         c);
+    }
+    return 0;
+  }
+
+  int collect_nn_profile() {
+    last_nn_ms = 0;
+    last_nn_launches = 0;
+    for (size_t i = 0; i < nn_events_used; i++) {
+      float ms = 0;
+      APD_HIP(hipEventElapsedTime(&ms, nn_events[i].first, nn_events[i].second));
+      last_nn_ms += ms;
+      last_nn_launches++;
+    }
+    return 0;
+  }
+
+  // L:55-80 for every pair; leaves ResultRec[npairs] in d_results.  Blocks until all pairs are done
+  // (the loop length is data dependent), polling the device every few ticks.
+  int run_align() {
+    APD_HIP(hipSetDevice(device));
+    nn_events_used = 0;
+    hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
+                       params.max_iterations);
+    const bool lm = params.optimizer == APDGICP_OPT_LM;
+    const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
+    const int chunk = std::max(1, env_int("APDGICP_POLL_TICKS", lm ? 4 : 8));
+    long long ticks = 0;
+    bool all_done = params.max_iterations <= 0;
+    while (!all_done && ticks < tick_cap) {
+      // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
+      const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
+      for (int t = 0; t < todo; t++) APD_TRY(launch_tick());
+      ticks += todo;
+      hipLaunchKernelGGL(k_copy_status, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_state.as<PairState>(), d_status.as<int>(), npairs);
+      APD_HIP(hipMemcpyAsync(h_status, d_status.p, npairs * sizeof(int), hipMemcpyDeviceToHost, stream));
+      APD_HIP(hipEventRecord(ev_poll, stream));
+      APD_HIP(hipEventSynchronize(ev_poll));
+      all_done = true;
+      for (int p = 0; p < npairs; p++) all_done &= (h_status[p] == ST_DONE);
+    }
+    last_ticks = (int)ticks;
+    hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), (int*)nullptr,
+                       npairs);
+    APD_HIP(hipGetLastError());
+    if (profile_nn) {
+      APD_HIP(hipStreamSynchronize(stream));
+      APD_TRY(collect_nn_profile());
+    }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ probes on pair 0
+  int probe_linearize(const double T[16], double* H, double* b, double* cost, int* matched) {
+    APD_HIP(hipSetDevice(device));
+    APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_LIN, 0);
+    APD_TRY(launch_nn());
+    APD_TRY(launch_linearize(H && b));
+    hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                       d_probe.as<double>(), 0);
+    APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    APD_HIP(hipStreamSynchronize(stream));
+    if (H && b) {
+      memcpy(H, h_probe, 36 * sizeof(double));
+      memcpy(b, h_probe + 36, 6 * sizeof(double));
+    }
+    if (cost) *cost = h_probe[42];
+    if (matched) *matched = (int)h_probe[43];
+    return 0;
+  }
+
+  int probe_error(const double T[16], double* cost) {
+    APD_HIP(hipSetDevice(device));
+    APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_ERR, 1);
+    APD_TRY(launch_error());
+    hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                       d_probe.as<double>(), 1);
+    APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    APD_HIP(hipStreamSynchronize(stream));
+    *cost = h_probe[42];
+    return 0;
+  }
+};
+
+}  // namespace apd

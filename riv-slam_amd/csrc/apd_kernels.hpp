@@ -1,0 +1,820 @@
+// Hand-written HIP kernels for the APD-GICP hot path on gfx950 (MI355X, wave64).
+//
+// Reference path (citations relative to /root/reference/fast_apdgicp/include/fast_gicp/):
+//   A = gicp/impl/fast_apdgicp_impl.hpp, L = gicp/impl/lsq_registration_impl.hpp
+//
+//   k_pack_points      PointXYZI/xyz strided -> float4 {x,y,z,1} (getVector4fMap, A:149)
+//   k_knn_cov          calculate_covariances, A:303-363  (exact k-NN + 3x3 eigen + regularisation)
+//   k_nn_partial       the 1-NN search of update_correspondences, A:149-153 (brute force, LDS tiles)
+//   k_linearize        rest of update_correspondences A:156-192 + linearize A:221-260
+//   k_error            compute_error, A:275-298
+//   k_lm_solve/decide  LsqRegistration::step_gn / step_lm, L:107-173, one lane per registration
+//   k_finalize         final_transformation_ = x0.cast<float>(), L:78
+//
+// All kernels are batched: the registration ("pair") index is a grid dimension and every pair
+// carries its own state machine, so a whole batch of GN/LM loops advances without host round trips.
+// The whole file is compiled with -ffp-contract=off: the fp32 nearest-neighbour arithmetic must not
+// be fused (the reference is built without FMA and FLANN's L2_Simple is mul+add).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "apd_math.hpp"
+
+namespace apd {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+struct CloudDesc {
+  const float4* pts;   // n x {x,y,z,1}
+  double* cov;         // SoA [6][n]: xx,xy,xz,yy,yz,zz (top-left 3x3 of the reference's Matrix4d)
+  int n;
+  int pad_;
+};
+
+struct PairDesc {
+  int src, tgt;
+};
+
+struct Consts {
+  int k, max_iterations, lm_max_iterations, optimizer, regularization;
+  double thr2;       // corr_dist_threshold_^2 in double (A:156)
+  double trans_eps, rot_eps, lm_init_lambda_factor;
+  double dist_var, sin_az, sin_el;  // A:169-171
+};
+
+enum { ST_NEED_LIN = 0, ST_NEED_ERR = 1, ST_DONE = 2 };
+
+struct PairState {
+  Rigid x0, xi, delta;
+  double H[36], b[6], d[6], final_H[36];
+  double y0, yi, lambda, nu;
+  int status, converged, iter, inner, n_lin, n_err, failed, n_matched;
+};
+
+// result record, identical to apdgicp_result in include/apdgicp_hip.h (static_assert'ed in the engine)
+struct ResultRec {
+  float T[16];
+  double final_cost;
+  int converged, iterations, n_linearize, n_compute_error, lm_failed, n_matched;
+};
+
+constexpr int kRed = 32;        // doubles per block partial: 21 H + 6 b + cost + matched + pad
+constexpr int kChunk = 16;      // NN index granularity: the winner is located inside a 16-target chunk
+constexpr unsigned kNoChunk = 0xFFFFFFFFu;
+
+struct Work {
+  unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
+  int* corr;                   // [pair][nstride]   correspondences_ (A:156)
+  float* sqd;                  // [pair][nstride]   sq_distances_ (A:153)
+  double* maha;                // [pair][6][nstride] mahalanobis_ upper triangle (A:191)
+  double* blkpart;             // [pair][nblk_max][kRed]
+  double* errpart;             // [pair][nblk_max]
+  int nstride, nblk_max, T;
+};
+
+// ----------------------------------------------------------------------------------------------
+// fp32 helpers: the exact operation order of the reference (see oracle/apdgicp_ref.cpp)
+__device__ __forceinline__ void load_Tf(const Rigid& T, float Tf[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) Tf[i] = (float)T.m[i];  // trans.cast<float>(), A:137
+}
+__device__ __forceinline__ float xf_row(const float* r, float x, float y, float z) { return ((r[0] * x + r[1] * y) + r[2] * z) + r[3]; }
+
+__device__ __forceinline__ float sqdist1(float tx, float ty, float tz, float px, float py, float pz) {
+  const float dx = tx - px, dy = ty - py, dz = tz - pz;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+__global__ void k_pack_points(const char* raw, long long stride_bytes, int n, float4* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = (const float*)(raw + (long long)i * stride_bytes);
+  out[i] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+
+__global__ void k_unpack_cov(const double* cov6, int n, double* out16) {  // -> n x Matrix4d (column-major)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double xx = cov6[i], xy = cov6[n + i], xz = cov6[2 * n + i], yy = cov6[3 * n + i], yz = cov6[4 * n + i], zz = cov6[5 * n + i];
+  double* o = out16 + 16ll * i;
+  o[0] = xx, o[1] = xy, o[2] = xz, o[3] = 0;
+  o[4] = xy, o[5] = yy, o[6] = yz, o[7] = 0;
+  o[8] = xz, o[9] = yz, o[10] = zz, o[11] = 0;
+  o[12] = 0, o[13] = 0, o[14] = 0, o[15] = 0;
+}
+
+__global__ void k_pack_cov(const double* in16, int n, double* cov6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* o = in16 + 16ll * i;
+  cov6[i] = o[0], cov6[n + i] = o[4], cov6[2 * n + i] = o[8], cov6[3 * n + i] = o[5], cov6[4 * n + i] = o[9], cov6[5 * n + i] = o[10];
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_knn_cov: exact k nearest neighbours of every point inside its own cloud (self included), then
+// population covariance and regularisation.  One thread per query, candidates streamed through
+// LDS tiles (wave-uniform address -> broadcast ds_read_b128).
+//   sweep 1: minima of 32 index-strided candidate classes.  k distinct points lie within the k-th
+//            smallest of those minima, so it bounds the k-th neighbour distance (tau).
+//   sweep 2: collect every candidate with (d, idx) <= tau into a per-thread LDS list (expected
+//            ~1.5 k entries); on overflow tau is tightened from the list and the sweep repeats.
+//   select : k rounds of lexicographic (d, idx) min-extraction; accumulate sums in fp64.
+constexpr int KNN_BLK = 128, KNN_CAP = 64, KNN_NC = 32, KNN_TILE = 1024;
+constexpr int KNN_LDS_BYTES = KNN_TILE * 16 + KNN_CAP * KNN_BLK * 8;
+
+__device__ __forceinline__ void knn_load_tile(float4* tile, const float4* pts, int t0, int n, int tid) {
+  const float inf = __builtin_inff();
+  for (int e = tid; e < KNN_TILE; e += KNN_BLK) {
+    const int j = t0 + e;
+    tile[e] = j < n ? pts[j] : make_float4(inf, inf, inf, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* tile = (float4*)smem;
+  int* lst_i = (int*)(smem + KNN_TILE * 16);
+  float* lst_d = (float*)(lst_i + KNN_CAP * KNN_BLK);
+
+  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  double* cov = c.cov;
+  const int n = c.n, tid = threadIdx.x;
+  if ((int)(blockIdx.x * KNN_BLK) >= n) return;  // block-uniform
+  const int i = blockIdx.x * KNN_BLK + tid;
+  const bool valid = i < n;
+  const float4 q = c.pts[valid ? i : n - 1];
+  const float inf = __builtin_inff();
+
+  // ---- sweep 1
+  float cm[KNN_NC];
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
+  for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+    __syncthreads();
+    knn_load_tile(tile, c.pts, t0, n, tid);
+    __syncthreads();
+    const int cnt = min(KNN_TILE, (n - t0 + KNN_NC - 1) / KNN_NC * KNN_NC);
+    for (int jj = 0; jj < cnt; jj += KNN_NC) {
+#pragma unroll
+      for (int s = 0; s < KNN_NC; s++) {
+        const float4 t = tile[jj + s];
+        cm[s] = fminf(cm[s], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
+      }
+    }
+  }
+  // bitonic sort of the 32 minima (static indices only)
+#pragma unroll
+  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int a = 0; a < KNN_NC; a++) {
+        const int l = a ^ j;
+        if (l > a) {
+          const bool up = (a & kk) == 0;
+          const float x = cm[a], y = cm[l];
+          const float lo = fminf(x, y), hi = fmaxf(x, y);
+          cm[a] = up ? lo : hi;
+          cm[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+  float tau_d = inf;
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++)
+    if (s == k - 1) tau_d = cm[s];
+  int tau_i = 0x7fffffff;
+
+  // ---- sweep 2 (+ tightening restarts)
+  bool need = valid;
+  int cnt_final = 0;
+  for (int round = 0;; round++) {
+    int cnt = 0;
+    for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+      __syncthreads();
+      knn_load_tile(tile, c.pts, t0, n, tid);
+      __syncthreads();
+      const int m = min(KNN_TILE, n - t0);
+      if (need) {
+#pragma unroll 4
+        for (int jj = 0; jj < m; jj++) {
+          const float4 t = tile[jj];
+          const float d = sqdist1(t.x, t.y, t.z, q.x, q.y, q.z);
+          const int j = t0 + jj;
+          if (d < tau_d || (d == tau_d && j <= tau_i)) {
+            if (cnt < KNN_CAP) {
+              lst_i[cnt * KNN_BLK + tid] = j;
+              lst_d[cnt * KNN_BLK + tid] = d;
+            }
+            cnt++;
+          }
+        }
+      }
+    }
+    bool ovf = false;
+    if (need) {
+      ovf = cnt > KNN_CAP;
+      cnt_final = min(cnt, KNN_CAP);
+      if (ovf) {  // tighten tau to the k-th smallest (d, idx) of the stored entries
+        float last_d = -1.f;
+        int last_i = -1;
+        for (int r = 0; r < k; r++) {
+          float bd = inf;
+          int bi = 0x7fffffff;
+          for (int a = 0; a < KNN_CAP; a++) {
+            const float d = lst_d[a * KNN_BLK + tid];
+            const int ii = lst_i[a * KNN_BLK + tid];
+            const bool gt = d > last_d || (d == last_d && ii > last_i);
+            const bool lt = d < bd || (d == bd && ii < bi);
+            if (gt && lt) bd = d, bi = ii;
+          }
+          last_d = bd, last_i = bi;
+        }
+        tau_d = last_d, tau_i = last_i;
+      }
+    }
+    need = ovf;
+    if (!__syncthreads_or(ovf ? 1 : 0)) break;
+    if (round >= 32) {  // cannot happen: every restart strictly shrinks the candidate set
+      if (tid == 0) atomicExch(err_flag, 1);
+      break;
+    }
+  }
+  if (!valid) return;
+
+  // ---- select the k nearest, accumulate in fp64 relative to the query point (differences of
+  // fp32 numbers are exact in fp64); cov = S2/k - mean*mean^T  ==  A:323-324
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  {
+    float last_d = -1.f;
+    int last_i = -1;
+    for (int r = 0; r < k; r++) {
+      float bd = inf;
+      int bi = 0x7fffffff;
+      for (int a = 0; a < cnt_final; a++) {
+        const float d = lst_d[a * KNN_BLK + tid];
+        const int ii = lst_i[a * KNN_BLK + tid];
+        const bool gt = d > last_d || (d == last_d && ii > last_i);
+        const bool lt = d < bd || (d == bd && ii < bi);
+        if (gt && lt) bd = d, bi = ii;
+      }
+      last_d = bd, last_i = bi;
+      if (bi == 0x7fffffff) {  // fewer than k candidates: impossible when n >= k
+        atomicExch(err_flag, 2);
+        break;
+      }
+      const float4 p = c.pts[bi];
+      const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
+      s1x += x, s1y += y, s1z += z;
+      sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+    }
+  }
+  const double ik = 1.0 / (double)k;
+  const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
+  Sym3 pc;
+  pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
+  pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
+  Sym3 out;
+  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+  cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_nn_partial: brute-force nearest neighbour of T*p_i in the target (A:149-153), exact fp32
+// difference form.  grid = (source blocks, target splits, pairs); block = 256 lanes, S sources per
+// lane held as packed float2 registers so the distance math issues as v_pk_{add,mul}_f32.
+// A block stages its target split through LDS in 1024-point tiles; all lanes of a wave read the
+// same target (broadcast ds_read_b128).  The running minimum is kept per 16-target chunk
+// (v_min3_f32) and the winning chunk id, not the index, is tracked: k_linearize re-scans that one
+// chunk to recover the exact index (lowest index on ties).
+constexpr int NN_BLK = 256, NN_TILE = 1024;
+
+template <int S>
+__global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  static_assert(S % 2 == 0, "S must be even");
+  // LDS tile, two targets per entry: {x0,x1,y0,y1} (ds_read_b128) + {z0,z1} (ds_read_b64): every byte read is
+  // used and each coordinate pair sits in one 64-bit register pair for the v_pk op_sel splats.
+  __shared__ float4 txy[NN_TILE / 2];
+  __shared__ float2 tz[NN_TILE / 2];
+  const int pair = blockIdx.z;
+  if (st[pair].status != ST_NEED_LIN) return;
+  const PairDesc pd = pairs[pair];
+  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const int N = src.n, M = tgt.n, tid = threadIdx.x;
+  const int base = blockIdx.x * (NN_BLK * S);
+  if (base >= N) return;
+  float Tf[12];
+  load_Tf(st[pair].x0, Tf);
+
+  float2v px[S / 2], py[S / 2], pz[S / 2];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const int i = base + s * NN_BLK + tid;
+    const float4 p = src.pts[i < N ? i : N - 1];
+    const float x = xf_row(Tf + 0, p.x, p.y, p.z), y = xf_row(Tf + 4, p.x, p.y, p.z), z = xf_row(Tf + 8, p.x, p.y, p.z);
+    if (s & 1) px[s / 2].y = x, py[s / 2].y = y, pz[s / 2].y = z;
+    else px[s / 2].x = x, py[s / 2].x = y, pz[s / 2].x = z;
+  }
+  const float inf = __builtin_inff();
+  float best[S];
+  unsigned bestc[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) best[s] = inf, bestc[s] = kNoChunk;
+
+  const int nchunks = (M + kChunk - 1) / kChunk;
+  const int per = (nchunks + w.T - 1) / w.T;
+  const int c0 = blockIdx.y * per, c1 = min(c0 + per, nchunks);
+  for (int tc0 = c0; tc0 < c1; tc0 += NN_TILE / kChunk) {
+    __syncthreads();
+    const int jend = min(c1 * kChunk, M);
+    for (int e = tid; e < NN_TILE / 2; e += NN_BLK) {
+      const int j = tc0 * kChunk + 2 * e;
+      const float4 a = j < jend ? tgt.pts[j] : make_float4(inf, inf, inf, 0.f);
+      const float4 b = j + 1 < jend ? tgt.pts[j + 1] : make_float4(inf, inf, inf, 0.f);
+      txy[e] = make_float4(a.x, b.x, a.y, b.y);
+      tz[e] = make_float2(a.z, b.z);
+    }
+    __syncthreads();
+    const int nch = min(NN_TILE / kChunk, c1 - tc0);
+    for (int ch = 0; ch < nch; ch++) {
+      float m[S];
+#pragma unroll
+      for (int s = 0; s < S; s++) m[s] = inf;
+#pragma unroll
+      for (int jj = 0; jj < kChunk / 2; jj++) {
+        const float4 A = txy[ch * (kChunk / 2) + jj];
+        const float2 Z = tz[ch * (kChunk / 2) + jj];
+#pragma unroll
+        for (int sp = 0; sp < S / 2; sp++) {
+          float2v dx = A.x - px[sp], dy = A.z - py[sp], dz = Z.x - pz[sp];
+          float2v d0 = dx * dx;
+          d0 = d0 + dy * dy;
+          d0 = d0 + dz * dz;
+          dx = A.y - px[sp], dy = A.w - py[sp], dz = Z.y - pz[sp];
+          float2v d1 = dx * dx;
+          d1 = d1 + dy * dy;
+          d1 = d1 + dz * dz;
+          m[2 * sp] = fminf(fminf(m[2 * sp], d0.x), d1.x);
+          m[2 * sp + 1] = fminf(fminf(m[2 * sp + 1], d0.y), d1.y);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        if (m[s] < best[s]) best[s] = m[s], bestc[s] = (unsigned)(tc0 + ch);
+      }
+    }
+  }
+  unsigned long long* out = w.nnpart + ((size_t)pair * w.T + blockIdx.y) * w.nstride;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const int i = base + s * NN_BLK + tid;
+    if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// block reduction of R doubles per lane: wave shuffle tree, then LDS across the block's waves.
+// Fixed order -> bitwise reproducible (the reference's per-thread slots are not, A:262-269).
+template <int R, int BLK>
+__device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][R] */, int tid) {
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    double x = v[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    v[r] = x;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; r++) lds[wave * R + r] = v[r];
+  }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_linearize: one lane per source point.  Merges the split partials, re-scans the winning chunk
+// for the exact correspondence, applies the gate (A:156), builds the APD covariance (A:167-184),
+// RCR and its inverse (A:188-192, stored for k_error), then e, J, H, b (A:229-258) and reduces
+// 21+6+1 sums per block.  fp64 throughout after the NN, as in the reference.
+constexpr int LIN_BLK = 256;
+
+__global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w, Consts cst,
+                                                       int want_Hb) {
+  __shared__ double red[(LIN_BLK / 64) * 29];
+  const int pair = blockIdx.y;
+  if (st[pair].status != ST_NEED_LIN) return;
+  const PairDesc pd = pairs[pair];
+  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const int N = src.n, M = tgt.n, tid = threadIdx.x;
+  if ((int)(blockIdx.x * LIN_BLK) >= N) return;
+  const int i = blockIdx.x * LIN_BLK + tid;
+  const Rigid T = st[pair].x0;
+
+  double acc[29];
+#pragma unroll
+  for (int r = 0; r < 29; r++) acc[r] = 0.0;
+
+  if (i < N) {
+    unsigned long long bestp = ~0ull;
+    const unsigned long long* part = w.nnpart + (size_t)pair * w.T * w.nstride + i;
+    for (int sp = 0; sp < w.T; sp++) {
+      const unsigned long long v = part[(size_t)sp * w.nstride];
+      bestp = v < bestp ? v : bestp;
+    }
+    const float m = __uint_as_float((unsigned)(bestp >> 32));
+    const unsigned chunk = (unsigned)bestp;
+    float Tf[12];
+    load_Tf(T, Tf);
+    const float4 p = src.pts[i];
+    const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
+    int j = -1;
+    if (chunk != kNoChunk) {
+      float4 t[kChunk];
+#pragma unroll
+      for (int jj = 0; jj < kChunk; jj++) {
+        const int g = (int)chunk * kChunk + jj;
+        t[jj] = tgt.pts[g < M ? g : M - 1];
+      }
+#pragma unroll
+      for (int jj = kChunk - 1; jj >= 0; jj--) {
+        const int g = (int)chunk * kChunk + jj;
+        const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
+        if (g < M && d == m) j = g;  // descending scan: the lowest index wins ties
+      }
+    }
+    w.sqd[(size_t)pair * w.nstride + i] = m;
+    const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
+    w.corr[(size_t)pair * w.nstride + i] = corr;
+    if (corr >= 0) {
+      const double* ca = src.cov;
+      const double* cb = tgt.cov;
+      const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
+      const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
+      // APD sensor-noise covariance from the transformed point (A:167-184)
+      const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
+      const double aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
+      const double cos_aoa = cos(aoa);
+      const double s_x = dist * cst.dist_var / 400;
+      const double s_y = dist * cst.sin_az / cos_aoa;
+      const double s_z = dist * cst.sin_el / cos_aoa;
+      const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
+      const double azimuth = (double)atan2f(pty, ptx);
+      const double ce = cos(elevation), se = sin(elevation), caz = cos(azimuth), saz = sin(azimuth);
+      // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
+      const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
+      const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
+      const double a20 = -se * s_x, a22 = ce * s_z;  // a21 = 0
+      Sym3 cd;
+      cd.xx = a00 * a00 + a01 * a01 + a02 * a02;
+      cd.xy = a00 * a10 + a01 * a11 + a02 * a12;
+      cd.xz = a00 * a20 + a02 * a22;
+      cd.yy = a10 * a10 + a11 * a11 + a12 * a12;
+      cd.yz = a10 * a20 + a12 * a22;
+      cd.zz = a20 * a20 + a22 * a22;
+      const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
+      const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
+      double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
+      mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
+      mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
+
+      const float4 q = tgt.pts[corr];
+      const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
+      const double vx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];   // transed_mean_A, A:236
+      const double vy = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+      const double vz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+      const double ex = (double)q.x - vx, ey = (double)q.y - vy, ez = (double)q.z - vz;  // A:237
+      const double mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
+      const double mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
+      const double mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
+      acc[27] = ex * mex + ey * mey + ez * mez;  // A:240
+      acc[28] = 1.0;
+      if (want_Hb) {
+        // J = [skew(v) | -I] (A:248-250).  MA = M * skew(v), columns:
+        const double m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;     // MA[:,0]
+        const double m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;  // MA[:,1]
+        const double m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;     // MA[:,2]
+        // H upper triangle, row-major order (0,0),(0,1)...(0,5),(1,1)...(5,5)
+        // rotation block skew^T M skew: row p = skew[:,p] . MA[:,q]
+        acc[0] = vz * m0y - vy * m0z;    // (0,0)
+        acc[1] = vz * m1y - vy * m1z;    // (0,1)
+        acc[2] = vz * m2y - vy * m2z;    // (0,2)
+        acc[3] = -m0x;                   // (0,3) = -(MA)[0][0]   (top-right block = -MA^T)
+        acc[4] = -m0y;                   // (0,4) = -(MA)[1][0]
+        acc[5] = -m0z;                   // (0,5)
+        acc[6] = -vz * m1x + vx * m1z;   // (1,1)
+        acc[7] = -vz * m2x + vx * m2z;   // (1,2)
+        acc[8] = -m1x;                   // (1,3)
+        acc[9] = -m1y;                   // (1,4)
+        acc[10] = -m1z;                  // (1,5)
+        acc[11] = vy * m2x - vx * m2y;   // (2,2)
+        acc[12] = -m2x;                  // (2,3)
+        acc[13] = -m2y;                  // (2,4)
+        acc[14] = -m2z;                  // (2,5)
+        acc[15] = Mi.xx, acc[16] = Mi.xy, acc[17] = Mi.xz;  // (3,3),(3,4),(3,5)
+        acc[18] = Mi.yy, acc[19] = Mi.yz;                   // (4,4),(4,5)
+        acc[20] = Mi.zz;                                    // (5,5)
+        // b = J^T M e : rotation part skew^T (Me), translation part -(Me)   (A:254)
+        acc[21] = vz * mey - vy * mez;
+        acc[22] = -vz * mex + vx * mez;
+        acc[23] = vy * mex - vx * mey;
+        acc[24] = -mex, acc[25] = -mey, acc[26] = -mez;
+      }
+    }
+  }
+  block_reduce<29, LIN_BLK>(acc, red, tid);
+  if (tid < 29) {
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv * 29 + tid];
+    w.blkpart[((size_t)pair * w.nblk_max + blockIdx.x) * kRed + tid] = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_error: compute_error (A:275-298) at the trial pose xi with the FROZEN correspondences and
+// Mahalanobis matrices of the last linearize.
+__global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  __shared__ double red[LIN_BLK / 64];
+  const int pair = blockIdx.y;
+  if (st[pair].status != ST_NEED_ERR) return;
+  const PairDesc pd = pairs[pair];
+  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const int N = src.n, tid = threadIdx.x;
+  if ((int)(blockIdx.x * LIN_BLK) >= N) return;
+  const int i = blockIdx.x * LIN_BLK + tid;
+  const Rigid T = st[pair].xi;
+  double acc[1] = {0.0};
+  if (i < N) {
+    const int corr = w.corr[(size_t)pair * w.nstride + i];
+    if (corr >= 0) {
+      const float4 p = src.pts[i], q = tgt.pts[corr];
+      const double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
+      const size_t ns = w.nstride;
+      const double mxx = mo[0], mxy = mo[ns], mxz = mo[2 * ns], myy = mo[3 * ns], myz = mo[4 * ns], mzz = mo[5 * ns];
+      const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
+      const double ex = (double)q.x - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
+      const double ey = (double)q.y - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
+      const double ez = (double)q.z - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
+      acc[0] = ex * (mxx * ex + mxy * ey + mxz * ez) + ey * (mxy * ex + myy * ey + myz * ez) + ez * (mxz * ex + myz * ey + mzz * ez);
+    }
+  }
+  block_reduce<1, LIN_BLK>(acc, red, tid);
+  if (tid == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv];
+    w.errpart[(size_t)pair * w.nblk_max + blockIdx.x] = s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// The Gauss-Newton / Levenberg-Marquardt bookkeeping (L:55-173) as a per-pair state machine.
+__device__ __forceinline__ void lm_trial(PairState& s) {  // L:137-144
+  double H[36], b[6], d[6];
+#pragma unroll
+  for (int q = 0; q < 36; q++) H[q] = s.H[q];
+#pragma unroll
+  for (int q = 0; q < 6; q++) b[q] = s.b[q];
+  solve6_spd(H, s.lambda, b, d);
+#pragma unroll
+  for (int q = 0; q < 6; q++) s.d[q] = d[q];
+  const Rigid delta = make_delta(d);
+  const Rigid x0 = s.x0;
+  s.delta = delta;
+  s.xi = rigid_mul(delta, x0);
+}
+
+// after step_optimize returned `ok` (L:71-75): convergence test and loop bookkeeping
+__device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok) {
+  if (!ok) {  // "lm not converged!!" -> break
+    s.failed = 1;
+    s.status = ST_DONE;
+    return;
+  }
+  s.converged = is_converged(s.delta, c.rot_eps, c.trans_eps) ? 1 : 0;
+  if (s.converged || s.iter + 1 >= c.max_iterations) {
+    s.status = ST_DONE;
+    return;
+  }
+  s.iter += 1;  // nr_iterations_ = i (L:68)
+  s.status = ST_NEED_LIN;
+}
+
+// sums the block partials of k_linearize in block order (deterministic) into s.H / s.b / s.y0
+__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid) {
+  if (tid < 29) {
+    double v = 0.0;
+    const double* p = w.blkpart + (size_t)pair * w.nblk_max * kRed + tid;
+    for (int b = 0; b < nblk; b++) v += p[(size_t)b * kRed];
+    lds[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int q = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c2 = r; c2 < 6; c2++, q++) s.H[r + 6 * c2] = lds[q], s.H[c2 + 6 * r] = lds[q];
+    for (int r = 0; r < 6; r++) s.b[r] = lds[21 + r];
+    s.y0 = lds[27];
+    s.n_matched = (int)lds[28];
+  }
+}
+
+// after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error)
+__global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
+  __shared__ double lds[32];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (st[pair].status != ST_NEED_LIN) return;
+  const int N = clouds[pairs[pair].src].n;
+  const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
+  PairState& s = st[pair];
+  gather_linearize(s, w, pair, nblk, lds, tid);
+  if (tid != 0) return;
+  s.n_lin += 1;
+  if (c.optimizer == 1) {  // step_gn
+    s.lambda = 0.0;
+    lm_trial(s);
+    s.x0 = s.xi;
+    for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
+    step_done(s, c, true);
+    return;
+  }
+  if (s.lambda < 0.0) {  // L:131-133
+    double mx = 0.0;
+    for (int q = 0; q < 6; q++) mx = fmax(mx, fabs(s.H[q + 6 * q]));
+    s.lambda = c.lm_init_lambda_factor * mx;
+  }
+  s.nu = 2.0;
+  s.inner = 0;
+  if (c.lm_max_iterations <= 0) {  // the for loop at L:136 never runs -> return false
+    step_done(s, c, false);
+    return;
+  }
+  lm_trial(s);
+  s.status = ST_NEED_ERR;
+}
+
+// after k_error: L:145-172
+__global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (st[pair].status != ST_NEED_ERR) return;
+  if (tid != 0) return;
+  const int N = clouds[pairs[pair].src].n;
+  const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
+  PairState& s = st[pair];
+  double yi = 0.0;
+  for (int b = 0; b < nblk; b++) yi += w.errpart[(size_t)pair * w.nblk_max + b];
+  s.yi = yi;
+  s.n_err += 1;
+  double den = 0.0;
+  for (int q = 0; q < 6; q++) den += s.d[q] * (s.lambda * s.d[q] - s.b[q]);
+  const double rho = (s.y0 - yi) / den;  // L:146
+  if (rho < 0) {                         // L:156-164
+    if (is_converged(s.delta, c.rot_eps, c.trans_eps)) {
+      step_done(s, c, true);  // returns true WITHOUT applying delta
+      return;
+    }
+    s.lambda = s.nu * s.lambda;
+    s.nu = 2 * s.nu;
+    s.inner += 1;
+    if (s.inner >= c.lm_max_iterations) {  // L:172
+      step_done(s, c, false);
+      return;
+    }
+    lm_trial(s);  // next inner iteration, status stays ST_NEED_ERR
+    return;
+  }
+  s.x0 = s.xi;  // L:166-169
+  const double t = 2 * rho - 1;
+  s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
+  for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
+  step_done(s, c, true);
+}
+
+// L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false
+__global__ void k_init_state(PairState* st, const float* guesses /* n x 16 column-major, or null */, int npairs, int max_iterations) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  PairState& s = st[p];
+  if (guesses) {
+    const float* g = guesses + 16 * p;
+    for (int r = 0; r < 3; r++)
+      for (int c2 = 0; c2 < 4; c2++) s.x0.m[4 * r + c2] = (double)g[r + 4 * c2];
+  } else {
+    s.x0 = rigid_identity();
+  }
+  s.xi = s.x0;
+  s.delta = rigid_identity();
+  for (int q = 0; q < 36; q++) s.H[q] = 0.0, s.final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
+  for (int q = 0; q < 6; q++) s.b[q] = 0.0, s.d[q] = 0.0;
+  s.y0 = s.yi = 0.0;
+  s.lambda = -1.0;
+  s.nu = 2.0;
+  s.status = max_iterations > 0 ? ST_NEED_LIN : ST_DONE;
+  s.converged = 0, s.iter = 0, s.inner = 0, s.n_lin = 0, s.n_err = 0, s.failed = 0, s.n_matched = 0;
+}
+
+// probe support: put pair 0 into a given state at pose T (column-major double 4x4)
+__global__ void k_set_probe(PairState* st, const double* T16, int status, int use_xi) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  PairState& s = st[0];
+  Rigid r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) r.m[4 * i + j] = T16[i + 4 * j];
+  if (use_xi) s.xi = r;
+  else s.x0 = r;
+  s.status = status;
+}
+
+// probe support: reduce the linearize / error partials of pair 0 into out[0..43]:
+// H (36, column-major), b (6), cost, matched
+__global__ __launch_bounds__(64) void k_probe_reduce(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, double* out, int which) {
+  __shared__ double lds[32];
+  const int tid = threadIdx.x;
+  const int N = clouds[pairs[0].src].n;
+  const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
+  PairState& s = st[0];
+  if (which == 0) {
+    gather_linearize(s, w, 0, nblk, lds, tid);
+    if (tid == 0) {
+      for (int q = 0; q < 36; q++) out[q] = s.H[q];
+      for (int q = 0; q < 6; q++) out[36 + q] = s.b[q];
+      out[42] = s.y0;
+      out[43] = (double)s.n_matched;
+      s.n_lin += 1;
+    }
+  } else if (tid == 0) {
+    double yi = 0.0;
+    for (int b = 0; b < nblk; b++) yi += w.errpart[b];
+    out[42] = yi;
+    s.n_err += 1;
+  }
+}
+
+__global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const PairState& s = st[p];
+  ResultRec r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) r.T[i + 4 * j] = (float)s.x0.m[4 * i + j];  // x0.cast<float>(), L:78
+  r.T[3] = 0.f, r.T[7] = 0.f, r.T[11] = 0.f, r.T[15] = 1.f;
+  r.final_cost = s.y0;
+  r.converged = s.converged;
+  r.iterations = s.iter;
+  r.n_linearize = s.n_lin;
+  r.n_compute_error = s.n_err;
+  r.lm_failed = s.failed;
+  r.n_matched = s.n_matched;
+  out[p] = r;
+  if (status_out) status_out[p] = s.status;
+}
+
+__global__ void k_copy_status(const PairState* st, int* status_out, int npairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < npairs) status_out[p] = st[p].status;
+}
+
+// pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}
+__global__ void k_transform_points(const float4* pts, int n, const float* T16 /* column-major, device */, float* out, long long out_stride_floats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  float* o = out + (long long)i * out_stride_floats;
+  o[0] = T16[0] * p.x + T16[4] * p.y + T16[8] * p.z + T16[12];
+  o[1] = T16[1] * p.x + T16[5] * p.y + T16[9] * p.z + T16[13];
+  o[2] = T16[2] * p.x + T16[6] * p.y + T16[10] * p.z + T16[14];
+}
+
+// fitness (pcl::Registration::getFitnessScore): per-point gated 1-NN squared distance from the
+// merged nn partials of a probe at T; out[0] += d2 (double), out[1] += 1
+__global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out) {
+  __shared__ double red[(LIN_BLK / 64) * 2];
+  const int N = clouds[pairs[0].src].n, tid = threadIdx.x;
+  const int i = blockIdx.x * LIN_BLK + tid;
+  double acc[2] = {0.0, 0.0};
+  if (i < N) {
+    unsigned long long bestp = ~0ull;
+    for (int sp = 0; sp < w.T; sp++) {
+      const unsigned long long v = w.nnpart[(size_t)sp * w.nstride + i];
+      bestp = v < bestp ? v : bestp;
+    }
+    const float m = __uint_as_float((unsigned)(bestp >> 32));
+    if ((unsigned)bestp != kNoChunk && (double)m <= max_range2) acc[0] = (double)m, acc[1] = 1.0;
+  }
+  block_reduce<2, LIN_BLK>(acc, red, tid);
+  if (tid == 0) {
+    double a = 0, b = 0;
+    for (int wv = 0; wv < LIN_BLK / 64; wv++) a += red[wv * 2], b += red[wv * 2 + 1];
+    atomicAdd(out, a);
+    atomicAdd(out + 1, b);
+  }
+}
+
+}  // namespace apd

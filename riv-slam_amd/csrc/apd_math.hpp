@@ -1,0 +1,276 @@
+// Small fixed-size fp64 algebra shared by the APD-GICP kernels (device) and the host-loop debug
+// path (host).  Everything is written with static indices so that it stays in registers on gfx950
+// (runtime-indexed private arrays go to scratch).  Compiled with -ffp-contract=off: no expression
+// in this project is fused unless it calls fma() explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define APD_HD __host__ __device__ __forceinline__
+
+namespace apd {
+
+// symmetric 3x3, upper triangle
+struct Sym3 {
+  double xx, xy, xz, yy, yz, zz;
+};
+
+// rigid transform, row-major 3x4 [R | t]
+struct Rigid {
+  double m[12];
+};
+
+APD_HD Rigid rigid_identity() {
+  Rigid r;
+  r.m[0] = 1, r.m[1] = 0, r.m[2] = 0, r.m[3] = 0;
+  r.m[4] = 0, r.m[5] = 1, r.m[6] = 0, r.m[7] = 0;
+  r.m[8] = 0, r.m[9] = 0, r.m[10] = 1, r.m[11] = 0;
+  return r;
+}
+
+// Isometry3d * Isometry3d (x0 = delta * x0, lsq_registration_impl.hpp:119,144)
+APD_HD Rigid rigid_mul(const Rigid& a, const Rigid& b) {
+  Rigid r;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.m[4 * i + j] = a.m[4 * i] * b.m[j] + a.m[4 * i + 1] * b.m[4 + j] + a.m[4 * i + 2] * b.m[8 + j];
+    r.m[4 * i + 3] = a.m[4 * i] * b.m[3] + a.m[4 * i + 1] * b.m[7] + a.m[4 * i + 2] * b.m[11] + a.m[4 * i + 3];
+  }
+  return r;
+}
+
+APD_HD Sym3 sym3_add(const Sym3& a, const Sym3& b) { return Sym3{a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz}; }
+
+// R * C * R^T for symmetric C (R = rows r0,r1,r2 of a Rigid)
+APD_HD Sym3 sym3_rotate(const Rigid& T, const Sym3& c) {
+  // RC = R * C
+  double rc[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double a = T.m[4 * i], b = T.m[4 * i + 1], d = T.m[4 * i + 2];
+    rc[3 * i + 0] = a * c.xx + b * c.xy + d * c.xz;
+    rc[3 * i + 1] = a * c.xy + b * c.yy + d * c.yz;
+    rc[3 * i + 2] = a * c.xz + b * c.yz + d * c.zz;
+  }
+  Sym3 o;
+  o.xx = rc[0] * T.m[0] + rc[1] * T.m[1] + rc[2] * T.m[2];
+  o.xy = rc[0] * T.m[4] + rc[1] * T.m[5] + rc[2] * T.m[6];
+  o.xz = rc[0] * T.m[8] + rc[1] * T.m[9] + rc[2] * T.m[10];
+  o.yy = rc[3] * T.m[4] + rc[4] * T.m[5] + rc[5] * T.m[6];
+  o.yz = rc[3] * T.m[8] + rc[4] * T.m[9] + rc[5] * T.m[10];
+  o.zz = rc[6] * T.m[8] + rc[7] * T.m[9] + rc[8] * T.m[10];
+  return o;
+}
+
+// inverse of a symmetric 3x3 by cofactors (stands in for Matrix4d::inverse() of blkdiag(C,1),
+// fast_apdgicp_impl.hpp:191)
+APD_HD Sym3 sym3_inverse(const Sym3& a) {
+  const double c00 = a.yy * a.zz - a.yz * a.yz;
+  const double c01 = a.yz * a.xz - a.xy * a.zz;
+  const double c02 = a.xy * a.yz - a.yy * a.xz;
+  const double det = a.xx * c00 + a.xy * c01 + a.xz * c02;
+  const double id = 1.0 / det;
+  Sym3 r;
+  r.xx = c00 * id;
+  r.xy = c01 * id;
+  r.xz = c02 * id;
+  r.yy = (a.xx * a.zz - a.xz * a.xz) * id;
+  r.yz = (a.xy * a.xz - a.xx * a.yz) * id;
+  r.zz = (a.xx * a.yy - a.xy * a.xy) * id;
+  return r;
+}
+
+// One Jacobi rotation zeroing a_pq of a symmetric 3x3; r is the third index.
+// (app, aqq, apq, arp, arq) are the affected entries, (v?p, v?q) the two eigenvector columns.
+APD_HD void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq, double& v0p, double& v0q, double& v1p, double& v1q,
+                       double& v2p, double& v2q) {
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  app = app - t * apq;
+  aqq = aqq + t * apq;
+  apq = 0.0;
+  const double rp = arp, rq = arq;
+  arp = c * rp - s * rq;
+  arq = s * rp + c * rq;
+  double a, b;
+  a = v0p, b = v0q, v0p = c * a - s * b, v0q = s * a + c * b;
+  a = v1p, b = v1q, v1p = c * a - s * b, v1q = s * a + c * b;
+  a = v2p, b = v2q, v2p = c * a - s * b, v2q = s * a + c * b;
+}
+
+// Symmetric eigen-decomposition, eigenvalues descending (w0>=w1>=w2), U columns = eigenvectors
+// (u[3*row+col]).  Stands in for Eigen::JacobiSVD<Matrix3d> on a symmetric PSD input
+// (fast_apdgicp_impl.hpp:337).
+APD_HD void sym3_eig(const Sym3& A, double w[3], double u[9]) {
+  double a00 = A.xx, a01 = A.xy, a02 = A.xz, a11 = A.yy, a12 = A.yz, a22 = A.zz;
+  double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+  for (int sweep = 0; sweep < 32; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12;
+    const double diag = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off == 0.0 || off <= 1e-40 * diag) break;
+    jacobi_rot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21);  // (p,q)=(0,1), r=2
+    jacobi_rot(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22);  // (0,2), r=1
+    jacobi_rot(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22);  // (1,2), r=0
+  }
+  // sort descending, carrying columns
+#define APD_SWAPCOL(wa, wb, c0a, c1a, c2a, c0b, c1b, c2b) \
+  if (wa < wb) {                                          \
+    double t_;                                            \
+    t_ = wa, wa = wb, wb = t_;                            \
+    t_ = c0a, c0a = c0b, c0b = t_;                        \
+    t_ = c1a, c1a = c1b, c1b = t_;                        \
+    t_ = c2a, c2a = c2b, c2b = t_;                        \
+  }
+  APD_SWAPCOL(a00, a11, v00, v10, v20, v01, v11, v21)
+  APD_SWAPCOL(a00, a22, v00, v10, v20, v02, v12, v22)
+  APD_SWAPCOL(a11, a22, v01, v11, v21, v02, v12, v22)
+#undef APD_SWAPCOL
+  w[0] = a00, w[1] = a11, w[2] = a22;
+  u[0] = v00, u[1] = v01, u[2] = v02, u[3] = v10, u[4] = v11, u[5] = v12, u[6] = v20, u[7] = v21, u[8] = v22;
+}
+
+// U * diag(vals) * U^T
+APD_HD Sym3 sym3_from_eig(const double u[9], double l0, double l1, double l2) {
+  Sym3 o;
+  o.xx = u[0] * l0 * u[0] + u[1] * l1 * u[1] + u[2] * l2 * u[2];
+  o.xy = u[0] * l0 * u[3] + u[1] * l1 * u[4] + u[2] * l2 * u[5];
+  o.xz = u[0] * l0 * u[6] + u[1] * l1 * u[7] + u[2] * l2 * u[8];
+  o.yy = u[3] * l0 * u[3] + u[4] * l1 * u[4] + u[5] * l2 * u[5];
+  o.yz = u[3] * l0 * u[6] + u[4] * l1 * u[7] + u[5] * l2 * u[8];
+  o.zz = u[6] * l0 * u[6] + u[7] * l1 * u[7] + u[8] * l2 * u[8];
+  return o;
+}
+
+// fast_apdgicp_impl.hpp:326-357 applied to the population covariance `cov`.
+// returns false for an unknown mode (the reference aborts, :341-343)
+APD_HD bool regularize_cov(int mode, const Sym3& cov, Sym3& out) {
+  if (mode == 0) {  // NONE
+    out = cov;
+    return true;
+  }
+  if (mode == 4) {  // FROBENIUS: ((C+lI)^-1 / ||(C+lI)^-1||_F)^-1 = (C+lI) * ||(C+lI)^-1||_F
+    Sym3 C = cov;
+    C.xx += 1e-3, C.yy += 1e-3, C.zz += 1e-3;
+    Sym3 Ci = sym3_inverse(C);
+    const double nf = sqrt(Ci.xx * Ci.xx + Ci.yy * Ci.yy + Ci.zz * Ci.zz + 2.0 * (Ci.xy * Ci.xy + Ci.xz * Ci.xz + Ci.yz * Ci.yz));
+    Ci.xx /= nf, Ci.xy /= nf, Ci.xz /= nf, Ci.yy /= nf, Ci.yz /= nf, Ci.zz /= nf;
+    out = sym3_inverse(Ci);
+    return true;
+  }
+  double w[3], u[9];
+  sym3_eig(cov, w, u);
+  double l0, l1, l2;
+  if (mode == 3) {  // PLANE
+    l0 = 1.0, l1 = 1.0, l2 = 1e-3;
+  } else if (mode == 1) {  // MIN_EIG
+    l0 = fmax(w[0], 1e-3), l1 = fmax(w[1], 1e-3), l2 = fmax(w[2], 1e-3);
+  } else if (mode == 2) {  // NORMALIZED_MIN_EIG
+    const double mx = fmax(w[0], fmax(w[1], w[2]));
+    l0 = fmax(w[0] / mx, 1e-3), l1 = fmax(w[1] / mx, 1e-3), l2 = fmax(w[2] / mx, 1e-3);
+  } else {
+    out = Sym3{0, 0, 0, 0, 0, 0};
+    return false;
+  }
+  out = sym3_from_eig(u, l0, l1, l2);
+  return true;
+}
+
+// so3_exp (so3/so3.hpp:59-78) followed by Quaterniond::toRotationMatrix(); writes the rotation
+// block of `delta` and d[3..5] into its translation (lsq_registration_impl.hpp:115-117,140-142).
+APD_HD Rigid make_delta(const double d[6]) {
+  const double theta_sq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double theta_quad = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * theta_quad;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * theta_quad;
+  } else {
+    const double theta = sqrt(theta_sq), half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  const double w = real, x = imag * d[0], y = imag * d[1], z = imag * d[2];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  Rigid r;
+  r.m[0] = 1 - (tyy + tzz), r.m[1] = txy - twz, r.m[2] = txz + twy, r.m[3] = d[3];
+  r.m[4] = txy + twz, r.m[5] = 1 - (txx + tzz), r.m[6] = tyz - twx, r.m[7] = d[4];
+  r.m[8] = txz - twy, r.m[9] = tyz + twx, r.m[10] = 1 - (txx + tyy), r.m[11] = d[5];
+  return r;
+}
+
+// is_converged (lsq_registration_impl.hpp:83-92): element-wise on R-I and t, not an angle.
+APD_HD bool is_converged(const Rigid& delta, double rot_eps, double trans_eps) {
+  double rmax = 0.0, tmax = 0.0;
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double v = 1.0 / rot_eps * fabs(delta.m[4 * i + j] - (i == j ? 1.0 : 0.0));
+      nan |= (v != v);
+      rmax = fmax(rmax, v);
+    }
+    const double v = 1.0 / trans_eps * fabs(delta.m[4 * i + 3]);
+    nan |= (v != v);
+    tmax = fmax(tmax, v);
+  }
+  if (nan) return false;  // epsilon == 0 with a zero entry: inf*0; the reference's maxCoeff is then unspecified
+  return fmax(rmax, tmax) < 1.0;
+}
+
+// Solve (H + lambda I) x = -b for a symmetric positive semi-definite 6x6 (H column-major).
+// LDL^T without pivoting (fully unrolled, register resident).  Eigen::LDLT pivots on the diagonal
+// (lsq_registration_impl.hpp:112,137); for the SPD systems of this path both are backward stable
+// and agree to ~cond*eps.  A vanishing pivot zeroes that unknown (LDLT's pseudo-inverse rule), so
+// H == 0 (no correspondences) gives x == 0 like the reference.
+APD_HD void solve6_spd(const double* H, double lambda, const double* b, double* x) {
+  double L[6][6];
+  double D[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = H[j + 6 * j] + lambda;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < j) dj -= L[j][k] * L[j][k] * D[k];
+    D[j] = dj;
+    const bool ok = fabs(dj) > 1e-300;
+    const double inv = ok ? 1.0 / dj : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i > j) {
+        double v = H[i + 6 * j];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (k < j) v -= L[i][k] * L[j][k] * D[k];
+        L[i][j] = v * inv;
+      }
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = -b[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < i) v -= L[i][k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = fabs(D[i]) > 1e-300 ? y[i] / D[i] : 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k > i) v -= L[k][i] * x[k];
+    x[i] = v;
+  }
+}
+
+}  // namespace apd

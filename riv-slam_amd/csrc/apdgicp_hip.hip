@@ -1,0 +1,562 @@
+// libapdgicp_hip.so -- the C ABI declared in include/apdgicp_hip.h, on top of apd::Engine.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC (see build.py)
+#include <cstddef>
+#include <new>
+
+#include "apd_engine.hpp"
+
+using namespace apd;
+
+struct apdgicp_handle {
+  Engine eng;
+  bool pair_ready = false;   // work buffers / descriptors match the current source+target
+  bool have_corr = false;    // correspondences_/mahalanobis_ hold a linearize result
+  int n_src_at_corr = 0;
+};
+
+struct apdgicp_batch {
+  Engine eng;
+};
+
+namespace {
+
+constexpr int kSrc = 0, kTgt = 1;
+
+int ensure_pair(apdgicp_handle* h) {
+  Engine& e = h->eng;
+  if (e.clouds.size() < 2 || e.clouds[kSrc].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "source cloud is not set");
+  if (e.clouds[kTgt].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "target cloud is not set");
+  if (h->pair_ready && e.clouds[kSrc].cov_valid && e.clouds[kTgt].cov_valid) return 0;
+  apdgicp_pair p;
+  p.source_cloud = kSrc;
+  p.target_cloud = kTgt;
+  memset(p.guess, 0, sizeof(p.guess));
+  p.guess[0] = p.guess[5] = p.guess[10] = p.guess[15] = 1.f;
+  APD_TRY(e.setup_pairs(&p, 1, true));
+  h->pair_ready = true;
+  h->have_corr = false;
+  return 0;
+}
+
+void identity16(float* g) {
+  memset(g, 0, 16 * sizeof(float));
+  g[0] = g[5] = g[10] = g[15] = 1.f;
+}
+
+Rigid rigid_from_colmajor(const double* T) {
+  Rigid r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) r.m[4 * i + j] = T[i + 4 * j];
+  return r;
+}
+void rigid_to_colmajor(const Rigid& r, double* T) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) T[i + 4 * j] = r.m[4 * i + j];
+  T[3] = T[7] = T[11] = 0.0;
+  T[15] = 1.0;
+}
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(APDGICP_ERR_INTERNAL, "out of host memory");
+  } catch (...) {
+    return fail(APDGICP_ERR_INTERNAL, "unexpected C++ exception");
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int apdgicp_abi_version(void) { return APDGICP_ABI_VERSION; }
+const char* apdgicp_last_error(void) { return g_last_error.c_str(); }
+
+int apdgicp_device_count(int* count) {
+  if (!count) return fail(APDGICP_ERR_INVALID_ARG, "count is null");
+  *count = 0;
+  APD_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+
+void apdgicp_default_params(apdgicp_params* p) {
+  if (!p) return;
+  p->k_correspondences = 20;                 // A:21
+  p->max_iterations = 64;                    // L:13
+  p->lm_max_iterations = 10;                 // L:19
+  p->optimizer = APDGICP_OPT_LM;             // L:17
+  p->regularization = APDGICP_REG_PLANE;     // A:25
+  p->reserved = 0;
+  p->max_correspondence_distance = (double)FLT_MAX;  // A:23
+  p->transformation_epsilon = 5e-4;          // L:15
+  p->rotation_epsilon = 2e-3;                // L:14
+  p->lm_init_lambda_factor = 1e-9;           // L:20
+  p->distance_variance = 0.86;               // H:109
+  p->azimuth_variance_deg = 0.5;             // H:107
+  p->elevation_variance_deg = 1.0;           // H:108
+}
+
+// ------------------------------------------------------------------------------------ single
+int apdgicp_create(const apdgicp_params* p, int device, void* stream, apdgicp_handle** out) {
+  return guarded([&]() -> int {
+    if (!out) return fail(APDGICP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    apdgicp_params dflt;
+    apdgicp_default_params(&dflt);
+    apdgicp_handle* h = new apdgicp_handle;
+    const int rc = h->eng.init(p ? p : &dflt, device, stream);
+    if (rc < 0) {
+      delete h;
+      return rc;
+    }
+    h->eng.clouds.resize(2);
+    *out = h;
+    return 0;
+  });
+}
+
+int apdgicp_destroy(apdgicp_handle* h) {
+  delete h;
+  return 0;
+}
+
+int apdgicp_set_params(apdgicp_handle* h, const apdgicp_params* p) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  return h->eng.set_params(p);
+}
+
+int apdgicp_get_params(const apdgicp_handle* h, apdgicp_params* p) {
+  if (!h || !p) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  *p = h->eng.params;
+  return 0;
+}
+
+static int set_cloud_common(apdgicp_handle* h, int slot, const float* xyz, int64_t n, int64_t stride, int on_device, uint64_t token) {
+  return guarded([&]() -> int {
+    if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+    Engine& e = h->eng;
+    if (token != 0 && e.clouds[slot].n > 0 && e.clouds[slot].token == token) return 0;  // A:91-93 / A:102-104
+    APD_TRY(e.set_cloud(slot, xyz, n, stride, on_device, token));
+    h->pair_ready = false;
+    h->have_corr = false;
+    return 0;
+  });
+}
+
+int apdgicp_set_source(apdgicp_handle* h, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token) {
+  return set_cloud_common(h, kSrc, xyz, n, stride_bytes, on_device, token);
+}
+int apdgicp_set_target(apdgicp_handle* h, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token) {
+  return set_cloud_common(h, kTgt, xyz, n, stride_bytes, on_device, token);
+}
+
+int apdgicp_clear_source(apdgicp_handle* h) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  h->eng.clear_cloud(kSrc);
+  h->pair_ready = h->have_corr = false;
+  return 0;
+}
+int apdgicp_clear_target(apdgicp_handle* h) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  h->eng.clear_cloud(kTgt);
+  h->pair_ready = h->have_corr = false;
+  return 0;
+}
+int apdgicp_swap_source_and_target(apdgicp_handle* h) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  std::swap(h->eng.clouds[kSrc], h->eng.clouds[kTgt]);  // input_.swap(target_), covs swap, A:68-75
+  h->eng.desc_dirty = true;
+  h->pair_ready = h->have_corr = false;
+  return 0;
+}
+
+int apdgicp_compute_covariances(apdgicp_handle* h, int which) {
+  return guarded([&]() -> int {
+    if (!h || (which != kSrc && which != kTgt)) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    return h->eng.compute_covariances({which});
+  });
+}
+
+int apdgicp_get_covariances(apdgicp_handle* h, int which, double* out, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h || !out || (which != kSrc && which != kTgt)) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    Engine& e = h->eng;
+    APD_TRY(e.compute_covariances({which}));
+    Engine::Cloud& c = e.clouds[which];
+    if (n != c.n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the cloud size");
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n * 16 * sizeof(double)));
+    hipLaunchKernelGGL(k_unpack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.cov.as<double>(), (int)n, e.d_stage.as<double>());
+    APD_HIP(hipMemcpyAsync(out, e.d_stage.p, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_set_covariances(apdgicp_handle* h, int which, const double* in, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h || !in || (which != kSrc && which != kTgt)) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    Engine& e = h->eng;
+    Engine::Cloud& c = e.clouds[which];
+    if (c.n <= 0) return fail(APDGICP_ERR_NO_INPUT, "cloud not set");
+    if (n != c.n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the cloud size");
+    APD_TRY(e.upload_desc());  // allocates c.cov
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n * 16 * sizeof(double)));
+    APD_HIP(hipMemcpyAsync(e.d_stage.p, in, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, e.stream));
+    hipLaunchKernelGGL(k_pack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.d_stage.as<double>(), (int)n, c.cov.as<double>());
+    APD_HIP(hipStreamSynchronize(e.stream));
+    c.cov_valid = true;
+    return 0;
+  });
+}
+
+int apdgicp_linearize(apdgicp_handle* h, const double T[16], double H[36], double b[6], double* cost) {
+  return guarded([&]() -> int {
+    if (!h || !T) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(ensure_pair(h));
+    APD_TRY(h->eng.probe_linearize(T, H, b, cost, nullptr));
+    h->have_corr = true;
+    return 0;
+  });
+}
+
+int apdgicp_compute_error(apdgicp_handle* h, const double T[16], double* cost) {
+  return guarded([&]() -> int {
+    if (!h || !T || !cost) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (!h->pair_ready || !h->have_corr) return fail(APDGICP_ERR_NO_INPUT, "compute_error needs a previous linearize");
+    return h->eng.probe_error(T, cost);
+  });
+}
+
+int apdgicp_get_correspondences(apdgicp_handle* h, int32_t* corr, float* sq, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+    Engine& e = h->eng;
+    if (!h->pair_ready || !h->have_corr) return fail(APDGICP_ERR_NO_INPUT, "no correspondences yet");
+    if (n != e.clouds[kSrc].n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
+    if (corr) APD_HIP(hipMemcpyAsync(corr, e.work.corr, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    if (sq) APD_HIP(hipMemcpyAsync(sq, e.work.sqd, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_get_mahalanobis(apdgicp_handle* h, double* out, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h || !out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    Engine& e = h->eng;
+    if (!h->pair_ready || !h->have_corr) return fail(APDGICP_ERR_NO_INPUT, "no correspondences yet");
+    if (n != e.clouds[kSrc].n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
+    const size_t ns = e.work.nstride;
+    std::vector<double> m6(6 * ns);
+    std::vector<int> corr(n);
+    APD_HIP(hipMemcpyAsync(m6.data(), e.work.maha, 6 * ns * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipMemcpyAsync(corr.data(), e.work.corr, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    for (int64_t i = 0; i < n; i++) {
+      double* o = out + 16 * i;
+      memset(o, 0, 16 * sizeof(double));
+      if (corr[i] < 0) continue;
+      const double xx = m6[i], xy = m6[ns + i], xz = m6[2 * ns + i], yy = m6[3 * ns + i], yz = m6[4 * ns + i], zz = m6[5 * ns + i];
+      o[0] = xx, o[1] = xy, o[2] = xz, o[4] = xy, o[5] = yy, o[6] = yz, o[8] = xz, o[9] = yz, o[10] = zz;  // (3,3) = 0, A:192
+    }
+    return 0;
+  });
+}
+
+int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out) {
+  return guarded([&]() -> int {
+    if (!h || !out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(ensure_pair(h));
+    Engine& e = h->eng;
+    float g[16];
+    if (guess) memcpy(g, guess, sizeof(g));
+    else identity16(g);
+    APD_HIP(hipMemcpyAsync(e.d_guess.p, g, sizeof(g), hipMemcpyHostToDevice, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.run_align());
+    APD_HIP(hipMemcpyAsync(out, e.d_results.p, sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    h->have_corr = out->n_linearize > 0;
+    return 0;
+  });
+}
+
+// The reference's own control flow (L:55-173) on the host, calling the device through the same two
+// virtuals the reference uses (linearize, compute_error).  Used to separate "kernel parity" from
+// "state-machine parity" in the tests.
+int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_result* out) {
+  return guarded([&]() -> int {
+    if (!h || !out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(ensure_pair(h));
+    Engine& e = h->eng;
+    const apdgicp_params& p = e.params;
+    float g[16];
+    if (guess) memcpy(g, guess, sizeof(g));
+    else identity16(g);
+    Rigid x0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) x0.m[4 * i + j] = (double)g[i + 4 * j];  // L:56
+    double lambda = -1.0;                                                   // L:58
+    bool converged = false;
+    int nr_iterations = 0, n_lin = 0, n_err = 0, failed = 0, matched = 0;
+    double final_H[36];
+    for (int q = 0; q < 36; q++) final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
+    double y0 = 0.0;
+    for (int it = 0; it < p.max_iterations && !converged; it++) {  // L:67
+      nr_iterations = it;
+      double T16[16], H[36], b[6], d[6];
+      rigid_to_colmajor(x0, T16);
+      APD_TRY(e.probe_linearize(T16, H, b, &y0, &matched));
+      n_lin++;
+      Rigid delta = rigid_identity();
+      bool ok = false;
+      if (p.optimizer == APDGICP_OPT_GN) {  // L:107-123
+        solve6_spd(H, 0.0, b, d);
+        delta = make_delta(d);
+        x0 = rigid_mul(delta, x0);
+        memcpy(final_H, H, sizeof(H));
+        ok = true;
+      } else {  // L:127-173
+        if (lambda < 0.0) {
+          double mx = 0.0;
+          for (int q = 0; q < 6; q++) mx = std::max(mx, std::fabs(H[q + 6 * q]));
+          lambda = p.lm_init_lambda_factor * mx;
+        }
+        double nu = 2.0;
+        for (int in = 0; in < p.lm_max_iterations; in++) {
+          solve6_spd(H, lambda, b, d);
+          delta = make_delta(d);
+          const Rigid xi = rigid_mul(delta, x0);
+          double yi = 0.0;
+          rigid_to_colmajor(xi, T16);
+          APD_TRY(e.probe_error(T16, &yi));
+          n_err++;
+          double den = 0.0;
+          for (int q = 0; q < 6; q++) den += d[q] * (lambda * d[q] - b[q]);
+          const double rho = (y0 - yi) / den;
+          if (rho < 0) {
+            if (is_converged(delta, p.rotation_epsilon, p.transformation_epsilon)) {
+              ok = true;
+              break;
+            }
+            lambda = nu * lambda;
+            nu = 2 * nu;
+            continue;
+          }
+          x0 = xi;
+          const double t = 2 * rho - 1;
+          lambda = lambda * std::max(1.0 / 3.0, 1 - t * t * t);
+          memcpy(final_H, H, sizeof(H));
+          ok = true;
+          break;
+        }
+      }
+      if (!ok) {
+        failed = 1;
+        break;
+      }
+      converged = is_converged(delta, p.rotation_epsilon, p.transformation_epsilon);
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) out->T[i + 4 * j] = (float)x0.m[4 * i + j];
+    out->T[3] = out->T[7] = out->T[11] = 0.f;
+    out->T[15] = 1.f;
+    out->final_cost = y0;
+    out->converged = converged;
+    out->iterations = nr_iterations;
+    out->n_linearize = n_lin;
+    out->n_compute_error = n_err;
+    out->lm_failed = failed;
+    out->n_matched = matched;
+    h->have_corr = n_lin > 0;
+    // keep getFinalHessian() coherent with this path
+    APD_HIP(hipMemcpyAsync((char*)e.d_state.p + offsetof(PairState, final_H), final_H, sizeof(final_H), hipMemcpyHostToDevice, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_get_final_hessian(apdgicp_handle* h, double H[36]) {
+  return guarded([&]() -> int {
+    if (!h || !H) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    Engine& e = h->eng;
+    if (!h->pair_ready) {  // L:23: identity until the first accepted step
+      for (int q = 0; q < 36; q++) H[q] = (q % 7 == 0) ? 1.0 : 0.0;
+      return 0;
+    }
+    APD_HIP(hipMemcpyAsync(H, (char*)e.d_state.p + offsetof(PairState, final_H), 36 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xyz, int64_t n, int64_t out_stride_bytes) {
+  return guarded([&]() -> int {
+    if (!h || !T || !out_xyz) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    Engine& e = h->eng;
+    Engine::Cloud& c = e.clouds[kSrc];
+    if (c.n <= 0) return fail(APDGICP_ERR_NO_INPUT, "source cloud is not set");
+    if (n != c.n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
+    if (out_stride_bytes < 12 || (out_stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "bad output stride");
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n * 12 + 64));
+    float* dT = (float*)((char*)e.d_stage.p + (size_t)n * 12);
+    APD_HIP(hipMemcpyAsync(dT, T, 16 * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.pts.as<float4>(), (int)n, dT, e.d_stage.as<float>(),
+                       3ll);
+    if (out_stride_bytes == 12) {
+      APD_HIP(hipMemcpyAsync(out_xyz, e.d_stage.p, (size_t)n * 12, hipMemcpyDeviceToHost, e.stream));
+      APD_HIP(hipStreamSynchronize(e.stream));
+    } else {
+      std::vector<float> tmp((size_t)n * 3);
+      APD_HIP(hipMemcpyAsync(tmp.data(), e.d_stage.p, (size_t)n * 12, hipMemcpyDeviceToHost, e.stream));
+      APD_HIP(hipStreamSynchronize(e.stream));
+      for (int64_t i = 0; i < n; i++) memcpy((char*)out_xyz + i * out_stride_bytes, &tmp[3 * i], 12);
+    }
+    return 0;
+  });
+}
+
+int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range, double* score, int64_t* n_inliers) {
+  return guarded([&]() -> int {
+    if (!h || !T || !score) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(ensure_pair(h));
+    Engine& e = h->eng;
+    double T16[16];
+    for (int q = 0; q < 16; q++) T16[q] = (double)T[q];
+    APD_HIP(hipMemcpyAsync(e.d_T.p, T16, sizeof(T16), hipMemcpyHostToDevice, e.stream));
+    hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, e.stream, e.d_state.as<PairState>(), e.d_T.as<double>(), (int)ST_NEED_LIN, 0);
+    APD_TRY(e.launch_nn());
+    APD_HIP(hipMemsetAsync(e.d_probe.p, 0, 2 * sizeof(double), e.stream));
+    hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
+                       max_range, e.d_probe.as<double>());
+    APD_HIP(hipMemcpyAsync(e.h_probe, e.d_probe.p, 2 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    h->have_corr = false;  // the nn partials were overwritten at another pose
+    const double cnt = e.h_probe[1];
+    *score = cnt > 0 ? e.h_probe[0] / cnt : std::numeric_limits<double>::max();  // pcl returns max() when nothing is in range
+    if (n_inliers) *n_inliers = (int64_t)cnt;
+    return 0;
+  });
+}
+
+int apdgicp_synchronize(apdgicp_handle* h) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  APD_HIP(hipStreamSynchronize(h->eng.stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ batch
+int apdgicp_batch_create(const apdgicp_params* p, int device, void* stream, apdgicp_batch** out) {
+  return guarded([&]() -> int {
+    if (!out) return fail(APDGICP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    apdgicp_params dflt;
+    apdgicp_default_params(&dflt);
+    apdgicp_batch* b = new apdgicp_batch;
+    const int rc = b->eng.init(p ? p : &dflt, device, stream);
+    if (rc < 0) {
+      delete b;
+      return rc;
+    }
+    b->eng.profile_nn = env_int("APDGICP_PROFILE_NN", 0) != 0;
+    *out = b;
+    return 0;
+  });
+}
+
+int apdgicp_batch_destroy(apdgicp_batch* b) {
+  delete b;
+  return 0;
+}
+
+int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  return b->eng.set_params(p);
+}
+
+int apdgicp_batch_clear(apdgicp_batch* b) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  APD_HIP(hipStreamSynchronize(b->eng.stream));
+  for (auto& c : b->eng.clouds) c.pts.release(), c.cov.release();
+  b->eng.clouds.clear();
+  b->eng.desc_dirty = true;
+  return 0;
+}
+
+int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64_t stride_bytes, int on_device) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    const int slot = (int)b->eng.clouds.size();
+    const int rc = b->eng.set_cloud(slot, xyz, n, stride_bytes, on_device, 0);
+    if (rc < 0) {
+      if ((int)b->eng.clouds.size() > slot) b->eng.clouds.resize(slot);
+      return rc;
+    }
+    return slot;
+  });
+}
+
+int apdgicp_batch_compute_covariances(apdgicp_batch* b) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    std::vector<int> ids;
+    for (int i = 0; i < (int)b->eng.clouds.size(); i++)
+      if (b->eng.clouds[i].n > 0) ids.push_back(i);
+    return b->eng.compute_covariances(ids);
+  });
+}
+
+int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results) {
+  return guarded([&]() -> int {
+    if (!b || !pairs) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(b->eng.setup_pairs(pairs, n_pairs, true));
+    APD_TRY(b->eng.run_align());
+    if (d_results) *d_results = b->eng.d_results.p;
+    return 0;
+  });
+}
+
+int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, apdgicp_result* results) {
+  return guarded([&]() -> int {
+    if (!results) return fail(APDGICP_ERR_INVALID_ARG, "results is null");
+    APD_TRY(apdgicp_batch_align_async(b, pairs, n_pairs, nullptr));
+    Engine& e = b->eng;
+    APD_HIP(hipMemcpyAsync(results, e.d_results.p, n_pairs * sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_batch_synchronize(apdgicp_batch* b) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  APD_HIP(hipStreamSynchronize(b->eng.stream));
+  return 0;
+}
+
+int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  b->eng.profile_nn = enable != 0;
+  return 0;
+}
+
+int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  if (total_ms) *total_ms = b->eng.last_nn_ms;
+  if (launches) *launches = b->eng.last_nn_launches;
+  return 0;
+}
+
+int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  if (ticks) *ticks = b->eng.last_ticks;
+  if (nn_sources_per_lane) *nn_sources_per_lane = b->eng.nn_S;
+  if (nn_target_splits) *nn_target_splits = b->eng.work.T;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,471 @@
+"""ctypes binding of libapdgicp_hip.so (include/apdgicp_hip.h) with the reference's method names.
+
+`FastAPDGICP` mirrors fast_gicp::FastAPDGICP as seen through pcl::Registration
+(fast_apdgicp/include/fast_gicp/gicp/fast_apdgicp.hpp:19-110 and the calls made by
+radar_graph_slam/src/radar_graph_slam/registrations.cpp:38-50,
+radar_graph_slam/apps/scan_matching_odometry_nodelet.cpp:437-482): setInputSource / setInputTarget /
+align / hasConverged / getFinalTransformation / getFitnessScore plus the eight setters of the ROS
+factory.  `BatchAPDGICP` is the batched entry (loop-closure candidates, loop_detector.cpp:222-236).
+
+There is NO CPU fallback: if the HIP library or a GPU is missing every call raises.
+numpy matrices are row-major [4,4]/[6,6]; the C ABI is column-major (Eigen) -- converted here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapdgicp_hip.so")
+
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = 0, 1, 2, 3, 4
+OPT_LM, OPT_GN = 0, 1
+SOURCE, TARGET = 0, 1
+
+
+class ApdgicpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"apdgicp error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """apdgicp_params (include/apdgicp_hip.h)."""
+    _fields_ = [
+        ("k_correspondences", C.c_int32),
+        ("max_iterations", C.c_int32),
+        ("lm_max_iterations", C.c_int32),
+        ("optimizer", C.c_int32),
+        ("regularization", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_correspondence_distance", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("rotation_epsilon", C.c_double),
+        ("lm_init_lambda_factor", C.c_double),
+        ("distance_variance", C.c_double),
+        ("azimuth_variance_deg", C.c_double),
+        ("elevation_variance_deg", C.c_double),
+    ]
+
+
+class Result(C.Structure):
+    """apdgicp_result (include/apdgicp_hip.h)."""
+    _fields_ = [
+        ("T", C.c_float * 16),
+        ("final_cost", C.c_double),
+        ("converged", C.c_int32),
+        ("iterations", C.c_int32),
+        ("n_linearize", C.c_int32),
+        ("n_compute_error", C.c_int32),
+        ("lm_failed", C.c_int32),
+        ("n_matched", C.c_int32),
+    ]
+
+    def matrix(self) -> np.ndarray:
+        return np.array(self.T, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Pair(C.Structure):
+    """apdgicp_pair"""
+    _fields_ = [("source_cloud", C.c_int32), ("target_cloud", C.c_int32), ("guess", C.c_float * 16)]
+
+
+RESULT_DTYPE = np.dtype([("T", np.float32, (16,)), ("final_cost", np.float64), ("converged", np.int32), ("iterations", np.int32),
+                         ("n_linearize", np.int32), ("n_compute_error", np.int32), ("lm_failed", np.int32), ("n_matched", np.int32)])
+assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 96
+
+# every symbol include/apdgicp_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "apdgicp_abi_version", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
+    "apdgicp_create", "apdgicp_destroy", "apdgicp_set_params", "apdgicp_get_params",
+    "apdgicp_set_source", "apdgicp_set_target", "apdgicp_clear_source", "apdgicp_clear_target",
+    "apdgicp_swap_source_and_target", "apdgicp_compute_covariances", "apdgicp_get_covariances",
+    "apdgicp_set_covariances", "apdgicp_linearize", "apdgicp_compute_error", "apdgicp_get_correspondences",
+    "apdgicp_get_mahalanobis", "apdgicp_align", "apdgicp_align_host_loop", "apdgicp_get_final_hessian",
+    "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_synchronize",
+    "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
+    "apdgicp_batch_add_cloud", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
+    "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_set_profiling",
+    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks",
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads libapdgicp_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(p)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+    L.apdgicp_abi_version.restype = i32
+    L.apdgicp_last_error.restype = C.c_char_p
+    L.apdgicp_device_count.argtypes = [C.POINTER(i32)]
+    L.apdgicp_default_params.argtypes = [C.POINTER(Params)]
+    L.apdgicp_default_params.restype = None
+    L.apdgicp_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
+    L.apdgicp_destroy.argtypes = [vp]
+    L.apdgicp_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.apdgicp_get_params.argtypes = [vp, C.POINTER(Params)]
+    for f in (L.apdgicp_set_source, L.apdgicp_set_target):
+        f.argtypes = [vp, vp, i64, i64, i32, u64]
+    for f in (L.apdgicp_clear_source, L.apdgicp_clear_target, L.apdgicp_swap_source_and_target, L.apdgicp_synchronize):
+        f.argtypes = [vp]
+    L.apdgicp_compute_covariances.argtypes = [vp, i32]
+    L.apdgicp_get_covariances.argtypes = [vp, i32, vp, i64]
+    L.apdgicp_set_covariances.argtypes = [vp, i32, vp, i64]
+    L.apdgicp_linearize.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
+    L.apdgicp_compute_error.argtypes = [vp, vp, C.POINTER(dbl)]
+    L.apdgicp_get_correspondences.argtypes = [vp, vp, vp, i64]
+    L.apdgicp_get_mahalanobis.argtypes = [vp, vp, i64]
+    L.apdgicp_align.argtypes = [vp, vp, C.POINTER(Result)]
+    L.apdgicp_align_host_loop.argtypes = [vp, vp, C.POINTER(Result)]
+    L.apdgicp_get_final_hessian.argtypes = [vp, vp]
+    L.apdgicp_transform_source.argtypes = [vp, vp, vp, i64, i64]
+    L.apdgicp_fitness_score.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
+    L.apdgicp_batch_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
+    for f in (L.apdgicp_batch_destroy, L.apdgicp_batch_clear, L.apdgicp_batch_compute_covariances, L.apdgicp_batch_synchronize):
+        f.argtypes = [vp]
+    L.apdgicp_batch_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.apdgicp_batch_add_cloud.argtypes = [vp, vp, i64, i64, i32]
+    L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
+    L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
+    L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
+    L.apdgicp_batch_last_nn_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    if path is None:
+        _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().apdgicp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise ApdgicpError(rc, load_library().apdgicp_last_error().decode())
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cloud_arg(cloud):
+    """-> (pointer, n, stride_bytes, on_device, keepalive).  Accepts numpy [n,>=3] float32 or a
+    torch CUDA/CPU float32 tensor of the same shape (device pointers are passed straight through)."""
+    if hasattr(cloud, "data_ptr"):  # torch tensor
+        t = cloud
+        if t.dim() != 2 or t.shape[1] < 3 or str(t.dtype) != "torch.float32" or t.stride(1) != 1:
+            raise ValueError("cloud tensor must be [n, >=3] float32 with unit inner stride")
+        return C.c_void_p(t.data_ptr()), t.shape[0], t.stride(0) * 4, 1 if t.is_cuda else 0, t
+    a = np.asarray(cloud)
+    if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] < 3 or a.strides[1] != 4:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError("cloud must be [n, >=3]")
+    return _ptr(a), a.shape[0], a.strides[0], 0, a
+
+
+def _colmajor(T, dtype):
+    return np.asfortranarray(np.asarray(T, dtype=dtype))
+
+
+class FastAPDGICP:
+    """One registration object (== one fast_gicp::FastAPDGICP) on one GPU."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, stream=None):
+        self.L = load_library()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        _check(self.L.apdgicp_create(C.byref(self.params), device, stream, C.byref(self.h)))
+        self.n_src = self.n_tgt = 0
+        self.result = Result()
+        self._converged = False
+        self._final = np.eye(4, dtype=np.float32)
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.apdgicp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the setters of the ROS factory (registrations.cpp:41-48)
+    def _push(self):
+        _check(self.L.apdgicp_set_params(self.h, C.byref(self.params)))
+
+    def setNumThreads(self, n):  # A:34 -- no meaning on the GPU, accepted for drop-in compatibility
+        pass
+
+    def setTransformationEpsilon(self, eps):
+        self.params.transformation_epsilon = eps
+        self._push()
+
+    def setRotationEpsilon(self, eps):
+        self.params.rotation_epsilon = eps
+        self._push()
+
+    def setMaximumIterations(self, n):
+        self.params.max_iterations = n
+        self._push()
+
+    def setMaxCorrespondenceDistance(self, d):
+        self.params.max_correspondence_distance = d
+        self._push()
+
+    def setCorrespondenceRandomness(self, k):
+        self.params.k_correspondences = k
+        self._push()
+
+    def setRegularizationMethod(self, m):
+        self.params.regularization = m
+        self._push()
+
+    def setDistVar(self, v):
+        self.params.distance_variance = v
+        self._push()
+
+    def setAzimuthVar(self, v):
+        self.params.azimuth_variance_deg = v
+        self._push()
+
+    def setElevationVar(self, v):
+        self.params.elevation_variance_deg = v
+        self._push()
+
+    def setInitialLambdaFactor(self, v):
+        self.params.lm_init_lambda_factor = v
+        self._push()
+
+    def set_params(self, params: Params):
+        self.params = params
+        self._push()
+
+    # ---- clouds (A:90-108); token = identity of the caller's cloud object (pointer equality in the reference)
+    def setInputSource(self, cloud, token: int = 0):
+        p, n, stride, dev, keep = _cloud_arg(cloud)
+        _check(self.L.apdgicp_set_source(self.h, p, n, stride, dev, token))
+        self.n_src = n
+
+    def setInputTarget(self, cloud, token: int = 0):
+        p, n, stride, dev, keep = _cloud_arg(cloud)
+        _check(self.L.apdgicp_set_target(self.h, p, n, stride, dev, token))
+        self.n_tgt = n
+
+    def clearSource(self):
+        _check(self.L.apdgicp_clear_source(self.h))
+        self.n_src = 0
+
+    def clearTarget(self):
+        _check(self.L.apdgicp_clear_target(self.h))
+        self.n_tgt = 0
+
+    def swapSourceAndTarget(self):
+        _check(self.L.apdgicp_swap_source_and_target(self.h))
+        self.n_src, self.n_tgt = self.n_tgt, self.n_src
+
+    # ---- covariances (H:64-74)
+    def _n(self, which):
+        return self.n_src if which == SOURCE else self.n_tgt
+
+    def computeCovariances(self, which):
+        _check(self.L.apdgicp_compute_covariances(self.h, which))
+
+    def _get_covs(self, which):
+        n = self._n(which)
+        out = np.empty((n, 16))
+        _check(self.L.apdgicp_get_covariances(self.h, which, _ptr(out), n))
+        return out.reshape(n, 4, 4).transpose(0, 2, 1).copy()  # column-major -> numpy [n,4,4]
+
+    def getSourceCovariances(self):
+        return self._get_covs(SOURCE)
+
+    def getTargetCovariances(self):
+        return self._get_covs(TARGET)
+
+    def _set_covs(self, which, covs):
+        covs = np.asarray(covs, dtype=np.float64)
+        n = self._n(which)
+        if covs.shape == (n, 3, 3):
+            full = np.zeros((n, 4, 4))
+            full[:, :3, :3] = covs
+            covs = full
+        buf = np.ascontiguousarray(covs.transpose(0, 2, 1)).reshape(n, 16)
+        _check(self.L.apdgicp_set_covariances(self.h, which, _ptr(buf), n))
+
+    def setSourceCovariances(self, covs):
+        self._set_covs(SOURCE, covs)
+
+    def setTargetCovariances(self, covs):
+        self._set_covs(TARGET, covs)
+
+    # ---- probes (L:45-52, A:198-298)
+    def linearize(self, T, want_Hb: bool = True):
+        Tc = _colmajor(T, np.float64)
+        H = np.zeros((6, 6), order="F")
+        b = np.zeros(6)
+        cost = C.c_double()
+        _check(self.L.apdgicp_linearize(self.h, _ptr(Tc), _ptr(H) if want_Hb else None, _ptr(b) if want_Hb else None, C.byref(cost)))
+        return cost.value, (np.ascontiguousarray(H) if want_Hb else None), (b if want_Hb else None)
+
+    def evaluateCost(self, relative_pose, want_Hb: bool = False):  # L:50-52 (Matrix4f pose)
+        return self.linearize(np.asarray(relative_pose, dtype=np.float32).astype(np.float64), want_Hb)
+
+    def compute_error(self, T) -> float:
+        Tc = _colmajor(T, np.float64)
+        cost = C.c_double()
+        _check(self.L.apdgicp_compute_error(self.h, _ptr(Tc), C.byref(cost)))
+        return cost.value
+
+    def correspondences(self):
+        corr = np.empty(self.n_src, dtype=np.int32)
+        sqd = np.empty(self.n_src, dtype=np.float32)
+        _check(self.L.apdgicp_get_correspondences(self.h, _ptr(corr), _ptr(sqd), self.n_src))
+        return corr, sqd
+
+    def mahalanobis(self) -> np.ndarray:
+        out = np.empty((self.n_src, 16))
+        _check(self.L.apdgicp_get_mahalanobis(self.h, _ptr(out), self.n_src))
+        return out.reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3].copy()
+
+    # ---- align (pcl::Registration::align -> A:121-130 -> L:55-80)
+    def align(self, guess=None, host_loop: bool = False, want_output: bool = False):
+        g = None if guess is None else _colmajor(guess, np.float32)
+        fn = self.L.apdgicp_align_host_loop if host_loop else self.L.apdgicp_align
+        _check(fn(self.h, _ptr(g) if g is not None else None, C.byref(self.result)))
+        self._converged = bool(self.result.converged)
+        self._final = self.result.matrix()
+        if want_output:
+            return self.transformSource(self._final)
+        return self._final
+
+    def hasConverged(self) -> bool:
+        return self._converged
+
+    def getFinalTransformation(self) -> np.ndarray:
+        return self._final
+
+    def getFinalHessian(self) -> np.ndarray:
+        H = np.zeros((6, 6), order="F")
+        _check(self.L.apdgicp_get_final_hessian(self.h, _ptr(H)))
+        return np.ascontiguousarray(H)
+
+    def transformSource(self, T) -> np.ndarray:
+        out = np.empty((self.n_src, 3), dtype=np.float32)
+        Tc = _colmajor(T, np.float32)
+        _check(self.L.apdgicp_transform_source(self.h, _ptr(Tc), _ptr(out), self.n_src, 12))
+        return out
+
+    def getFitnessScore(self, max_range: float = float(np.finfo(np.float64).max), T=None):
+        Tc = _colmajor(self._final if T is None else T, np.float32)
+        score, cnt = C.c_double(), C.c_int64()
+        _check(self.L.apdgicp_fitness_score(self.h, _ptr(Tc), max_range, C.byref(score), C.byref(cnt)))
+        self.last_inliers = cnt.value
+        return score.value
+
+    @property
+    def nr_iterations(self):
+        return int(self.result.iterations)
+
+
+class BatchAPDGICP:
+    """Many independent registrations on one GPU (apdgicp_batch_*)."""
+
+    def __init__(self, params: Params | None = None, device: int = 0, stream=None):
+        self.L = load_library()
+        self.params = params or default_params()
+        self.b = C.c_void_p()
+        _check(self.L.apdgicp_batch_create(C.byref(self.params), device, stream, C.byref(self.b)))
+        self.n_clouds = 0
+
+    def close(self):
+        if getattr(self, "b", None):
+            self.L.apdgicp_batch_destroy(self.b)
+            self.b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params: Params):
+        self.params = params
+        _check(self.L.apdgicp_batch_set_params(self.b, C.byref(params)))
+
+    def clear(self):
+        _check(self.L.apdgicp_batch_clear(self.b))
+        self.n_clouds = 0
+
+    def add_cloud(self, cloud) -> int:
+        p, n, stride, dev, keep = _cloud_arg(cloud)
+        idx = _check(self.L.apdgicp_batch_add_cloud(self.b, p, n, stride, dev))
+        self.n_clouds = idx + 1
+        return idx
+
+    def compute_covariances(self):
+        _check(self.L.apdgicp_batch_compute_covariances(self.b))
+
+    @staticmethod
+    def make_pairs(pairs, guesses=None):
+        arr = (Pair * len(pairs))()
+        for i, (s, t) in enumerate(pairs):
+            arr[i].source_cloud, arr[i].target_cloud = int(s), int(t)
+            g = np.eye(4, dtype=np.float32) if guesses is None else np.asarray(guesses[i], dtype=np.float32)
+            arr[i].guess[:] = g.T.reshape(-1).tolist()
+        return arr
+
+    def align(self, pairs, guesses=None) -> np.ndarray:
+        """pairs: list of (source_cloud, target_cloud) or a prepared Pair array.  Returns a
+        structured numpy array (RESULT_DTYPE); T is column-major (use result_matrix)."""
+        arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
+        out = np.zeros(len(arr), dtype=RESULT_DTYPE)
+        _check(self.L.apdgicp_batch_align(self.b, arr, len(arr), _ptr(out)))
+        return out
+
+    def align_async(self, pairs, guesses=None):
+        """Runs the batch and leaves the results on the device; returns (device_pointer, n_bytes)."""
+        arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
+        dptr = C.c_void_p()
+        _check(self.L.apdgicp_batch_align_async(self.b, arr, len(arr), C.byref(dptr)))
+        return dptr.value, len(arr) * RESULT_DTYPE.itemsize
+
+    def synchronize(self):
+        _check(self.L.apdgicp_batch_synchronize(self.b))
+
+    def set_profiling(self, enable: bool):
+        _check(self.L.apdgicp_batch_set_profiling(self.b, 1 if enable else 0))
+
+    def last_nn_time(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.L.apdgicp_batch_last_nn_time(self.b, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_ticks(self):
+        a, s, t = C.c_int(), C.c_int(), C.c_int()
+        _check(self.L.apdgicp_batch_last_ticks(self.b, C.byref(a), C.byref(s), C.byref(t)))
+        return a.value, s.value, t.value
+
+
+def result_matrix(rec) -> np.ndarray:
+    return np.asarray(rec["T"], dtype=np.float32).reshape(4, 4).T.copy()

@@ -1,0 +1,401 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the committed golden
+vectors and against the CPU oracle on seeded inputs.
+
+Bars: correspondences / iteration counts / converged flags exact; fp32 squared distances bit-exact;
+covariances 1e-10; M, H, b, cost 5e-6 relative (the device's fp32 atan2f differs from glibc's in the
+last ulp and the APD model amplifies it near the +x axis); final transforms <= 1e-3 m and <= 1e-4 rad
+(north_star) -- asserted much tighter where the run is well conditioned.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import ref as R
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+REGS = (("none", 0), ("min_eig", 1), ("norm_min_eig", 2), ("plane", 3), ("frobenius", 4))
+T_TOL, R_TOL = 1e-3, 1e-4
+
+
+@pytest.fixture(scope="module")
+def reg():
+    import __graft_entry__ as g
+    g.build()
+    return importlib.import_module("riv-slam_amd.registration")
+
+
+def both(reg, src, tgt, **kw):
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    o = R.RefAPDGICP(R.default_params(**kw))
+    for x in (g, o):
+        x.setInputSource(src)
+        x.setInputTarget(tgt)
+    return g, o
+
+
+def info_of(g):
+    r = g.result
+    return [int(r.converged), int(r.iterations), int(r.n_linearize), int(r.n_compute_error)]
+
+
+# ------------------------------------------------------------------ covariances (a6)
+@pytest.mark.parametrize("name,mode", REGS)
+def test_cov_golden(reg, golden, name, mode):
+    g = reg.FastAPDGICP(reg.default_params(regularization=mode))
+    g.setInputSource(golden["cov_cloud"])
+    c = g.getSourceCovariances()
+    assert np.all(c[:, 3, :] == 0) and np.all(c[:, :, 3] == 0)
+    assert np.abs(c[:, :3, :3] - golden[f"cov_{name}"]).max() <= 1e-10
+
+
+def test_cov_vs_oracle_2k_and_ragged(reg, scene):
+    for n in (20, 21, 127, 129, 1000, 2048, 2500):
+        src, _, _, _ = scene.make_pair(n, 32, scene.pair_seed(7, n), "odometry")
+        g = reg.FastAPDGICP()
+        g.setInputSource(src)
+        o = R.RefAPDGICP()
+        o.setInputSource(src)
+        assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10, n
+
+
+def test_cov_k_values(reg, golden):
+    cloud = golden["lin_source"][:700]
+    for k in (5, 10, 32):
+        g = reg.FastAPDGICP(reg.default_params(k_correspondences=k, regularization=0))
+        g.setInputSource(cloud)
+        o = R.RefAPDGICP(R.default_params(k_correspondences=k, regularization=0))
+        o.setInputSource(cloud)
+        assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10, k
+
+
+def test_cov_duplicate_points(reg):
+    """Many identical points: ties are resolved by index, the selection must still be exact."""
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 10, size=(40, 3)).astype(np.float32)
+    cloud = np.repeat(base, 8, axis=0)  # every point 8 times -> 320 points, massive ties
+    g = reg.FastAPDGICP(reg.default_params(regularization=0))
+    g.setInputSource(cloud)
+    o = R.RefAPDGICP(R.default_params(regularization=0))
+    o.setInputSource(cloud)
+    assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
+
+
+# ------------------------------------------------------------------ linearize / compute_error (a7-a9)
+@pytest.mark.parametrize("tag,kw", (("default", {}), ("launch", LAUNCH)))
+def test_linearize_golden(reg, golden, tag, kw):
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    g.setInputSource(golden["lin_source"])
+    g.setInputTarget(golden["lin_target"])
+    for k in range(3):
+        cost, H, b = g.linearize(golden[f"lin_{tag}_{k}_T"])
+        corr, sqd = g.correspondences()
+        assert np.array_equal(corr, golden[f"lin_{tag}_{k}_corr"])
+        assert np.array_equal(sqd.view(np.uint32), golden[f"lin_{tag}_{k}_sqd"].view(np.uint32))
+        assert rel_err(H, golden[f"lin_{tag}_{k}_H"]) < 5e-6
+        assert rel_err(b, golden[f"lin_{tag}_{k}_b"]) < 5e-6
+        assert abs(cost - golden[f"lin_{tag}_{k}_cost"]) < 5e-6 * cost
+        assert np.allclose(H, H.T)
+        assert rel_err(g.mahalanobis()[:128], golden[f"lin_{tag}_{k}_maha128"]) < 5e-6
+        err = g.compute_error(golden[f"lin_{tag}_{k}_errT"])
+        assert abs(err - golden[f"lin_{tag}_{k}_err"]) < 5e-6 * err
+        cost_only, _, _ = g.linearize(golden[f"lin_{tag}_{k}_T"], want_Hb=False)
+        assert abs(cost_only - cost) <= 1e-12 * cost
+
+
+def test_linearize_with_injected_covariances_is_tight(reg, golden):
+    """With the oracle's covariances injected (setSourceCovariances, A:111-118) only the per-point
+    kernel differs; compare_error == linearize cost at the same pose (frozen state)."""
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(golden["lin_source"])
+    g.setInputTarget(golden["lin_target"])
+    g.setSourceCovariances(golden["lin_source_cov"])
+    g.setTargetCovariances(golden["lin_target_cov"])
+    T = golden["lin_launch_1_T"]
+    cost, H, b = g.linearize(T)
+    assert rel_err(H, golden["lin_launch_1_H"]) < 5e-6
+    assert abs(g.compute_error(T) - cost) <= 1e-12 * cost
+    assert np.abs(g.getSourceCovariances()[:, :3, :3] - golden["lin_source_cov"]).max() == 0.0
+
+
+def test_degenerate_golden(reg, golden):
+    g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
+    g.setInputSource(golden["deg_source"])
+    g.setInputTarget(golden["deg_target"])
+    cost, H, b = g.linearize(np.eye(4))
+    corr, sqd = g.correspondences()
+    assert np.array_equal(corr, golden["deg_corr"]) and corr[2] == -1
+    assert np.array_equal(sqd.view(np.uint32), golden["deg_sqd"].view(np.uint32))
+    assert rel_err(H, golden["deg_H"]) < 5e-6 and rel_err(b, golden["deg_b"]) < 5e-6
+    M = g.mahalanobis()
+    assert np.all(M[2] == 0)
+    # the +x-axis points carry the APD blow-up: compare those two matrices entry by entry, loosely
+    assert rel_err(M[:2], golden["deg_maha128"][:2]) < 1e-3
+    assert rel_err(M[3:128], golden["deg_maha128"][3:128]) < 5e-6
+
+
+def test_all_unmatched_is_not_an_error(reg, golden):
+    """No correspondence inside the gate: H = 0, d = 0, the reference converges at once (L:156-159 / rho = NaN)."""
+    src = golden["lin_source"][:256] + np.float32(1000.0)
+    kw = dict(max_correspondence_distance=1.0)
+    g, o = both(reg, src, golden["lin_target"][:256], **kw)
+    T, To = g.align(None), o.align(None)
+    assert info_of(g) == [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error]
+    assert np.array_equal(T, To) and g.result.n_matched == 0
+
+
+# ------------------------------------------------------------------ the optimiser (a11-a14)
+RUNS = {
+    "lm_default": {},
+    "lm_launch": LAUNCH,
+    "gn20": dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300),
+    "lm_loop": dict(max_correspondence_distance=2.5),
+}
+
+
+@pytest.mark.parametrize("host_loop", (False, True))
+@pytest.mark.parametrize("tag", list(RUNS))
+def test_align_golden(reg, golden, scene, tag, host_loop):
+    pre = "lm_loop" if tag == "lm_loop" else "lin"
+    g = reg.FastAPDGICP(reg.default_params(**RUNS[tag]))
+    g.setInputSource(golden[f"{pre}_source"])
+    g.setInputTarget(golden[f"{pre}_target"])
+    T = g.align(golden[f"{pre}_guess"], host_loop=host_loop)
+    assert info_of(g) == list(golden[f"{tag}_info"])
+    te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+    assert te <= T_TOL and re_ <= R_TOL
+    assert te <= 1e-5 and re_ <= 1e-6, (te, re_)
+    assert rel_err(g.getFinalHessian(), golden[f"{tag}_final_hessian"]) < 1e-4
+    assert g.hasConverged() == bool(golden[f"{tag}_info"][0])
+
+
+@pytest.mark.parametrize("tag,kw", (("rej", {}), ("fail", dict(lm_max_iterations=1))))
+def test_lm_rejection_and_failure_paths(reg, golden, scene, tag, kw):
+    """rho < 0 -> lambda *= nu (L:156-164) and the 'lm not converged' exit (L:71-74,172)."""
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    g.setInputSource(golden["rej_source"])
+    g.setInputTarget(golden["rej_target"])
+    for host_loop in (False, True):
+        T = g.align(None, host_loop=host_loop)
+        assert info_of(g) == list(golden[f"{tag}_info"])
+        assert g.result.n_compute_error > g.result.n_linearize or tag == "fail"
+        te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+        assert te <= T_TOL and re_ <= R_TOL
+        assert bool(g.result.lm_failed) == (tag == "fail")
+
+
+def test_max_iterations_zero_returns_guess(reg, golden):
+    g = reg.FastAPDGICP(reg.default_params(max_iterations=0))
+    g.setInputSource(golden["lin_source"][:512])
+    g.setInputTarget(golden["lin_target"][:512])
+    T = g.align(golden["lin_guess"])
+    assert np.array_equal(T[:3], golden["lin_guess"][:3]) and not g.hasConverged() and g.result.n_linearize == 0
+
+
+def test_align_seeded_pairs_vs_oracle(reg, scene):
+    """Seeded pairs the golden file does not hold: odometry + loop closure, launch parameters."""
+    for idx, (kind, n, m) in enumerate((("odometry", 3000, 2500), ("loop", 1500, 4097), ("odometry", 4096, 4096))):
+        src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(3, idx), kind)
+        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+        g, o = both(reg, src, tgt, **kw)
+        T, To = g.align(guess), o.align(guess)
+        assert info_of(g) == [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error]
+        te, re_ = scene.pose_error(To, T)
+        assert te <= T_TOL and re_ <= R_TOL, (kind, te, re_)
+        cg, _ = g.correspondences()
+        co, _ = o.correspondences()
+        assert np.array_equal(cg, co)
+
+
+def test_full_size_8k_pair(reg, scene):
+    """BASELINE configs[1]: 8k x 8k, GN-20; correspondences at the guess bit-exact, final pose within the
+    north-star tolerance, plus size-independent properties."""
+    src, tgt, _, guess = scene.make_pair(8192, 8192, scene.pair_seed(2, 0), "odometry")
+    kw = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
+              max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    g, o = both(reg, src, tgt, **kw)
+    c1, H1, b1 = g.linearize(guess.astype(np.float64))
+    c2, H2, b2 = o.linearize(guess.astype(np.float64))
+    cg, sg = g.correspondences()
+    co, so = o.correspondences()
+    assert np.array_equal(cg, co) and np.array_equal(sg.view(np.uint32), so.view(np.uint32))
+    assert rel_err(H1, H2) < 5e-6 and rel_err(b1, b2) < 5e-6 and abs(c1 - c2) < 5e-6 * c2
+    T, To = g.align(guess), o.align(guess)
+    assert g.result.n_linearize == 20 == o.n_linearize
+    te, re_ = scene.pose_error(To, T)
+    assert te <= T_TOL and re_ <= R_TOL, (te, re_)
+    # property: registering a cloud against itself from identity is a fixed point
+    g.setInputSource(tgt)
+    Ti = g.align(None)
+    assert np.abs(Ti - np.eye(4)).max() < 1e-6
+    # property: linearize is invariant to the order of the target points except for the indices
+    perm = np.random.default_rng(0).permutation(len(tgt))
+    g.setInputSource(src)
+    g.setInputTarget(tgt[perm])
+    c3, H3, b3 = g.linearize(guess.astype(np.float64))
+    cp, sp = g.correspondences()
+    assert np.array_equal(sp.view(np.uint32), sg.view(np.uint32))
+    ok = cp >= 0
+    assert np.array_equal(ok, cg >= 0)
+    same_point = np.all(tgt[perm][cp[ok]] == tgt[cg[ok]], axis=1)
+    assert same_point.mean() > 0.999  # exact-tie targets may swap
+    assert rel_err(H3, H1) < 1e-6
+
+
+# ------------------------------------------------------------------ object semantics (a3-a5)
+def test_caching_tokens_swap_and_clear(reg, golden, scene):
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(src, token=11)
+    g.setInputTarget(tgt, token=22)
+    T1 = g.align(guess)
+    g.setInputTarget(np.zeros_like(tgt), token=22)   # same token: pointer-equality early return (A:102-104)
+    T2 = g.align(guess)
+    assert np.array_equal(T1, T2)
+    g.swapSourceAndTarget()                          # A:68-75
+    Tinv = g.align(np.linalg.inv(guess.astype(np.float64)).astype(np.float32))
+    o = R.RefAPDGICP(R.default_params(**LAUNCH))
+    o.setInputSource(tgt)
+    o.setInputTarget(src)
+    To = o.align(np.linalg.inv(guess.astype(np.float64)).astype(np.float32))
+    te, re_ = scene.pose_error(To, Tinv)
+    assert te <= T_TOL and re_ <= R_TOL
+    g.clearSource()                                  # A:78-81
+    with pytest.raises(reg.ApdgicpError) as e:
+        g.align(guess)
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("stride_floats", (3, 4, 8))
+def test_point_strides(reg, golden, stride_floats):
+    """packed xyz, float4 and the 32-byte pcl::PointXYZI layout (x,y,z,1,intensity,pad)."""
+    src, tgt = golden["lin_source"][:999], golden["lin_target"][:1001]
+
+    def widen(a):
+        w = np.full((len(a), stride_floats), 7.0, dtype=np.float32)
+        w[:, :3] = a
+        return w
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(widen(src))
+    g.setInputTarget(widen(tgt))
+    h = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    h.setInputSource(src)
+    h.setInputTarget(tgt)
+    a, b = g.linearize(np.eye(4)), h.linearize(np.eye(4))
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+def test_device_pointer_input_and_output_cloud(reg, golden):
+    import torch
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(torch.from_numpy(src).cuda())
+    g.setInputTarget(torch.from_numpy(tgt).cuda())
+    out = g.align(guess, want_output=True)            # pcl::transformPointCloud, L:79
+    T = g.getFinalTransformation()
+    want = src @ T[:3, :3].T + T[:3, 3]
+    assert np.abs(out - want).max() < 1e-4
+    h = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    h.setInputSource(src)
+    h.setInputTarget(tgt)
+    assert np.array_equal(h.align(guess), T)
+
+
+def test_errors_are_codes_not_crashes(reg, golden):
+    g = reg.FastAPDGICP()
+    with pytest.raises(reg.ApdgicpError) as e:
+        g.align(None)
+    assert e.value.code == -3
+    g.setInputSource(golden["lin_source"][:10])   # fewer than k points
+    g.setInputTarget(golden["lin_target"][:100])
+    with pytest.raises(reg.ApdgicpError) as e:
+        g.align(None)
+    assert e.value.code == -4
+    with pytest.raises(reg.ApdgicpError) as e:
+        g.setCorrespondenceRandomness(33)
+    assert e.value.code == -5
+    g.params.k_correspondences = 20
+    with pytest.raises(reg.ApdgicpError):
+        g.setRegularizationMethod(9)
+    with pytest.raises(reg.ApdgicpError):
+        g.compute_error(np.eye(4))
+
+
+def test_two_handles_two_threads(reg, golden):
+    """Several registration objects coexist in one process (three in the nodelet manager)."""
+    import threading
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    outs = {}
+
+    def work(i):
+        g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+        g.setInputSource(src)
+        g.setInputTarget(tgt)
+        for _ in range(3):
+            outs[i] = g.align(guess)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_fitness_score(reg, golden):
+    import apdgicp_np as O
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(src)
+    g.setInputTarget(tgt)
+    T = g.align(guess)
+    pt = O.transform_points_f32(T.astype(np.float64), src)
+    _, sq = O.nn1(pt, tgt)
+    for max_range in (np.finfo(np.float64).max, 4.0, 0.25):
+        sel = sq.astype(np.float64) <= max_range
+        want = sq[sel].astype(np.float64).mean()
+        got = g.getFitnessScore(max_range)
+        assert abs(got - want) < 1e-9 * want and g.last_inliers == sel.sum()
+
+
+# ------------------------------------------------------------------ batched registrations (8e / C3)
+def test_batch_matches_single(reg, golden, scene):
+    clouds, pairs, guesses = [], [], []
+    for i in range(5):
+        n = (2048, 1500, 2300, 1024, 2048)[i]
+        s, t, _, gs = scene.make_pair(n, n + 17 * i, scene.pair_seed(4, i), "odometry" if i % 2 == 0 else "loop")
+        clouds += [s, t]
+        pairs.append((2 * i, 2 * i + 1))
+        guesses.append(gs)
+    pairs.append((0, 3))          # clouds shared between pairs
+    guesses.append(np.eye(4, dtype=np.float32))
+    kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    for c in clouds:
+        b.add_cloud(c)
+    res = b.align(pairs, guesses)
+    for i, (s, t) in enumerate(pairs):
+        g = reg.FastAPDGICP(reg.default_params(**kw))
+        g.setInputSource(clouds[s])
+        g.setInputTarget(clouds[t])
+        T = g.align(guesses[i])
+        assert np.array_equal(reg.result_matrix(res[i]), T), i
+        assert [res[i]["converged"], res[i]["iterations"], res[i]["n_linearize"], res[i]["n_compute_error"]] == info_of(g)
+        o = R.RefAPDGICP(R.default_params(**kw))
+        o.setInputSource(clouds[s])
+        o.setInputTarget(clouds[t])
+        To = o.align(guesses[i])
+        te, re_ = scene.pose_error(To, T)
+        assert te <= T_TOL and re_ <= R_TOL
+    # one source against several keyframe targets (BASELINE configs[2])
+    res2 = b.align([(0, 1), (0, 3), (0, 5), (0, 7)])
+    assert res2["n_linearize"].min() >= 1
+
+
+def test_batch_is_deterministic(reg, scene):
+    s, t, _, gs = scene.make_pair(2048, 2048, scene.pair_seed(4, 77), "odometry")
+    b = reg.BatchAPDGICP(reg.default_params(**LAUNCH))
+    i0, i1 = b.add_cloud(s), b.add_cloud(t)
+    r1 = b.align([(i0, i1)] * 7, [gs] * 7)
+    r2 = b.align([(i0, i1)] * 7, [gs] * 7)
+    assert np.array_equal(r1["T"], r2["T"]) and np.all(r1["T"] == r1["T"][0])
