@@ -170,6 +170,9 @@ int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p);
 int apdgicp_batch_clear(apdgicp_batch* b);
 /* returns the cloud's index (>= 0) or a negative status */
 int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
+/* replaces cloud `index` (0 <= index <= number of clouds; == appends) in place, reusing its device
+ * buffers; its covariances are recomputed by the next align */
+int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
 /* covariances of every cloud that does not have them yet (align does this lazily as well) */
 int apdgicp_batch_compute_covariances(apdgicp_batch* b);
 /* aligns all pairs; results[i] belongs to pairs[i].  `results` is host memory. */
@@ -179,6 +182,9 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
  * gather results with RCCL.  apdgicp_batch_synchronize() waits for the stream. */
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results);
 int apdgicp_batch_synchronize(apdgicp_batch* b);
+/* copies the n_pairs result records of the last align into caller memory (device pointer when
+ * dst_on_device != 0, e.g. a tensor that RCCL will all-gather) and waits for the copy */
+int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int dst_on_device);
 /* Measurement hooks (bench.py's roofline leg).  With profiling enabled every launch of the dominant
  * kernel (brute-force nearest neighbour) is bracketed by HIP events on the batch's stream;
  * last_nn_time returns their summed milliseconds and the launch count for the last align;

@@ -501,6 +501,15 @@ int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64
   });
 }
 
+int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    if (index < 0 || index > (int)b->eng.clouds.size()) return fail(APDGICP_ERR_INVALID_ARG, "cloud index out of range");
+    APD_TRY(b->eng.set_cloud(index, xyz, n, stride_bytes, on_device, 0));
+    return index;
+  });
+}
+
 int apdgicp_batch_compute_covariances(apdgicp_batch* b) {
   return guarded([&]() -> int {
     if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
@@ -535,6 +544,16 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
 int apdgicp_batch_synchronize(apdgicp_batch* b) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   APD_HIP(hipStreamSynchronize(b->eng.stream));
+  return 0;
+}
+
+int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int dst_on_device) {
+  if (!b || !dst) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  Engine& e = b->eng;
+  if (n_pairs <= 0 || n_pairs > e.npairs) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs exceeds the last batch");
+  APD_HIP(hipSetDevice(e.device));
+  APD_HIP(hipMemcpyAsync(dst, e.d_results.p, n_pairs * sizeof(apdgicp_result), dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e.stream));
+  APD_HIP(hipStreamSynchronize(e.stream));
   return 0;
 }
 

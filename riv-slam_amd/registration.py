@@ -86,8 +86,8 @@ SYMBOLS = [
     "apdgicp_get_mahalanobis", "apdgicp_align", "apdgicp_align_host_loop", "apdgicp_get_final_hessian",
     "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_synchronize",
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
-    "apdgicp_batch_add_cloud", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
-    "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_set_profiling",
+    "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
+    "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
     "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks",
 ]
 
@@ -100,6 +100,13 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  Whichever copy is
+    # loaded first serves the whole process, and two different ROCm runtimes in one process do not
+    # work ("No HIP GPUs are available"), so when torch is installed let it load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
@@ -135,8 +142,10 @@ def load_library(path: str | None = None):
         f.argtypes = [vp]
     L.apdgicp_batch_set_params.argtypes = [vp, C.POINTER(Params)]
     L.apdgicp_batch_add_cloud.argtypes = [vp, vp, i64, i64, i32]
+    L.apdgicp_batch_set_cloud.argtypes = [vp, i32, vp, i64, i64, i32]
     L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
     L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
+    L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
     L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
     L.apdgicp_batch_last_nn_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
@@ -423,6 +432,12 @@ class BatchAPDGICP:
         self.n_clouds = idx + 1
         return idx
 
+    def set_cloud(self, index: int, cloud) -> int:
+        p, n, stride, dev, keep = _cloud_arg(cloud)
+        idx = _check(self.L.apdgicp_batch_set_cloud(self.b, index, p, n, stride, dev))
+        self.n_clouds = max(self.n_clouds, idx + 1)
+        return idx
+
     def compute_covariances(self):
         _check(self.L.apdgicp_batch_compute_covariances(self.b))
 
@@ -452,6 +467,13 @@ class BatchAPDGICP:
 
     def synchronize(self):
         _check(self.L.apdgicp_batch_synchronize(self.b))
+
+    def copy_results_to(self, dst, n_pairs: int):
+        """dst: torch uint8 tensor (device or host) or numpy array with room for n_pairs records."""
+        if hasattr(dst, "data_ptr"):
+            _check(self.L.apdgicp_batch_copy_results(self.b, C.c_void_p(dst.data_ptr()), n_pairs, 1 if dst.is_cuda else 0))
+        else:
+            _check(self.L.apdgicp_batch_copy_results(self.b, _ptr(dst), n_pairs, 0))
 
     def set_profiling(self, enable: bool):
         _check(self.L.apdgicp_batch_set_profiling(self.b, 1 if enable else 0))
