@@ -1,0 +1,196 @@
+// fast_gicp::FastAPDGICPHip -- drop-in replacement for fast_gicp::FastAPDGICP
+// (/root/reference/fast_apdgicp/include/fast_gicp/gicp/fast_apdgicp.hpp:19-110) that runs the whole
+// registration on an MI355X through the C ABI of libapdgicp_hip.so (include/apdgicp_hip.h).
+//
+// It derives from pcl::Registration<PointSource, PointTarget, float> exactly like the reference, so
+// radar_graph_slam's select_registration_method() (registrations.cpp:38-50) can return it through the
+// same pcl::Registration<PointXYZI,PointXYZI>::Ptr, and the callers' setInputTarget / setInputSource /
+// align / hasConverged / getFinalTransformation / getFitnessScore / getSearchMethodTarget keep working
+// (the last two are served by the PCL base class on its own tree_).
+//
+// Header-only; needs only <pcl/registration/registration.h> (and whatever it pulls in) plus
+// apdgicp_hip.h.  Error convention of the reference: no exceptions, no return codes -- a failed call
+// leaves hasConverged() == false and prints one line on stderr (lsq_registration_impl.hpp:72).
+#ifndef FAST_GICP_FAST_APDGICP_HIP_HPP
+#define FAST_GICP_FAST_APDGICP_HIP_HPP
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include <pcl/registration/registration.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "apdgicp_hip.h"
+
+namespace fast_gicp {
+
+#ifndef FAST_GICP_GICP_SETTINGS_HPP  // same enum as gicp/gicp_settings.hpp:6 when that header is absent
+#define FAST_GICP_GICP_SETTINGS_HPP
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };
+#endif
+
+template <typename PointSource, typename PointTarget>
+class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float> {
+ public:
+  using Scalar = float;
+  using Base = pcl::Registration<PointSource, PointTarget, Scalar>;
+  using Matrix4 = typename Base::Matrix4;
+  using PointCloudSource = typename Base::PointCloudSource;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTarget = typename Base::PointCloudTarget;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+  using CovVector = std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>;
+#if PCL_VERSION >= PCL_VERSION_CALC(1, 10, 0)
+  using Ptr = pcl::shared_ptr<FastAPDGICPHip<PointSource, PointTarget>>;
+  using ConstPtr = pcl::shared_ptr<const FastAPDGICPHip<PointSource, PointTarget>>;
+#else
+  using Ptr = boost::shared_ptr<FastAPDGICPHip<PointSource, PointTarget>>;
+  using ConstPtr = boost::shared_ptr<const FastAPDGICPHip<PointSource, PointTarget>>;
+#endif
+
+ protected:
+  using Base::converged_;
+  using Base::corr_dist_threshold_;
+  using Base::final_transformation_;
+  using Base::input_;
+  using Base::max_iterations_;
+  using Base::nr_iterations_;
+  using Base::reg_name_;
+  using Base::target_;
+  using Base::transformation_epsilon_;
+
+ public:
+  explicit FastAPDGICPHip(int device = 0) {
+    reg_name_ = "FastAPDGICPHip";
+    apdgicp_default_params(&params_);
+    // the values the reference constructors put into the pcl::Registration members
+    // (fast_apdgicp_impl.hpp:23, lsq_registration_impl.hpp:13-15)
+    corr_dist_threshold_ = params_.max_correspondence_distance;
+    max_iterations_ = params_.max_iterations;
+    transformation_epsilon_ = params_.transformation_epsilon;
+    if (apdgicp_create(&params_, device, nullptr, &handle_) != 0) report("apdgicp_create");
+  }
+  ~FastAPDGICPHip() override {
+    if (handle_) apdgicp_destroy(handle_);
+  }
+  FastAPDGICPHip(const FastAPDGICPHip&) = delete;
+  FastAPDGICPHip& operator=(const FastAPDGICPHip&) = delete;
+
+  bool ok() const { return handle_ != nullptr; }  // false when no GPU / library error at construction
+
+  // ---- setters of the reference (fast_apdgicp_impl.hpp:34-65, lsq_registration_impl.hpp:30-42)
+  void setNumThreads(int) {}  // OpenMP team size: meaningless on the GPU, kept for source compatibility
+  void setCorrespondenceRandomness(int k) { params_.k_correspondences = k; }
+  void setRegularizationMethod(RegularizationMethod m) { params_.regularization = static_cast<int>(m); }
+  void setAzimuthVar(double v) { params_.azimuth_variance_deg = v; }
+  void setElevationVar(double v) { params_.elevation_variance_deg = v; }
+  void setDistVar(double v) { params_.distance_variance = v; }
+  void setRotationEpsilon(double eps) { params_.rotation_epsilon = eps; }
+  void setInitialLambdaFactor(double f) { params_.lm_init_lambda_factor = f; }
+  void setDebugPrint(bool) {}
+  /// not in the reference (its optimizer enum is protected without a setter, lsq_registration.hpp:78)
+  void setOptimizer(apdgicp_optimizer o) { params_.optimizer = o; }
+
+  // ---- cache management (fast_apdgicp_impl.hpp:68-108)
+  virtual void swapSourceAndTarget() {
+    input_.swap(target_);
+    if (handle_ && apdgicp_swap_source_and_target(handle_) != 0) report("swapSourceAndTarget");
+  }
+  virtual void clearSource() {
+    input_.reset();
+    if (handle_) apdgicp_clear_source(handle_);
+  }
+  virtual void clearTarget() {
+    target_.reset();
+    if (handle_) apdgicp_clear_target(handle_);
+  }
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {
+    if (input_ == cloud) return;  // pointer equality keeps the cached covariances, :91-93
+    Base::setInputSource(cloud);
+    if (handle_ && cloud && !cloud->empty() &&
+        apdgicp_set_source(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointSource), 0, token_of(cloud.get())) != 0)
+      report("setInputSource");
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
+    if (target_ == cloud) return;  // :102-104
+    Base::setInputTarget(cloud);
+    if (handle_ && cloud && !cloud->empty() &&
+        apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
+      report("setInputTarget");
+  }
+  virtual void setSourceCovariances(const CovVector& covs) {
+    if (handle_ && apdgicp_set_covariances(handle_, APDGICP_SOURCE, covs[0].data(), (int64_t)covs.size()) != 0) report("setSourceCovariances");
+  }
+  virtual void setTargetCovariances(const CovVector& covs) {
+    if (handle_ && apdgicp_set_covariances(handle_, APDGICP_TARGET, covs[0].data(), (int64_t)covs.size()) != 0) report("setTargetCovariances");
+  }
+  /// by value (the reference returns a const& to host-resident storage, fast_apdgicp.hpp:67-73)
+  CovVector getSourceCovariances() { return get_covs(APDGICP_SOURCE, input_ ? input_->size() : 0); }
+  CovVector getTargetCovariances() { return get_covs(APDGICP_TARGET, target_ ? target_->size() : 0); }
+
+  // ---- LsqRegistration probes (lsq_registration_impl.hpp:45-52); H6/B6: any type with double* data()
+  template <typename H6>
+  void getFinalHessian(H6& H) {
+    if (handle_) apdgicp_get_final_hessian(handle_, H.data());
+  }
+  template <typename H6 = Eigen::Matrix4d, typename B6 = Eigen::Matrix4d>
+  double evaluateCost(const Matrix4& relative_pose, H6* H = nullptr, B6* b = nullptr) {
+    push_params();
+    double T[16], cost = 0.0;
+    for (int i = 0; i < 16; i++) T[i] = (double)relative_pose.data()[i];
+    if (!handle_ || apdgicp_linearize(handle_, T, H ? H->data() : nullptr, b ? b->data() : nullptr, &cost) != 0) report("evaluateCost");
+    return cost;
+  }
+  const apdgicp_result& lastResult() const { return result_; }
+
+ protected:
+  // pcl::Registration::align -> this (fast_apdgicp_impl.hpp:121-130 + lsq_registration_impl.hpp:55-80)
+  void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
+    converged_ = false;
+    final_transformation_ = guess;
+    if (!handle_ || !input_ || !target_) {
+      report("align (no GPU handle or no input)");
+      return;
+    }
+    push_params();
+    if (apdgicp_align(handle_, guess.data(), &result_) != 0) {
+      report("align");
+      return;
+    }
+    for (int i = 0; i < 16; i++) final_transformation_.data()[i] = result_.T[i];  // both column-major
+    converged_ = result_.converged != 0;
+    nr_iterations_ = result_.iterations;
+    if (result_.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:72
+    // pcl::transformPointCloud(*input_, output, final_transformation_), :79
+    output.points = input_->points;
+    if (apdgicp_transform_source(handle_, result_.T, &output.points[0].x, (int64_t)output.size(), (int64_t)sizeof(PointSource)) != 0)
+      report("transformPointCloud");
+  }
+
+ private:
+  static uint64_t token_of(const void* p) { return (uint64_t)(uintptr_t)p; }
+  void push_params() {  // the PCL base-class setters write plain members; read them at call time
+    params_.max_correspondence_distance = corr_dist_threshold_;
+    params_.max_iterations = max_iterations_;
+    params_.transformation_epsilon = transformation_epsilon_;
+    if (handle_ && apdgicp_set_params(handle_, &params_) != 0) report("set_params");
+  }
+  CovVector get_covs(int which, std::size_t n) {
+    CovVector out(n);
+    if (n && handle_) {
+      push_params();
+      if (apdgicp_get_covariances(handle_, which, out[0].data(), (int64_t)n) != 0) report("getCovariances");
+    }
+    return out;
+  }
+  void report(const char* what) const { std::fprintf(stderr, "[FastAPDGICPHip] %s failed: %s\n", what, apdgicp_last_error()); }
+
+  apdgicp_handle* handle_ = nullptr;
+  apdgicp_params params_;
+  apdgicp_result result_{};
+};
+
+}  // namespace fast_gicp
+#endif

@@ -1,0 +1,71 @@
+// Drives fast_gicp::FastAPDGICPHip the way RIV-SLAM does: created like the FAST_APDGICP branch of
+// select_registration_method() (registrations.cpp:38-50), used through the pcl::Registration base
+// pointer like ScanMatchingOdometryNodelet::matching() (scan_matching_odometry_nodelet.cpp:437-482).
+// usage: test_adapter <pair.bin> [compile-only check when no file is given]
+//   pair.bin: int32 n_src, int32 n_tgt, float guess[16] (column-major), src xyz[n_src*3], tgt xyz[n_tgt*3]
+// prints: converged iterations T[16] (column-major) and the first transformed output point
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fast_apdgicp_hip.hpp"
+
+using PointT = pcl::PointXYZI;
+
+pcl::Registration<PointT, PointT>::Ptr select_registration_method_hip() {
+  fast_gicp::FastAPDGICPHip<PointT, PointT>::Ptr apdgicp(new fast_gicp::FastAPDGICPHip<PointT, PointT>());
+  apdgicp->setNumThreads(0);
+  apdgicp->setTransformationEpsilon(0.1);        // launch:96
+  apdgicp->setMaximumIterations(64);
+  apdgicp->setMaxCorrespondenceDistance(2.0);    // launch:98
+  apdgicp->setCorrespondenceRandomness(20);
+  apdgicp->setDistVar(0.86);
+  apdgicp->setAzimuthVar(1.0);                   // launch:35
+  apdgicp->setElevationVar(1.0);
+  return apdgicp;
+}
+
+static pcl::PointCloud<PointT>::Ptr make_cloud(const float* xyz, int n) {
+  pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>());
+  c->resize(n);
+  for (int i = 0; i < n; i++) {
+    c->at(i).x = xyz[3 * i], c->at(i).y = xyz[3 * i + 1], c->at(i).z = xyz[3 * i + 2];
+    c->at(i).intensity = 42.f;
+  }
+  return c;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::printf("compile-only\n");
+    return 0;
+  }
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  int n[2];
+  float guess[16];
+  if (std::fread(n, 4, 2, f) != 2 || std::fread(guess, 4, 16, f) != 16) return 2;
+  std::vector<float> s(3 * n[0]), t(3 * n[1]);
+  if (std::fread(s.data(), 4, s.size(), f) != s.size() || std::fread(t.data(), 4, t.size(), f) != t.size()) return 2;
+  std::fclose(f);
+
+  auto registration = select_registration_method_hip();
+  auto source = make_cloud(s.data(), n[0]);
+  auto target = make_cloud(t.data(), n[1]);
+  registration->setInputTarget(target);
+  registration->setInputSource(source);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  pcl::Registration<PointT, PointT>::Matrix4 g;
+  for (int i = 0; i < 16; i++) g.data()[i] = guess[i];
+  registration->align(*aligned, g);
+  // second frame against the same keyframe: the target pointer is unchanged -> cached covariances
+  registration->setInputTarget(target);
+  registration->align(*aligned, g);
+  const auto T = registration->getFinalTransformation();
+  std::printf("%d", registration->hasConverged() ? 1 : 0);
+  auto* hip = dynamic_cast<fast_gicp::FastAPDGICPHip<PointT, PointT>*>(registration.get());
+  std::printf(" %d", hip->lastResult().iterations);
+  for (int i = 0; i < 16; i++) std::printf(" %.9g", T.data()[i]);
+  std::printf(" %.9g %.9g %.9g %.9g\n", aligned->at(0).x, aligned->at(0).y, aligned->at(0).z, aligned->at(0).intensity);
+  return 0;
+}

@@ -1,0 +1,1 @@
+#include <pcl/pcl_shim_core.h>

@@ -19,7 +19,7 @@ for r in rows:
     print(f"| {name} | {r[1]} | {r[2]/1e3:.1f} | {r[3]/1e3:.2f} | {r[4]/1e3:.2f} | {r[5]/1e3:.2f} | {100*r[2]/total:.1f} | {r[6]} | {r[7]} | {r[8]} | "
           f"({r[9]},{r[10]},{r[11]}) | {r[12]} |")
 try:
-    pm = db.execute("select name, counter_name, avg(value), count(*) from counters_collection group by name, counter_name order by name").fetchall()
+    pm = db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name order by kernel_name").fetchall()
     if pm:
         print("\n## PMC counters (average per dispatch)\n\n| kernel | counter | avg | dispatches |\n|---|---|---|---|")
         for r in pm:
