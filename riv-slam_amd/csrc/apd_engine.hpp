@@ -75,10 +75,14 @@ inline int env_int(const char* name, int dflt) {
 class Engine {
  public:
   struct Cloud {
-    DevBuf pts, cov;
+    DevBuf opts;                     // caller's order, float4
+    DevBuf pts, perm, cbox, gbox;    // Z-curve order + boxes (apd_sort.hpp), valid when `sorted`
+    DevBuf cov;                      // sorted order
     int n = 0;
+    bool sorted = false;
     bool cov_valid = false;
     uint64_t token = 0;
+    void release_all() { opts.release(), pts.release(), perm.release(), cbox.release(), gbox.release(), cov.release(); }
   };
 
   int device = 0;
@@ -92,9 +96,12 @@ class Engine {
   int npairs = 0, nmax_src = 0;
   std::vector<PairDesc> h_pairs;
   DevBuf d_desc, d_pairs, d_state, d_results, d_status, d_guess, d_ids, d_errflag, d_probe, d_stage, d_T;
+  DevBuf d_jobs, d_keys, d_box6, d_listoff, d_glist;
   DevBuf b_nnpart, b_corr, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
+  bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
+  bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
   int* h_status = nullptr;   // pinned
   double* h_probe = nullptr; // pinned, 48 doubles
   hipEvent_t ev_poll = nullptr;
@@ -126,6 +133,10 @@ class Engine {
     APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
     APD_TRY(d_probe.ensure(64 * sizeof(double)));
     APD_TRY(d_T.ensure(16 * sizeof(double)));
+    const char* m = getenv("APDGICP_NN_MODE");
+    nn_pruned = !(m && std::string(m) == "brute");
+    m = getenv("APDGICP_KNN_MODE");
+    knn_pruned = !(m && std::string(m) == "brute");
     return set_params(p);
   }
 
@@ -133,9 +144,9 @@ class Engine {
     hipError_t e;
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
-    for (auto& c : clouds) c.pts.release(), c.cov.release();
-    for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &b_nnpart,
-                      &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+    for (auto& c : clouds) c.release_all();
+    for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &d_jobs,
+                      &d_keys, &d_box6, &d_listoff, &d_glist, &b_nnpart, &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
@@ -185,8 +196,8 @@ class Engine {
     if ((int)clouds.size() <= slot) clouds.resize(slot + 1);
     Cloud& c = clouds[slot];
     // the previous contents may still be in use by queued kernels on this stream; stream order protects us
-    if ((size_t)n * 16 > c.pts.cap) APD_HIP(hipStreamSynchronize(stream));
-    APD_TRY(c.pts.ensure((size_t)n * 16));
+    if ((size_t)n * 16 > c.opts.cap) APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
     if (!on_device) {
       const size_t bytes = (size_t)(n - 1) * stride_bytes + 12;
@@ -195,10 +206,11 @@ class Engine {
       APD_HIP(hipMemcpyAsync(d_stage.p, xyz, bytes, hipMemcpyHostToDevice, stream));
       raw = (const char*)d_stage.p;
     }
-    hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.pts.as<float4>());
+    hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.opts.as<float4>());
     APD_HIP(hipGetLastError());
     if (!on_device) APD_HIP(hipStreamSynchronize(stream));  // the host buffer may be released by the caller now
     c.n = (int)n;
+    c.sorted = false;  // Z-curve sort is deferred so that a batch of clouds is sorted by ONE launch
     c.cov_valid = false;
     c.token = token;
     desc_dirty = true;
@@ -208,18 +220,99 @@ class Engine {
   void clear_cloud(int slot) {
     if (slot < (int)clouds.size()) {
       clouds[slot].n = 0;
+      clouds[slot].sorted = false;
       clouds[slot].cov_valid = false;
       clouds[slot].token = 0;
       desc_dirty = true;
     }
   }
 
+  // Z-curve sort + chunk/group boxes of every cloud that was (re)set since the last call
+  int sort_clouds() {
+    std::vector<SortJob> small;
+    std::vector<int> large;
+    int np2max = 1;
+    bool grew = false;
+    for (size_t i = 0; i < clouds.size(); i++) {
+      Cloud& c = clouds[i];
+      if (c.n <= 0 || c.sorted) continue;
+      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
+      grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || ngr * sizeof(Box) > c.gbox.cap;
+    }
+    if (grew) APD_HIP(hipStreamSynchronize(stream));  // old buffers may still be read by queued kernels
+    for (size_t i = 0; i < clouds.size(); i++) {
+      Cloud& c = clouds[i];
+      if (c.n <= 0 || c.sorted) continue;
+      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
+      APD_TRY(c.pts.ensure(n * 16));
+      APD_TRY(c.perm.ensure(n * 4));
+      APD_TRY(c.cbox.ensure(nch * sizeof(Box)));
+      APD_TRY(c.gbox.ensure(ngr * sizeof(Box)));
+      if (c.n <= SORT_LDS_MAX_N) {
+        SortJob j;
+        j.pts = c.opts.as<float4>(), j.spts = c.pts.as<float4>(), j.perm = c.perm.as<int>();
+        j.cbox = c.cbox.as<Box>(), j.gbox = c.gbox.as<Box>(), j.n = c.n, j.pad_ = 0;
+        small.push_back(j);
+        int np2 = 1;
+        while (np2 < c.n) np2 <<= 1;
+        np2max = std::max(np2max, np2);
+      } else {
+        large.push_back((int)i);
+      }
+      c.sorted = true;
+      desc_dirty = true;
+    }
+    if (!small.empty()) {
+      APD_HIP(hipStreamSynchronize(stream));  // d_jobs reuse
+      APD_TRY(d_jobs.ensure(small.size() * sizeof(SortJob)));
+      APD_HIP(hipMemcpyAsync(d_jobs.p, small.data(), small.size() * sizeof(SortJob), hipMemcpyHostToDevice, stream));
+      static bool attr_set = false;
+      if (!attr_set) {
+        APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_jobs.as<SortJob>());
+      APD_HIP(hipGetLastError());
+      APD_HIP(hipStreamSynchronize(stream));  // `small` is a local
+    }
+    for (int id : large) {  // generic path: keys in global memory, one launch per bitonic stage
+      Cloud& c = clouds[id];
+      const int n = c.n;
+      int np2 = 1;
+      while (np2 < n) np2 <<= 1;
+      APD_HIP(hipStreamSynchronize(stream));
+      APD_TRY(d_keys.ensure((size_t)np2 * 8));
+      APD_TRY(d_box6.ensure(6 * sizeof(int)));
+      const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff};  // +inf x3, -inf x3 (ordered-int)
+      APD_HIP(hipMemcpyAsync(d_box6.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+      APD_HIP(hipStreamSynchronize(stream));
+      hipLaunchKernelGGL(k_bbox_atomic, dim3((n + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, d_box6.as<int>());
+      hipLaunchKernelGGL(k_morton_keys, dim3((np2 + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, np2, d_box6.as<int>(),
+                         d_keys.as<unsigned long long>());
+      for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1)
+          hipLaunchKernelGGL(k_bitonic_global, dim3((np2 / 2 + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), np2, k, j);
+      hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), c.opts.as<float4>(), n,
+                         c.pts.as<float4>(), c.perm.as<int>());
+      const int nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
+      hipLaunchKernelGGL(k_boxes, dim3((nch + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, 16, c.cbox.as<Box>(), nch);
+      hipLaunchKernelGGL(k_boxes, dim3((ngr + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, kGroupPts, c.gbox.as<Box>(), ngr);
+      APD_HIP(hipGetLastError());
+    }
+    return 0;
+  }
+
   int upload_desc() {
+    APD_TRY(sort_clouds());
     if (!desc_dirty) return 0;
     std::vector<CloudDesc> h(clouds.size());
     for (size_t i = 0; i < clouds.size(); i++) {
       if (clouds[i].n > 0) APD_TRY(clouds[i].cov.ensure((size_t)clouds[i].n * 6 * sizeof(double)));
       h[i].pts = clouds[i].pts.as<float4>();
+      h[i].opts = clouds[i].opts.as<float4>();
+      h[i].perm = clouds[i].perm.as<int>();
+      h[i].cbox = clouds[i].cbox.as<Box>();
+      h[i].gbox = clouds[i].gbox.as<Box>();
       h[i].cov = clouds[i].cov.as<double>();
       h[i].n = clouds[i].n;
       h[i].pad_ = 0;
@@ -262,14 +355,30 @@ class Engine {
     APD_HIP(hipStreamSynchronize(stream));
     APD_TRY(d_ids.ensure(ids.size() * sizeof(int)));
     APD_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    static bool attr_set = false;
-    if (!attr_set) {
-      APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
-      attr_set = true;
+    if (knn_pruned) {
+      std::vector<long long> off(ids.size());
+      long long total = 0;
+      for (size_t q = 0; q < ids.size(); q++) {
+        off[q] = total;
+        total += (long long)((clouds[ids[q]].n + 63) & ~63) * KP_CAP;
+      }
+      APD_TRY(d_listoff.ensure(ids.size() * sizeof(long long)));
+      APD_TRY(d_glist.ensure((size_t)total * 8));
+      APD_HIP(hipMemcpyAsync(d_listoff.p, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+      APD_HIP(hipStreamSynchronize(stream));  // `off` is a local
+      const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)ids.size());
+      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), d_listoff.as<long long>(),
+                         d_glist.as<unsigned long long>(), params.k_correspondences, params.regularization, d_errflag.as<int>());
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
+        attr_set = true;
+      }
+      const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)ids.size());
+      hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
+                         params.regularization, d_errflag.as<int>());
     }
-    const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)ids.size());
-    hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
-                       params.regularization, d_errflag.as<int>());
     APD_HIP(hipGetLastError());
     APD_TRY(check_errflag("k_knn_cov"));
     for (int id : ids) clouds[id].cov_valid = true;
@@ -310,12 +419,17 @@ class Engine {
     const int nchunks_min = 1;
     (void)nchunks_min;
     int S = env_int("APDGICP_NN_S", 0);
-    if (S != 2 && S != 4 && S != 8) S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
+    int T = 1;
+    if (nn_pruned) {
+      if (S != 2 && S != 4) S = 2;
+    } else {
+      if (S != 2 && S != 4 && S != 8) S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
+      const int src_blocks = (nmax_src + NN_BLK * S - 1) / (NN_BLK * S);
+      T = env_int("APDGICP_NN_T", 0);
+      if (T <= 0) T = (512 + npairs * src_blocks - 1) / (npairs * src_blocks);
+      T = std::max(1, std::min(T, 64));
+    }
     nn_S = S;
-    const int src_blocks = (nmax_src + NN_BLK * S - 1) / (NN_BLK * S);
-    int T = env_int("APDGICP_NN_T", 0);
-    if (T <= 0) T = (512 + npairs * src_blocks - 1) / (npairs * src_blocks);
-    T = std::max(1, std::min(T, 64));
     work.T = T;
     work.nstride = (nmax_src + 255) & ~255;
     work.nblk_max = (nmax_src + LIN_BLK - 1) / LIN_BLK;
@@ -336,8 +450,8 @@ class Engine {
   }
 
   int launch_nn() {
-    const int src_blocks = (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
-    const dim3 grid((unsigned)src_blocks, (unsigned)work.T, (unsigned)npairs);
+    const int src_blocks = nn_pruned ? (nmax_src + 64 * nn_S - 1) / (64 * nn_S) : (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
+    const dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)npairs : (unsigned)work.T, nn_pruned ? 1u : (unsigned)npairs);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_nn) {
       if (nn_events_used == nn_events.size()) {
@@ -353,7 +467,10 @@ class Engine {
     const CloudDesc* cd = d_desc.as<CloudDesc>();
     const PairDesc* pd = d_pairs.as<PairDesc>();
     const PairState* st = d_state.as<PairState>();
-    if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
+    if (nn_pruned) {
+      if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, stream, cd, pd, st, work);
+      else hipLaunchKernelGGL(k_nn_pruned<4>, grid, dim3(64), 0, stream, cd, pd, st, work);
+    } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
     else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
     else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
     if (profile_nn) APD_HIP(hipEventRecord(e1, stream));

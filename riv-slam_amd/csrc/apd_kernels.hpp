@@ -20,14 +20,21 @@
 #include <stdint.h>
 
 #include "apd_math.hpp"
+#include "apd_sort.hpp"
 
 namespace apd {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// All per-point device arrays of a cloud are kept in Z-curve (Morton) order, see apd_sort.hpp;
+// `perm` maps a sorted position back to the caller's index and is applied by the getters.
 struct CloudDesc {
-  const float4* pts;   // n x {x,y,z,1}
-  double* cov;         // SoA [6][n]: xx,xy,xz,yy,yz,zz (top-left 3x3 of the reference's Matrix4d)
+  const float4* pts;   // n x {x,y,z,1}, SORTED order
+  const float4* opts;  // same points in the caller's original order
+  const int* perm;     // sorted position -> original index
+  const Box* cbox;     // ceil(n/16) chunk boxes
+  const Box* gbox;     // ceil(n/128) group boxes
+  double* cov;         // SoA [6][n] (sorted order): xx,xy,xz,yy,yz,zz (top-left 3x3 of the reference's Matrix4d)
   int n;
   int pad_;
 };
@@ -62,6 +69,7 @@ struct ResultRec {
 constexpr int kRed = 32;        // doubles per block partial: 21 H + 6 b + cost + matched + pad
 constexpr int kChunk = 16;      // NN index granularity: the winner is located inside a 16-target chunk
 constexpr unsigned kNoChunk = 0xFFFFFFFFu;
+constexpr unsigned kTieBit = 0x80000000u;  // set in a chunk id when the minimum was reached in more than one chunk
 
 struct Work {
   unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
@@ -97,22 +105,33 @@ __global__ void k_pack_points(const char* raw, long long stride_bytes, int n, fl
   out[i] = make_float4(p[0], p[1], p[2], 1.0f);
 }
 
-__global__ void k_unpack_cov(const double* cov6, int n, double* out16) {  // -> n x Matrix4d (column-major)
+// sorted SoA covariances -> n x Matrix4d (column-major) in the caller's point order
+__global__ void k_unpack_cov(const double* cov6, const int* perm, int n, double* out16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double xx = cov6[i], xy = cov6[n + i], xz = cov6[2 * n + i], yy = cov6[3 * n + i], yz = cov6[4 * n + i], zz = cov6[5 * n + i];
-  double* o = out16 + 16ll * i;
+  double* o = out16 + 16ll * perm[i];
   o[0] = xx, o[1] = xy, o[2] = xz, o[3] = 0;
   o[4] = xy, o[5] = yy, o[6] = yz, o[7] = 0;
   o[8] = xz, o[9] = yz, o[10] = zz, o[11] = 0;
   o[12] = 0, o[13] = 0, o[14] = 0, o[15] = 0;
 }
 
-__global__ void k_pack_cov(const double* in16, int n, double* cov6) {
+__global__ void k_pack_cov(const double* in16, const int* perm, int n, double* cov6) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double* o = in16 + 16ll * i;
+  const double* o = in16 + 16ll * perm[i];
   cov6[i] = o[0], cov6[n + i] = o[4], cov6[2 * n + i] = o[8], cov6[3 * n + i] = o[5], cov6[4 * n + i] = o[9], cov6[5 * n + i] = o[10];
+}
+
+// correspondences_ / sq_distances_ from the internal (sorted source, sorted target index) form to the
+// caller's indexing
+__global__ void k_export_corr(const int* corr, const float* sqd, const int* perm_src, const int* perm_tgt, int n, int* out_corr, float* out_sqd) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int o = perm_src[s], j = corr[s];
+  if (out_corr) out_corr[o] = j >= 0 ? perm_tgt[j] : -1;
+  if (out_sqd) out_sqd[o] = sqd[s];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -207,12 +226,15 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
           const float4 t = tile[jj];
           const float d = sqdist1(t.x, t.y, t.z, q.x, q.y, q.z);
           const int j = t0 + jj;
-          if (d < tau_d || (d == tau_d && j <= tau_i)) {
-            if (cnt < KNN_CAP) {
-              lst_i[cnt * KNN_BLK + tid] = j;
-              lst_d[cnt * KNN_BLK + tid] = d;
+          if (d <= tau_d) {
+            const int o = c.perm[j];  // ties are ordered by the caller's ORIGINAL index, like the oracle
+            if (d < tau_d || o <= tau_i) {
+              if (cnt < KNN_CAP) {
+                lst_i[cnt * KNN_BLK + tid] = o;
+                lst_d[cnt * KNN_BLK + tid] = d;
+              }
+              cnt++;
             }
-            cnt++;
           }
         }
       }
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
         atomicExch(err_flag, 2);
         break;
       }
-      const float4 p = c.pts[bi];
+      const float4 p = c.opts[bi];
       const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
       s1x += x, s1y += y, s1z += z;
       sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
   }
   const float inf = __builtin_inff();
   float best[S];
-  unsigned bestc[S];
+  unsigned bestc[S];  // winning chunk | kTieBit when a second chunk reached exactly the same minimum
 #pragma unroll
   for (int s = 0; s < S; s++) best[s] = inf, bestc[s] = kNoChunk;
 
@@ -367,6 +389,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
 #pragma unroll
       for (int s = 0; s < S; s++) {
         if (m[s] < best[s]) best[s] = m[s], bestc[s] = (unsigned)(tc0 + ch);
+        else if (m[s] == best[s] && m[s] < inf) bestc[s] |= kTieBit;
       }
     }
   }
@@ -376,6 +399,360 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
     const int i = base + s * NN_BLK + tid;
     if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// fp32 lower bounds used for pruning.  They are evaluated with the same operation order as the
+// distance itself; rounding is monotone, so for EVERY target t inside the box
+//   lb(p, box) <= sqdist1(t, p)   holds for the computed fp32 values, not just the real numbers.
+// A chunk is skipped only when lb > best (strict), so ties survive and the result is unchanged.
+__device__ __forceinline__ float lb_point_box(const Box& b, float px, float py, float pz) {
+  const float gx = fmaxf(fmaxf(b.lx - px, px - b.hx), 0.f);
+  const float gy = fmaxf(fmaxf(b.ly - py, py - b.hy), 0.f);
+  const float gz = fmaxf(fmaxf(b.lz - pz, pz - b.hz), 0.f);
+  float r = gx * gx;
+  r = r + gy * gy;
+  r = r + gz * gz;
+  return r;
+}
+__device__ __forceinline__ float lb_box_box(const Box& a, const Box& b) {
+  const float gx = fmaxf(fmaxf(b.lx - a.hx, a.lx - b.hx), 0.f);
+  const float gy = fmaxf(fmaxf(b.ly - a.hy, a.ly - b.hy), 0.f);
+  const float gz = fmaxf(fmaxf(b.lz - a.hz, a.lz - b.hz), 0.f);
+  float r = gx * gx;
+  r = r + gy * gy;
+  r = r + gz * gz;
+  return r;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// one wave stages one 128-target group into its LDS tile: lane l loads targets 2l, 2l+1, and lanes
+// 0..47 the group's 8 chunk boxes (48 consecutive floats)
+__device__ __forceinline__ void stage_group(float4* txy, float2* tz, float* cbl, const float4* pts, const Box* cbox, int g, int M, int nchunks,
+                                            int lane) {
+  const float inf = __builtin_inff();
+  const int j = g * kGroupPts + 2 * lane;
+  const float4 a = j < M ? pts[j] : make_float4(inf, inf, inf, 0.f);
+  const float4 b = j + 1 < M ? pts[j + 1] : make_float4(inf, inf, inf, 0.f);
+  txy[lane] = make_float4(a.x, b.x, a.y, b.y);
+  tz[lane] = make_float2(a.z, b.z);
+  if (lane < 6 * kGroupChunks) {
+    const int c = g * kGroupChunks + lane / 6;
+    cbl[lane] = c < nchunks ? ((const float*)cbox)[(size_t)g * kGroupChunks * 6 + lane] : inf;
+  }
+}
+__device__ __forceinline__ Box lds_box(const float* cbl, int ch) {
+  return Box{cbl[6 * ch], cbl[6 * ch + 1], cbl[6 * ch + 2], cbl[6 * ch + 3], cbl[6 * ch + 4], cbl[6 * ch + 5]};
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_nn_pruned: the same exact 1-NN as k_nn_partial, on Z-curve-sorted clouds.  One wave (= one block)
+// owns 64*S consecutive sorted source points, i.e. a spatially compact set.  Target groups (128 pts)
+// are tested lane-parallel against the wave's bounding box; surviving groups are staged into the
+// wave's LDS tile and their 16-point chunks are tested per lane against the running best before the
+// 16x(S) distance block is evaluated.  Pass 0 visits the groups that overlap the wave box (they seed
+// `best`), pass 1 the remaining ones that can still beat the largest `best` in the wave.
+template <int S>
+__global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  static_assert(S % 2 == 0, "S must be even");
+  __shared__ float4 txy[kGroupPts / 2];
+  __shared__ float2 tz[kGroupPts / 2];
+  __shared__ float cbl[6 * kGroupChunks];
+  const int pair = blockIdx.y;
+  if (st[pair].status != ST_NEED_LIN) return;
+  const PairDesc pd = pairs[pair];
+  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const int N = src.n, M = tgt.n, lane = threadIdx.x;
+  const int base = blockIdx.x * (64 * S);
+  if (base >= N) return;
+  float Tf[12];
+  load_Tf(st[pair].x0, Tf);
+  const float inf = __builtin_inff();
+
+  float2v px[S / 2], py[S / 2], pz[S / 2];
+  Box wb{inf, inf, inf, -inf, -inf, -inf};
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const int i = base + s * 64 + lane;
+    const float4 p = src.pts[i < N ? i : N - 1];
+    const float x = xf_row(Tf + 0, p.x, p.y, p.z), y = xf_row(Tf + 4, p.x, p.y, p.z), z = xf_row(Tf + 8, p.x, p.y, p.z);
+    if (s & 1) px[s / 2].y = x, py[s / 2].y = y, pz[s / 2].y = z;
+    else px[s / 2].x = x, py[s / 2].x = y, pz[s / 2].x = z;
+    wb.lx = fminf(wb.lx, x), wb.ly = fminf(wb.ly, y), wb.lz = fminf(wb.lz, z);
+    wb.hx = fmaxf(wb.hx, x), wb.hy = fmaxf(wb.hy, y), wb.hz = fmaxf(wb.hz, z);
+  }
+  wb.lx = wave_min(wb.lx), wb.ly = wave_min(wb.ly), wb.lz = wave_min(wb.lz);
+  wb.hx = wave_max(wb.hx), wb.hy = wave_max(wb.hy), wb.hz = wave_max(wb.hz);
+
+  float best[S];
+  unsigned bestc[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) best[s] = inf, bestc[s] = kNoChunk;
+  float maxbest = inf;
+
+  const int ngroups = (M + kGroupPts - 1) / kGroupPts;
+  const int nchunks = (M + kChunk - 1) / kChunk;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+      const int gl = g0 + lane;
+      const float lbg = gl < ngroups ? lb_box_box(wb, tgt.gbox[gl]) : inf;
+      unsigned long long mask = __ballot(pass == 0 ? (lbg == 0.f) : (lbg > 0.f && lbg <= maxbest));
+      while (mask) {
+        const int gi = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (pass == 1 && __shfl(lbg, gi, 64) > maxbest) continue;  // maxbest may have shrunk meanwhile
+        const int g = g0 + gi;
+        __syncthreads();  // single-wave block: orders the LDS tile reuse
+        stage_group(txy, tz, cbl, tgt.pts, tgt.cbox, g, M, nchunks, lane);
+        __syncthreads();
+        const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
+        for (int ch = 0; ch < cend; ch++) {
+          const int c = g * kGroupChunks + ch;
+          const Box cb = lds_box(cbl, ch);
+          bool need = false;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const float x = (s & 1) ? px[s / 2].y : px[s / 2].x, y = (s & 1) ? py[s / 2].y : py[s / 2].x, z = (s & 1) ? pz[s / 2].y : pz[s / 2].x;
+            need |= lb_point_box(cb, x, y, z) <= best[s];
+          }
+          if (!__any(need)) continue;
+          float m[S];
+#pragma unroll
+          for (int s = 0; s < S; s++) m[s] = inf;
+#pragma unroll
+          for (int jj = 0; jj < kChunk / 2; jj++) {
+            const float4 A = txy[ch * (kChunk / 2) + jj];
+            const float2 Z = tz[ch * (kChunk / 2) + jj];
+#pragma unroll
+            for (int sp = 0; sp < S / 2; sp++) {
+              float2v dx = A.x - px[sp], dy = A.z - py[sp], dz = Z.x - pz[sp];
+              float2v d0 = dx * dx;
+              d0 = d0 + dy * dy;
+              d0 = d0 + dz * dz;
+              dx = A.y - px[sp], dy = A.w - py[sp], dz = Z.y - pz[sp];
+              float2v d1 = dx * dx;
+              d1 = d1 + dy * dy;
+              d1 = d1 + dz * dz;
+              m[2 * sp] = fminf(fminf(m[2 * sp], d0.x), d1.x);
+              m[2 * sp + 1] = fminf(fminf(m[2 * sp + 1], d0.y), d1.y);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            if (m[s] < best[s]) best[s] = m[s], bestc[s] = (unsigned)c;
+            else if (m[s] == best[s] && m[s] < inf && (bestc[s] & ~kTieBit) != (unsigned)c) bestc[s] |= kTieBit;
+          }
+        }
+        float mb = best[0];
+#pragma unroll
+        for (int s = 1; s < S; s++) mb = fmaxf(mb, best[s]);
+        maxbest = wave_max(mb);
+      }
+    }
+  }
+  unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const int i = base + s * 64 + lane;
+    if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_knn_cov_pruned: calculate_covariances (A:303-363) on Z-curve-sorted clouds; exact k-NN with
+// bounding-box pruning.  One wave owns 64 consecutive sorted queries.
+//   phase 1  tau = k-th smallest of 32 strided class minima over the ~320 sorted neighbours around the
+//            wave (>= k distinct points lie inside, so tau bounds the k-th neighbour distance)
+//   phase 2  groups / chunks whose lower bound exceeds tau are skipped; every candidate with
+//            (d, original index) <= tau is appended to the query's list in global memory (slot-major,
+//            coalesced; a list is ~1.5-3 k entries, so it stays in L2); on overflow tau is tightened
+//            to the k-th smallest stored key and the sweep repeats for that wave
+//   phase 3  k rounds of min-extraction over the 64-bit keys (distance bits << 32 | original index:
+//            lexicographic order == the reference's (distance, index) order), sums in fp64
+constexpr int KP_CAP = 64, KP_WIN = 320;
+
+__global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, const long long* list_off,
+                                                       unsigned long long* glist, int k, int reg, int* err_flag) {
+  __shared__ float4 txy[KP_WIN / 2];
+  __shared__ float2 tz[KP_WIN / 2];
+  __shared__ float cbl[6 * kGroupChunks];
+  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  const int n = c.n, lane = threadIdx.x;
+  const int base = blockIdx.x * 64;
+  if (base >= n) return;
+  const int i = base + lane;
+  const bool valid = i < n;
+  const float4 q = c.pts[valid ? i : n - 1];
+  const float inf = __builtin_inff();
+  const int npad = (n + 63) & ~63;
+  unsigned long long* mylist = glist + list_off[blockIdx.y] + i;  // + slot * npad
+
+  // ---- phase 1: bound from the sorted neighbourhood
+  int w0 = max(0, base - (KP_WIN - 64) / 2) & ~1;
+  if (w0 + KP_WIN > n) w0 = max(0, n - KP_WIN) & ~1;
+  for (int e = lane; e < KP_WIN / 2; e += 64) {
+    const int j = w0 + 2 * e;
+    const float4 a = j < n ? c.pts[j] : make_float4(inf, inf, inf, 0.f);
+    const float4 b = j + 1 < n ? c.pts[j + 1] : make_float4(inf, inf, inf, 0.f);
+    txy[e] = make_float4(a.x, b.x, a.y, b.y);
+    tz[e] = make_float2(a.z, b.z);
+  }
+  __syncthreads();
+  float cm[KNN_NC];
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
+  for (int e0 = 0; e0 < KP_WIN / 2; e0 += KNN_NC) {
+#pragma unroll
+    for (int s = 0; s < KNN_NC; s++) {
+      const float4 A = txy[e0 + s];
+      const float2 Z = tz[e0 + s];
+      const float d0 = sqdist1(A.x, A.z, Z.x, q.x, q.y, q.z), d1 = sqdist1(A.y, A.w, Z.y, q.x, q.y, q.z);
+      cm[s] = fminf(fminf(cm[s], d0), d1);
+    }
+  }
+#pragma unroll
+  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int a = 0; a < KNN_NC; a++) {
+        const int l = a ^ j;
+        if (l > a) {
+          const bool up = (a & kk) == 0;
+          const float x = cm[a], y = cm[l];
+          const float lo = fminf(x, y), hi = fmaxf(x, y);
+          cm[a] = up ? lo : hi;
+          cm[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+  float tau_d = inf;
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++)
+    if (s == k - 1) tau_d = cm[s];
+  unsigned long long tau_key = ((unsigned long long)__float_as_uint(tau_d) << 32) | 0xFFFFFFFFull;
+
+  Box wb;
+  wb.lx = wave_min(q.x), wb.ly = wave_min(q.y), wb.lz = wave_min(q.z);
+  wb.hx = wave_max(q.x), wb.hy = wave_max(q.y), wb.hz = wave_max(q.z);
+
+  // ---- phase 2
+  const int ngroups = (n + kGroupPts - 1) / kGroupPts;
+  const int nchunks = (n + kChunk - 1) / kChunk;
+  bool active = valid;
+  int cnt_final = 0;
+  for (int round = 0;; round++) {
+    int cnt = 0;
+    const float my_tau = active ? __uint_as_float((unsigned)(tau_key >> 32)) : -1.f;
+    const float maxtau = wave_max(my_tau);
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+      const int gl = g0 + lane;
+      const float lbg = gl < ngroups ? lb_box_box(wb, c.gbox[gl]) : inf;
+      unsigned long long mask = __ballot(lbg <= maxtau);
+      while (mask) {
+        const int gi = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int g = g0 + gi;
+        __syncthreads();
+        stage_group(txy, tz, cbl, c.pts, c.cbox, g, n, nchunks, lane);
+        __syncthreads();
+        const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
+        for (int ch = 0; ch < cend; ch++) {
+          const int cc = g * kGroupChunks + ch;
+          const bool need = active && lb_point_box(lds_box(cbl, ch), q.x, q.y, q.z) <= my_tau;
+          if (!__any(need)) continue;
+#pragma unroll
+          for (int jj = 0; jj < kChunk / 2; jj++) {
+            const float4 A = txy[ch * (kChunk / 2) + jj];
+            const float2 Z = tz[ch * (kChunk / 2) + jj];
+            const float d0 = sqdist1(A.x, A.z, Z.x, q.x, q.y, q.z), d1 = sqdist1(A.y, A.w, Z.y, q.x, q.y, q.z);
+            const int j0 = cc * kChunk + 2 * jj;
+            if (need && d0 <= my_tau) {
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)c.perm[j0];
+              if (key <= tau_key) {
+                if (cnt < KP_CAP) mylist[(size_t)cnt * npad] = key;
+                cnt++;
+              }
+            }
+            if (need && d1 <= my_tau) {  // pad targets are +inf and never pass
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)c.perm[j0 + 1];
+              if (key <= tau_key) {
+                if (cnt < KP_CAP) mylist[(size_t)cnt * npad] = key;
+                cnt++;
+              }
+            }
+          }
+        }
+      }
+    }
+    bool ovf = false;
+    if (active) {
+      ovf = cnt > KP_CAP;
+      cnt_final = min(cnt, KP_CAP);
+      if (ovf) {  // tighten: k-th smallest stored key
+        unsigned long long last = 0;
+        bool first = true;
+        for (int r = 0; r < k; r++) {
+          unsigned long long bk = ~0ull;
+          for (int a = 0; a < KP_CAP; a++) {
+            const unsigned long long key = mylist[(size_t)a * npad];
+            if ((first || key > last) && key < bk) bk = key;
+          }
+          last = bk, first = false;
+        }
+        tau_key = last;
+      }
+    }
+    active = ovf;
+    if (!__any(ovf)) break;
+    if (round >= 40) {
+      if (lane == 0) atomicExch(err_flag, 1);
+      break;
+    }
+  }
+  if (!valid) return;
+
+  // ---- phase 3
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  {
+    unsigned long long last = 0;
+    bool first = true;
+    for (int r = 0; r < k; r++) {
+      unsigned long long bk = ~0ull;
+      for (int a = 0; a < cnt_final; a++) {
+        const unsigned long long key = mylist[(size_t)a * npad];
+        if ((first || key > last) && key < bk) bk = key;
+      }
+      if (bk == ~0ull) {
+        atomicExch(err_flag, 2);
+        break;
+      }
+      last = bk, first = false;
+      const float4 p = c.opts[(unsigned)bk];
+      const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
+      s1x += x, s1y += y, s1z += z;
+      sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+    }
+  }
+  const double ik = 1.0 / (double)k;
+  const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
+  Sym3 pc;
+  pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
+  pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
+  Sym3 out;
+  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+  double* cov = c.cov;
+  cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -423,30 +800,54 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
 
   if (i < N) {
     unsigned long long bestp = ~0ull;
+    bool tie = false;
     const unsigned long long* part = w.nnpart + (size_t)pair * w.T * w.nstride + i;
     for (int sp = 0; sp < w.T; sp++) {
       const unsigned long long v = part[(size_t)sp * w.nstride];
-      bestp = v < bestp ? v : bestp;
+      if ((unsigned)(v >> 32) == (unsigned)(bestp >> 32) && (unsigned)v != kNoChunk) tie = true;  // same minimum in two splits
+      if (v < bestp) {
+        if ((unsigned)(v >> 32) != (unsigned)(bestp >> 32)) tie = false;
+        bestp = v;
+      }
     }
     const float m = __uint_as_float((unsigned)(bestp >> 32));
-    const unsigned chunk = (unsigned)bestp;
+    unsigned chunk = (unsigned)bestp;
+    if (chunk != kNoChunk) {
+      tie |= (chunk & kTieBit) != 0;
+      chunk &= ~kTieBit;
+    }
     float Tf[12];
     load_Tf(T, Tf);
     const float4 p = src.pts[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
     int j = -1;
     if (chunk != kNoChunk) {
-      float4 t[kChunk];
+      // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
+      int jorig = 0x7fffffff;
+      if (!tie) {
+        float4 t[kChunk];
 #pragma unroll
-      for (int jj = 0; jj < kChunk; jj++) {
-        const int g = (int)chunk * kChunk + jj;
-        t[jj] = tgt.pts[g < M ? g : M - 1];
-      }
+        for (int jj = 0; jj < kChunk; jj++) {
+          const int g = (int)chunk * kChunk + jj;
+          t[jj] = tgt.pts[g < M ? g : M - 1];
+        }
 #pragma unroll
-      for (int jj = kChunk - 1; jj >= 0; jj--) {
-        const int g = (int)chunk * kChunk + jj;
-        const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
-        if (g < M && d == m) j = g;  // descending scan: the lowest index wins ties
+        for (int jj = 0; jj < kChunk; jj++) {
+          const int g = (int)chunk * kChunk + jj;
+          const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
+          if (g < M && d == m) {
+            const int o = tgt.perm[g];
+            if (o < jorig) jorig = o, j = g;
+          }
+        }
+      } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
+        for (int g = 0; g < M; g++) {
+          const float4 t = tgt.pts[g];
+          if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
+            const int o = tgt.perm[g];
+            if (o < jorig) jorig = o, j = g;
+          }
+        }
       }
     }
     w.sqd[(size_t)pair * w.nstride + i] = m;
@@ -782,7 +1183,7 @@ __global__ void k_copy_status(const PairState* st, int* status_out, int npairs) 
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}
-__global__ void k_transform_points(const float4* pts, int n, const float* T16 /* column-major, device */, float* out, long long out_stride_floats) {
+__global__ void k_transform_points(const float4* pts /* original order */, int n, const float* T16 /* column-major, device */, float* out, long long out_stride_floats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];

@@ -1,0 +1,226 @@
+// Spatial pre-ordering of a cloud (done once per set_cloud): Morton (Z-order) sort + per-chunk and
+// per-group axis-aligned bounding boxes.  Nothing here changes any result: the nearest-neighbour and
+// k-NN kernels use the boxes only to SKIP chunks whose fp32 lower bound proves they cannot contain a
+// (better) neighbour, and ties are still resolved by the ORIGINAL index (perm).
+//
+//   spts[s]  = pts[perm[s]]                     sorted copy, s = position on the Z-curve
+//   cbox[c]  = {lo.xyz, hi.xyz} of sorted points [16c, 16c+16)          (kChunk = 16)
+//   gbox[g]  = box of chunks [8g, 8g+8)  = 128 sorted points            (kGroup = 8 chunks)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace apd {
+
+constexpr int kGroupChunks = 8;            // chunks per group
+constexpr int kGroupPts = 16 * kGroupChunks;  // 128 points per group
+constexpr int SORT_BLK = 1024;
+constexpr int SORT_LDS_MAX_N = 16384;      // single-block LDS sort up to this many points (128 KB of u64 keys)
+
+struct Box {
+  float lx, ly, lz, hx, hy, hz;
+};
+
+__device__ __forceinline__ unsigned expand10(unsigned v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__device__ __forceinline__ unsigned morton30(float x, float y, float z, float lx, float ly, float lz, float scale) {
+  const float fx = fminf(fmaxf((x - lx) * scale, 0.f), 1023.f);
+  const float fy = fminf(fmaxf((y - ly) * scale, 0.f), 1023.f);
+  const float fz = fminf(fmaxf((z - lz) * scale, 0.f), 1023.f);
+  return (expand10((unsigned)fx) << 2) | (expand10((unsigned)fy) << 1) | expand10((unsigned)fz);
+}
+
+__device__ __forceinline__ float block_reduce_minmax(float v, bool is_max, float* lds, int tid, int nthreads) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(v, off, 64);
+    v = is_max ? fmaxf(v, o) : fminf(v, o);
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) lds[tid >> 6] = v;
+  __syncthreads();
+  float r = lds[0];
+  for (int w = 1; w < nthreads / 64; w++) r = is_max ? fmaxf(r, lds[w]) : fminf(r, lds[w]);
+  return r;
+}
+
+struct SortJob {
+  const float4* pts;  // original order
+  float4* spts;       // out: sorted
+  int* perm;          // out: sorted position -> original index
+  Box* cbox;          // out: ceil(n/16) chunk boxes
+  Box* gbox;          // out: ceil(n/128) group boxes
+  int n;
+  int pad_;
+};
+
+// One block per cloud, everything in LDS (n <= SORT_LDS_MAX_N).
+__global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_lds(const SortJob* jobs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ float red[SORT_BLK / 64];
+  const SortJob job = jobs[blockIdx.x];
+  const int n = job.n, tid = threadIdx.x;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  // bounding box
+  const float inf = __builtin_inff();
+  float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
+  for (int i = tid; i < n; i += SORT_BLK) {
+    const float4 p = job.pts[i];
+    lx = fminf(lx, p.x), ly = fminf(ly, p.y), lz = fminf(lz, p.z);
+    hx = fmaxf(hx, p.x), hy = fmaxf(hy, p.y), hz = fmaxf(hz, p.z);
+  }
+  lx = block_reduce_minmax(lx, false, red, tid, SORT_BLK);
+  ly = block_reduce_minmax(ly, false, red, tid, SORT_BLK);
+  lz = block_reduce_minmax(lz, false, red, tid, SORT_BLK);
+  hx = block_reduce_minmax(hx, true, red, tid, SORT_BLK);
+  hy = block_reduce_minmax(hy, true, red, tid, SORT_BLK);
+  hz = block_reduce_minmax(hz, true, red, tid, SORT_BLK);
+  const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  const float scale = 1023.f / ext;
+  for (int i = tid; i < np2; i += SORT_BLK) {
+    if (i < n) {
+      const float4 p = job.pts[i];
+      keys[i] = ((unsigned long long)morton30(p.x, p.y, p.z, lx, ly, lz, scale) << 32) | (unsigned)i;
+    } else {
+      keys[i] = ~0ull;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < np2 / 2; t += SORT_BLK) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j cleared
+        const int l = i | j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = keys[i], b = keys[l];
+        if ((a > b) == up) keys[i] = b, keys[l] = a;
+      }
+      __syncthreads();
+    }
+  }
+  for (int s = tid; s < n; s += SORT_BLK) {
+    const int o = (int)(unsigned)keys[s];
+    job.perm[s] = o;
+    job.spts[s] = job.pts[o];
+  }
+  __syncthreads();
+  // chunk boxes from the sorted copy just written by this block (same block -> visible after the barrier
+  // only through L1/L2 of this CU: we re-read our own writes, which is coherent within a workgroup)
+  __threadfence_block();
+  const int nchunks = (n + 15) / 16;
+  for (int c = tid; c < nchunks; c += SORT_BLK) {
+    Box b{inf, inf, inf, -inf, -inf, -inf};
+    for (int e = 0; e < 16; e++) {
+      const int s = c * 16 + e;
+      if (s < n) {
+        const int o = (int)(unsigned)keys[s];
+        const float4 p = job.pts[o];
+        b.lx = fminf(b.lx, p.x), b.ly = fminf(b.ly, p.y), b.lz = fminf(b.lz, p.z);
+        b.hx = fmaxf(b.hx, p.x), b.hy = fmaxf(b.hy, p.y), b.hz = fmaxf(b.hz, p.z);
+      }
+    }
+    job.cbox[c] = b;
+  }
+  const int ngroups = (n + kGroupPts - 1) / kGroupPts;
+  for (int g = tid; g < ngroups; g += SORT_BLK) {
+    Box b{inf, inf, inf, -inf, -inf, -inf};
+    for (int e = 0; e < kGroupPts; e++) {
+      const int s = g * kGroupPts + e;
+      if (s < n) {
+        const int o = (int)(unsigned)keys[s];
+        const float4 p = job.pts[o];
+        b.lx = fminf(b.lx, p.x), b.ly = fminf(b.ly, p.y), b.lz = fminf(b.lz, p.z);
+        b.hx = fmaxf(b.hx, p.x), b.hy = fmaxf(b.hy, p.y), b.hz = fmaxf(b.hz, p.z);
+      }
+    }
+    job.gbox[g] = b;
+  }
+}
+
+// ---- generic path for large clouds (n > SORT_LDS_MAX_N): keys in global memory
+__global__ void k_bbox_atomic(const float4* pts, int n, int* box6 /* ordered-int encoded, init lo=+inf hi=-inf */) {
+  __shared__ float red[256 / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
+  const float inf = __builtin_inff();
+  float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+  if (i < n) {
+    const float4 p = pts[i];
+    v[0] = v[3] = p.x, v[1] = v[4] = p.y, v[2] = v[5] = p.z;
+  }
+  for (int q = 0; q < 6; q++) {
+    const float r = block_reduce_minmax(v[q], q >= 3, red, tid, 256);
+    if (tid == 0) {
+      // monotone float -> int mapping so that integer atomics order like floats
+      int b = __float_as_int(r);
+      b = b >= 0 ? b : b ^ 0x7fffffff;
+      if (q < 3) atomicMin(box6 + q, b);
+      else atomicMax(box6 + q, b);
+    }
+  }
+}
+__device__ __forceinline__ float ordered_int_to_float(int b) { return __int_as_float(b >= 0 ? b : b ^ 0x7fffffff); }
+
+__global__ void k_morton_keys(const float4* pts, int n, int np2, const int* box6, unsigned long long* keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np2) return;
+  if (i >= n) {
+    keys[i] = ~0ull;
+    return;
+  }
+  const float lx = ordered_int_to_float(box6[0]), ly = ordered_int_to_float(box6[1]), lz = ordered_int_to_float(box6[2]);
+  const float hx = ordered_int_to_float(box6[3]), hy = ordered_int_to_float(box6[4]), hz = ordered_int_to_float(box6[5]);
+  const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  const float4 p = pts[i];
+  keys[i] = ((unsigned long long)morton30(p.x, p.y, p.z, lx, ly, lz, 1023.f / ext) << 32) | (unsigned)i;
+}
+
+__global__ void k_bitonic_global(unsigned long long* keys, int np2, int k, int j) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np2 / 2) return;
+  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  const int l = i | j;
+  const bool up = (i & k) == 0;
+  const unsigned long long a = keys[i], b = keys[l];
+  if ((a > b) == up) keys[i] = b, keys[l] = a;
+}
+
+__global__ void k_gather_sorted(const unsigned long long* keys, const float4* pts, int n, float4* spts, int* perm) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int o = (int)(unsigned)keys[s];
+  perm[s] = o;
+  spts[s] = pts[o];
+}
+
+__global__ void k_boxes(const float4* spts, int n, int pts_per_box, Box* out, int nboxes) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nboxes) return;
+  const float inf = __builtin_inff();
+  Box b{inf, inf, inf, -inf, -inf, -inf};
+  for (int e = 0; e < pts_per_box; e++) {
+    const int s = c * pts_per_box + e;
+    if (s < n) {
+      const float4 p = spts[s];
+      b.lx = fminf(b.lx, p.x), b.ly = fminf(b.ly, p.y), b.lz = fminf(b.lz, p.z);
+      b.hx = fmaxf(b.hx, p.x), b.hy = fmaxf(b.hy, p.y), b.hz = fmaxf(b.hz, p.z);
+    }
+  }
+  out[c] = b;
+}
+
+// un-permute helpers for the getters: out[perm[s]] = in[s]
+template <typename T>
+__global__ void k_scatter_by_perm(const T* in, const int* perm, int n, T* out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) out[perm[s]] = in[s];
+}
+
+}  // namespace apd

@@ -188,7 +188,8 @@ int apdgicp_get_covariances(apdgicp_handle* h, int which, double* out, int64_t n
     if (n != c.n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the cloud size");
     APD_HIP(hipStreamSynchronize(e.stream));
     APD_TRY(e.d_stage.ensure((size_t)n * 16 * sizeof(double)));
-    hipLaunchKernelGGL(k_unpack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.cov.as<double>(), (int)n, e.d_stage.as<double>());
+    hipLaunchKernelGGL(k_unpack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.cov.as<double>(), c.perm.as<int>(), (int)n,
+                       e.d_stage.as<double>());
     APD_HIP(hipMemcpyAsync(out, e.d_stage.p, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
     return 0;
@@ -206,7 +207,8 @@ int apdgicp_set_covariances(apdgicp_handle* h, int which, const double* in, int6
     APD_HIP(hipStreamSynchronize(e.stream));
     APD_TRY(e.d_stage.ensure((size_t)n * 16 * sizeof(double)));
     APD_HIP(hipMemcpyAsync(e.d_stage.p, in, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, e.stream));
-    hipLaunchKernelGGL(k_pack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.d_stage.as<double>(), (int)n, c.cov.as<double>());
+    hipLaunchKernelGGL(k_pack_cov, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.d_stage.as<double>(), c.perm.as<int>(), (int)n,
+                       c.cov.as<double>());
     APD_HIP(hipStreamSynchronize(e.stream));
     c.cov_valid = true;
     return 0;
@@ -237,8 +239,14 @@ int apdgicp_get_correspondences(apdgicp_handle* h, int32_t* corr, float* sq, int
     Engine& e = h->eng;
     if (!h->pair_ready || !h->have_corr) return fail(APDGICP_ERR_NO_INPUT, "no correspondences yet");
     if (n != e.clouds[kSrc].n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
-    if (corr) APD_HIP(hipMemcpyAsync(corr, e.work.corr, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
-    if (sq) APD_HIP(hipMemcpyAsync(sq, e.work.sqd, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n * 8));
+    int* d_c = e.d_stage.as<int>();
+    float* d_s = (float*)(d_c + n);
+    hipLaunchKernelGGL(k_export_corr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.work.corr, e.work.sqd, e.clouds[kSrc].perm.as<int>(),
+                       e.clouds[kTgt].perm.as<int>(), (int)n, d_c, d_s);
+    if (corr) APD_HIP(hipMemcpyAsync(corr, d_c, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    if (sq) APD_HIP(hipMemcpyAsync(sq, d_s, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
     return 0;
   });
@@ -252,12 +260,13 @@ int apdgicp_get_mahalanobis(apdgicp_handle* h, double* out, int64_t n) {
     if (n != e.clouds[kSrc].n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
     const size_t ns = e.work.nstride;
     std::vector<double> m6(6 * ns);
-    std::vector<int> corr(n);
+    std::vector<int> corr(n), perm(n);
     APD_HIP(hipMemcpyAsync(m6.data(), e.work.maha, 6 * ns * sizeof(double), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipMemcpyAsync(corr.data(), e.work.corr, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipMemcpyAsync(perm.data(), e.clouds[kSrc].perm.p, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
-    for (int64_t i = 0; i < n; i++) {
-      double* o = out + 16 * i;
+    for (int64_t i = 0; i < n; i++) {  // i = position on the Z-curve, perm[i] = the caller's index
+      double* o = out + 16 * perm[i];
       memset(o, 0, 16 * sizeof(double));
       if (corr[i] < 0) continue;
       const double xx = m6[i], xy = m6[ns + i], xz = m6[2 * ns + i], yy = m6[3 * ns + i], yz = m6[4 * ns + i], zz = m6[5 * ns + i];
@@ -406,7 +415,7 @@ int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xy
     APD_TRY(e.d_stage.ensure((size_t)n * 12 + 64));
     float* dT = (float*)((char*)e.d_stage.p + (size_t)n * 12);
     APD_HIP(hipMemcpyAsync(dT, T, 16 * sizeof(float), hipMemcpyHostToDevice, e.stream));
-    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.pts.as<float4>(), (int)n, dT, e.d_stage.as<float>(),
+    hipLaunchKernelGGL(k_transform_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.opts.as<float4>(), (int)n, dT, e.d_stage.as<float>(),
                        3ll);
     if (out_stride_bytes == 12) {
       APD_HIP(hipMemcpyAsync(out_xyz, e.d_stage.p, (size_t)n * 12, hipMemcpyDeviceToHost, e.stream));
@@ -482,7 +491,7 @@ int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p) {
 int apdgicp_batch_clear(apdgicp_batch* b) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   APD_HIP(hipStreamSynchronize(b->eng.stream));
-  for (auto& c : b->eng.clouds) c.pts.release(), c.cov.release();
+  for (auto& c : b->eng.clouds) c.release_all();
   b->eng.clouds.clear();
   b->eng.desc_dirty = true;
   return 0;
