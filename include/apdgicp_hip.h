@@ -192,6 +192,10 @@ int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int
 int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable);
 int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches);
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
+/* pruning diagnostics, collected only when the environment has APDGICP_STATS=1 (else zeros); reading
+ * resets them.  [0..3] nearest neighbour: groups scanned, chunks tested, chunks scanned, waves;
+ * [4..9] covariance k-NN: groups, chunks tested, chunks scanned, waves, sweep rounds, candidates kept */
+int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]);
 
 #ifdef __cplusplus
 }

@@ -96,7 +96,7 @@ class Engine {
   int npairs = 0, nmax_src = 0;
   std::vector<PairDesc> h_pairs;
   DevBuf d_desc, d_pairs, d_state, d_results, d_status, d_guess, d_ids, d_errflag, d_probe, d_stage, d_T;
-  DevBuf d_jobs, d_keys, d_box6, d_listoff, d_glist;
+  DevBuf d_jobs, d_keys, d_box6, d_stats;
   DevBuf b_nnpart, b_corr, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
@@ -133,6 +133,10 @@ class Engine {
     APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
     APD_TRY(d_probe.ensure(64 * sizeof(double)));
     APD_TRY(d_T.ensure(16 * sizeof(double)));
+    if (env_int("APDGICP_STATS", 0)) {
+      APD_TRY(d_stats.ensure(16 * sizeof(unsigned long long)));
+      APD_HIP(hipMemsetAsync(d_stats.p, 0, 16 * sizeof(unsigned long long), stream));
+    }
     const char* m = getenv("APDGICP_NN_MODE");
     nn_pruned = !(m && std::string(m) == "brute");
     m = getenv("APDGICP_KNN_MODE");
@@ -146,7 +150,7 @@ class Engine {
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
     for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &d_jobs,
-                      &d_keys, &d_box6, &d_listoff, &d_glist, &b_nnpart, &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_nnpart, &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
@@ -356,19 +360,9 @@ class Engine {
     APD_TRY(d_ids.ensure(ids.size() * sizeof(int)));
     APD_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     if (knn_pruned) {
-      std::vector<long long> off(ids.size());
-      long long total = 0;
-      for (size_t q = 0; q < ids.size(); q++) {
-        off[q] = total;
-        total += (long long)((clouds[ids[q]].n + 63) & ~63) * KP_CAP;
-      }
-      APD_TRY(d_listoff.ensure(ids.size() * sizeof(long long)));
-      APD_TRY(d_glist.ensure((size_t)total * 8));
-      APD_HIP(hipMemcpyAsync(d_listoff.p, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
-      APD_HIP(hipStreamSynchronize(stream));  // `off` is a local
       const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)ids.size());
-      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), d_listoff.as<long long>(),
-                         d_glist.as<unsigned long long>(), params.k_correspondences, params.regularization, d_errflag.as<int>());
+      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
+                         params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
     } else {
       static bool attr_set = false;
       if (!attr_set) {
@@ -421,7 +415,7 @@ class Engine {
     int S = env_int("APDGICP_NN_S", 0);
     int T = 1;
     if (nn_pruned) {
-      if (S != 2 && S != 4) S = 2;
+      if (S != 1 && S != 2 && S != 4) S = 1;
     } else {
       if (S != 2 && S != 4 && S != 8) S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
       const int src_blocks = (nmax_src + NN_BLK * S - 1) / (NN_BLK * S);
@@ -446,6 +440,7 @@ class Engine {
     work.maha = b_maha.as<double>();
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();
+    work.stats = d_stats.as<unsigned long long>();
     return 0;
   }
 
@@ -468,7 +463,8 @@ class Engine {
     const PairDesc* pd = d_pairs.as<PairDesc>();
     const PairState* st = d_state.as<PairState>();
     if (nn_pruned) {
-      if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, stream, cd, pd, st, work);
+      if (nn_S == 1) hipLaunchKernelGGL(k_nn_pruned<1>, grid, dim3(64), 0, stream, cd, pd, st, work);
+      else if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, stream, cd, pd, st, work);
       else hipLaunchKernelGGL(k_nn_pruned<4>, grid, dim3(64), 0, stream, cd, pd, st, work);
     } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
     else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);

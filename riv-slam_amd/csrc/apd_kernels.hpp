@@ -79,6 +79,7 @@ struct Work {
   double* blkpart;             // [pair][nblk_max][kRed]
   double* errpart;             // [pair][nblk_max]
   int nstride, nblk_max, T;
+  unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -437,8 +438,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // one wave stages one 128-target group into its LDS tile: lane l loads targets 2l, 2l+1, and lanes
 // 0..47 the group's 8 chunk boxes (48 consecutive floats)
+template <bool WITH_PERM = false>
 __device__ __forceinline__ void stage_group(float4* txy, float2* tz, float* cbl, const float4* pts, const Box* cbox, int g, int M, int nchunks,
-                                            int lane) {
+                                            int lane, int* perml = nullptr, const int* perm = nullptr) {
   const float inf = __builtin_inff();
   const int j = g * kGroupPts + 2 * lane;
   const float4 a = j < M ? pts[j] : make_float4(inf, inf, inf, 0.f);
@@ -449,6 +451,10 @@ __device__ __forceinline__ void stage_group(float4* txy, float2* tz, float* cbl,
     const int c = g * kGroupChunks + lane / 6;
     cbl[lane] = c < nchunks ? ((const float*)cbox)[(size_t)g * kGroupChunks * 6 + lane] : inf;
   }
+  if (WITH_PERM) {
+    perml[2 * lane] = j < M ? perm[j] : 0x7fffffff;
+    perml[2 * lane + 1] = j + 1 < M ? perm[j + 1] : 0x7fffffff;
+  }
 }
 __device__ __forceinline__ Box lds_box(const float* cbl, int ch) {
   return Box{cbl[6 * ch], cbl[6 * ch + 1], cbl[6 * ch + 2], cbl[6 * ch + 3], cbl[6 * ch + 4], cbl[6 * ch + 5]};
@@ -456,17 +462,19 @@ __device__ __forceinline__ Box lds_box(const float* cbl, int ch) {
 
 // ----------------------------------------------------------------------------------------------
 // k_nn_pruned: the same exact 1-NN as k_nn_partial, on Z-curve-sorted clouds.  One wave (= one block)
-// owns 64*S consecutive sorted source points, i.e. a spatially compact set.  Target groups (128 pts)
-// are tested lane-parallel against the wave's bounding box; surviving groups are staged into the
-// wave's LDS tile and their 16-point chunks are tested per lane against the running best before the
-// 16x(S) distance block is evaluated.  Pass 0 visits the groups that overlap the wave box (they seed
-// `best`), pass 1 the remaining ones that can still beat the largest `best` in the wave.
+// owns 64*S consecutive sorted source points, i.e. a spatially compact set.  For every 128-point
+// target group each lane evaluates the lower bound of ITS points to the group box; the wave stages
+// and scans a group only if some lane can still improve, and inside a group the 16-point chunks are
+// tested the same way before their distances are evaluated.  The group that contains most of the
+// wave's points is scanned first so that `best` is tight before the sweep.
+constexpr int GB_BATCH = 256;  // group boxes staged per LDS batch (6 KB)
+
 template <int S>
 __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
-  static_assert(S % 2 == 0, "S must be even");
   __shared__ float4 txy[kGroupPts / 2];
   __shared__ float2 tz[kGroupPts / 2];
   __shared__ float cbl[6 * kGroupChunks];
+  __shared__ float gbl[6 * GB_BATCH];
   const int pair = blockIdx.y;
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
@@ -478,85 +486,82 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   load_Tf(st[pair].x0, Tf);
   const float inf = __builtin_inff();
 
-  float2v px[S / 2], py[S / 2], pz[S / 2];
-  Box wb{inf, inf, inf, -inf, -inf, -inf};
+  float px[S], py[S], pz[S], best[S];
+  unsigned bestc[S];
 #pragma unroll
   for (int s = 0; s < S; s++) {
     const int i = base + s * 64 + lane;
     const float4 p = src.pts[i < N ? i : N - 1];
-    const float x = xf_row(Tf + 0, p.x, p.y, p.z), y = xf_row(Tf + 4, p.x, p.y, p.z), z = xf_row(Tf + 8, p.x, p.y, p.z);
-    if (s & 1) px[s / 2].y = x, py[s / 2].y = y, pz[s / 2].y = z;
-    else px[s / 2].x = x, py[s / 2].x = y, pz[s / 2].x = z;
-    wb.lx = fminf(wb.lx, x), wb.ly = fminf(wb.ly, y), wb.lz = fminf(wb.lz, z);
-    wb.hx = fmaxf(wb.hx, x), wb.hy = fmaxf(wb.hy, y), wb.hz = fmaxf(wb.hz, z);
+    px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
+    best[s] = inf, bestc[s] = kNoChunk;
   }
-  wb.lx = wave_min(wb.lx), wb.ly = wave_min(wb.ly), wb.lz = wave_min(wb.lz);
-  wb.hx = wave_max(wb.hx), wb.hy = wave_max(wb.hy), wb.hz = wave_max(wb.hz);
-
-  float best[S];
-  unsigned bestc[S];
-#pragma unroll
-  for (int s = 0; s < S; s++) best[s] = inf, bestc[s] = kNoChunk;
-  float maxbest = inf;
-
   const int ngroups = (M + kGroupPts - 1) / kGroupPts;
   const int nchunks = (M + kChunk - 1) / kChunk;
-  for (int pass = 0; pass < 2; pass++) {
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
-      const int gl = g0 + lane;
-      const float lbg = gl < ngroups ? lb_box_box(wb, tgt.gbox[gl]) : inf;
-      unsigned long long mask = __ballot(pass == 0 ? (lbg == 0.f) : (lbg > 0.f && lbg <= maxbest));
-      while (mask) {
-        const int gi = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        if (pass == 1 && __shfl(lbg, gi, 64) > maxbest) continue;  // maxbest may have shrunk meanwhile
-        const int g = g0 + gi;
-        __syncthreads();  // single-wave block: orders the LDS tile reuse
-        stage_group(txy, tz, cbl, tgt.pts, tgt.cbox, g, M, nchunks, lane);
-        __syncthreads();
-        const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
-        for (int ch = 0; ch < cend; ch++) {
-          const int c = g * kGroupChunks + ch;
-          const Box cb = lds_box(cbl, ch);
-          bool need = false;
+
+  unsigned n_groups = 0, n_ctest = 0, n_cscan = 0;
+  auto scan_group = [&](int g) {
+    n_groups++;
+    __syncthreads();  // single-wave block: orders the reuse of the LDS tile
+    stage_group(txy, tz, cbl, tgt.pts, tgt.cbox, g, M, nchunks, lane);
+    __syncthreads();
+    const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
+    for (int ch = 0; ch < cend; ch++) {
+      const Box cb = lds_box(cbl, ch);
+      bool need = false;
 #pragma unroll
-          for (int s = 0; s < S; s++) {
-            const float x = (s & 1) ? px[s / 2].y : px[s / 2].x, y = (s & 1) ? py[s / 2].y : py[s / 2].x, z = (s & 1) ? pz[s / 2].y : pz[s / 2].x;
-            need |= lb_point_box(cb, x, y, z) <= best[s];
-          }
-          if (!__any(need)) continue;
-          float m[S];
+      for (int s = 0; s < S; s++) need |= lb_point_box(cb, px[s], py[s], pz[s]) <= best[s];
+      n_ctest++;
+      if (!__any(need)) continue;
+      n_cscan++;
+      float m[S];
 #pragma unroll
-          for (int s = 0; s < S; s++) m[s] = inf;
+      for (int s = 0; s < S; s++) m[s] = inf;
 #pragma unroll
-          for (int jj = 0; jj < kChunk / 2; jj++) {
-            const float4 A = txy[ch * (kChunk / 2) + jj];
-            const float2 Z = tz[ch * (kChunk / 2) + jj];
+      for (int jj = 0; jj < kChunk / 2; jj++) {
+        const float4 A = txy[ch * (kChunk / 2) + jj];
+        const float2 Z = tz[ch * (kChunk / 2) + jj];
 #pragma unroll
-            for (int sp = 0; sp < S / 2; sp++) {
-              float2v dx = A.x - px[sp], dy = A.z - py[sp], dz = Z.x - pz[sp];
-              float2v d0 = dx * dx;
-              d0 = d0 + dy * dy;
-              d0 = d0 + dz * dz;
-              dx = A.y - px[sp], dy = A.w - py[sp], dz = Z.y - pz[sp];
-              float2v d1 = dx * dx;
-              d1 = d1 + dy * dy;
-              d1 = d1 + dz * dz;
-              m[2 * sp] = fminf(fminf(m[2 * sp], d0.x), d1.x);
-              m[2 * sp + 1] = fminf(fminf(m[2 * sp + 1], d0.y), d1.y);
-            }
-          }
-#pragma unroll
-          for (int s = 0; s < S; s++) {
-            if (m[s] < best[s]) best[s] = m[s], bestc[s] = (unsigned)c;
-            else if (m[s] == best[s] && m[s] < inf && (bestc[s] & ~kTieBit) != (unsigned)c) bestc[s] |= kTieBit;
-          }
+        for (int s = 0; s < S; s++) {
+          const float d0 = sqdist1(A.x, A.z, Z.x, px[s], py[s], pz[s]);
+          const float d1 = sqdist1(A.y, A.w, Z.y, px[s], py[s], pz[s]);
+          m[s] = fminf(fminf(m[s], d0), d1);
         }
-        float mb = best[0];
-#pragma unroll
-        for (int s = 1; s < S; s++) mb = fmaxf(mb, best[s]);
-        maxbest = wave_max(mb);
       }
+      const unsigned c = (unsigned)(g * kGroupChunks + ch);
+#pragma unroll
+      for (int s = 0; s < S; s++) {
+        if (m[s] < best[s]) best[s] = m[s], bestc[s] = c;
+        else if (m[s] == best[s] && m[s] < inf && (bestc[s] & ~kTieBit) != c) bestc[s] |= kTieBit;
+      }
+    }
+  };
+
+  for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
+    const int nb = min(GB_BATCH, ngroups - gb0);
+    __syncthreads();
+    for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
+    __syncthreads();
+    // seed: the group whose box contains the most points of this wave
+    int seed = -1, seed_cnt = 0;
+    if (gb0 == 0) {
+      for (int g = 0; g < nb; g++) {
+        const Box gb = lds_box(gbl, g);
+        int inside = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) inside += lb_point_box(gb, px[s], py[s], pz[s]) == 0.f ? 1 : 0;
+        const int cntg = __popcll(__ballot(inside > 0));
+        if (cntg > seed_cnt) seed_cnt = cntg, seed = g;
+      }
+      if (seed >= 0) scan_group(seed);
+    }
+    for (int g = 0; g < nb; g++) {
+      if (g == seed) continue;
+      const Box gb = lds_box(gbl, g);
+      bool need = false;
+#pragma unroll
+      for (int s = 0; s < S; s++) need |= lb_point_box(gb, px[s], py[s], pz[s]) <= best[s];
+      if (!__any(need)) continue;
+      scan_group(gb0 + g);
     }
   }
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
@@ -565,184 +570,188 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
     const int i = base + s * 64 + lane;
     if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
   }
+  if (w.stats && lane == 0) {
+    atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
+    atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_knn_cov_pruned: calculate_covariances (A:303-363) on Z-curve-sorted clouds; exact k-NN with
-// bounding-box pruning.  One wave owns 64 consecutive sorted queries.
-//   phase 1  tau = k-th smallest of 32 strided class minima over the ~320 sorted neighbours around the
-//            wave (>= k distinct points lie inside, so tau bounds the k-th neighbour distance)
-//   phase 2  groups / chunks whose lower bound exceeds tau are skipped; every candidate with
-//            (d, original index) <= tau is appended to the query's list in global memory (slot-major,
-//            coalesced; a list is ~1.5-3 k entries, so it stays in L2); on overflow tau is tightened
-//            to the k-th smallest stored key and the sweep repeats for that wave
-//   phase 3  k rounds of min-extraction over the 64-bit keys (distance bits << 32 | original index:
-//            lexicographic order == the reference's (distance, index) order), sums in fp64
-constexpr int KP_CAP = 64, KP_WIN = 320;
+// wave-wide bitonic sort (ascending over lane id) of one 64-bit key per lane
+__device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)v, j, 64), hi = __shfl_xor((unsigned)(v >> 32), j, 64);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      const bool asc = (lane & k) == 0, lower = (lane & j) == 0;
+      const bool take_min = lower == asc;
+      v = take_min ? (o < v ? o : v) : (o > v ? o : v);
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, off, 64), hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long dist_key(float d, int orig) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)orig; }
 
-__global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, const long long* list_off,
-                                                       unsigned long long* glist, int k, int reg, int* err_flag) {
-  __shared__ float4 txy[KP_WIN / 2];
-  __shared__ float2 tz[KP_WIN / 2];
-  __shared__ float cbl[6 * kGroupChunks];
+// ----------------------------------------------------------------------------------------------
+// k_knn_cov_pruned: calculate_covariances (A:303-363) on Z-curve-sorted clouds; exact k-NN.
+// One wave owns 64 consecutive sorted queries and works through them ONE AT A TIME with the lanes
+// spread over the CANDIDATES (no divergence, coalesced loads, per-query pruning):
+//   1. tau_key = k-th smallest (distance, original index) key among the 64 sorted neighbours of the
+//      query (a wave bitonic sort): k distinct points lie within it, so it bounds the k-th neighbour;
+//   2. the group boxes (staged once per wave in LDS) are tested lane-parallel against tau; each
+//      surviving 128-point group is evaluated two candidates per lane, and the candidates with
+//      key <= tau_key are compacted into the query's LDS list with ballot/popcount;
+//   3. the list (normally < 64 keys) is sorted across the wave; the first k lanes hold the neighbours.
+// Neighbour indices are parked in LDS; after the 64 queries every lane finishes ITS query: gathers
+// the k points, accumulates the moments in fp64 relative to the query (exact differences),
+// cov = S2/k - m m^T (A:323-324), 3x3 Jacobi eigen-decomposition and the regularisation (A:326-357).
+constexpr int KT_CAP = 128;
+
+__global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
+                                                       unsigned long long* stats) {
+  __shared__ float gbl[6 * GB_BATCH];
+  __shared__ unsigned long long lst[KT_CAP];
+  __shared__ int nbr[64 * KNN_NC];  // [query][slot]
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
   const int base = blockIdx.x * 64;
   if (base >= n) return;
-  const int i = base + lane;
-  const bool valid = i < n;
-  const float4 q = c.pts[valid ? i : n - 1];
   const float inf = __builtin_inff();
-  const int npad = (n + 63) & ~63;
-  unsigned long long* mylist = glist + list_off[blockIdx.y] + i;  // + slot * npad
-
-  // ---- phase 1: bound from the sorted neighbourhood
-  int w0 = max(0, base - (KP_WIN - 64) / 2) & ~1;
-  if (w0 + KP_WIN > n) w0 = max(0, n - KP_WIN) & ~1;
-  for (int e = lane; e < KP_WIN / 2; e += 64) {
-    const int j = w0 + 2 * e;
-    const float4 a = j < n ? c.pts[j] : make_float4(inf, inf, inf, 0.f);
-    const float4 b = j + 1 < n ? c.pts[j + 1] : make_float4(inf, inf, inf, 0.f);
-    txy[e] = make_float4(a.x, b.x, a.y, b.y);
-    tz[e] = make_float2(a.z, b.z);
-  }
-  __syncthreads();
-  float cm[KNN_NC];
-#pragma unroll
-  for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
-  for (int e0 = 0; e0 < KP_WIN / 2; e0 += KNN_NC) {
-#pragma unroll
-    for (int s = 0; s < KNN_NC; s++) {
-      const float4 A = txy[e0 + s];
-      const float2 Z = tz[e0 + s];
-      const float d0 = sqdist1(A.x, A.z, Z.x, q.x, q.y, q.z), d1 = sqdist1(A.y, A.w, Z.y, q.x, q.y, q.z);
-      cm[s] = fminf(fminf(cm[s], d0), d1);
-    }
-  }
-#pragma unroll
-  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
-#pragma unroll
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int a = 0; a < KNN_NC; a++) {
-        const int l = a ^ j;
-        if (l > a) {
-          const bool up = (a & kk) == 0;
-          const float x = cm[a], y = cm[l];
-          const float lo = fminf(x, y), hi = fmaxf(x, y);
-          cm[a] = up ? lo : hi;
-          cm[l] = up ? hi : lo;
-        }
-      }
-    }
-  }
-  float tau_d = inf;
-#pragma unroll
-  for (int s = 0; s < KNN_NC; s++)
-    if (s == k - 1) tau_d = cm[s];
-  unsigned long long tau_key = ((unsigned long long)__float_as_uint(tau_d) << 32) | 0xFFFFFFFFull;
-
-  Box wb;
-  wb.lx = wave_min(q.x), wb.ly = wave_min(q.y), wb.lz = wave_min(q.z);
-  wb.hx = wave_max(q.x), wb.hy = wave_max(q.y), wb.hz = wave_max(q.z);
-
-  // ---- phase 2
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
-  const int nchunks = (n + kChunk - 1) / kChunk;
-  bool active = valid;
-  int cnt_final = 0;
-  for (int round = 0;; round++) {
-    int cnt = 0;
-    const float my_tau = active ? __uint_as_float((unsigned)(tau_key >> 32)) : -1.f;
-    const float maxtau = wave_max(my_tau);
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
-      const int gl = g0 + lane;
-      const float lbg = gl < ngroups ? lb_box_box(wb, c.gbox[gl]) : inf;
-      unsigned long long mask = __ballot(lbg <= maxtau);
-      while (mask) {
-        const int gi = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int g = g0 + gi;
-        __syncthreads();
-        stage_group(txy, tz, cbl, c.pts, c.cbox, g, n, nchunks, lane);
-        __syncthreads();
-        const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
-        for (int ch = 0; ch < cend; ch++) {
-          const int cc = g * kGroupChunks + ch;
-          const bool need = active && lb_point_box(lds_box(cbl, ch), q.x, q.y, q.z) <= my_tau;
-          if (!__any(need)) continue;
-#pragma unroll
-          for (int jj = 0; jj < kChunk / 2; jj++) {
-            const float4 A = txy[ch * (kChunk / 2) + jj];
-            const float2 Z = tz[ch * (kChunk / 2) + jj];
-            const float d0 = sqdist1(A.x, A.z, Z.x, q.x, q.y, q.z), d1 = sqdist1(A.y, A.w, Z.y, q.x, q.y, q.z);
-            const int j0 = cc * kChunk + 2 * jj;
-            if (need && d0 <= my_tau) {
-              const unsigned long long key = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)c.perm[j0];
-              if (key <= tau_key) {
-                if (cnt < KP_CAP) mylist[(size_t)cnt * npad] = key;
-                cnt++;
-              }
-            }
-            if (need && d1 <= my_tau) {  // pad targets are +inf and never pass
-              const unsigned long long key = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)c.perm[j0 + 1];
-              if (key <= tau_key) {
-                if (cnt < KP_CAP) mylist[(size_t)cnt * npad] = key;
-                cnt++;
-              }
-            }
-          }
-        }
-      }
-    }
-    bool ovf = false;
-    if (active) {
-      ovf = cnt > KP_CAP;
-      cnt_final = min(cnt, KP_CAP);
-      if (ovf) {  // tighten: k-th smallest stored key
-        unsigned long long last = 0;
-        bool first = true;
-        for (int r = 0; r < k; r++) {
-          unsigned long long bk = ~0ull;
-          for (int a = 0; a < KP_CAP; a++) {
-            const unsigned long long key = mylist[(size_t)a * npad];
-            if ((first || key > last) && key < bk) bk = key;
-          }
-          last = bk, first = false;
-        }
-        tau_key = last;
-      }
-    }
-    active = ovf;
-    if (!__any(ovf)) break;
-    if (round >= 40) {
-      if (lane == 0) atomicExch(err_flag, 1);
-      break;
-    }
-  }
-  if (!valid) return;
+  unsigned n_groups = 0, n_compact = 0, n_cand = 0;
 
-  // ---- phase 3
-  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-  {
-    unsigned long long last = 0;
-    bool first = true;
-    for (int r = 0; r < k; r++) {
-      unsigned long long bk = ~0ull;
-      for (int a = 0; a < cnt_final; a++) {
-        const unsigned long long key = mylist[(size_t)a * npad];
-        if ((first || key > last) && key < bk) bk = key;
-      }
-      if (bk == ~0ull) {
-        atomicExch(err_flag, 2);
-        break;
-      }
-      last = bk, first = false;
-      const float4 p = c.opts[(unsigned)bk];
-      const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
-      s1x += x, s1y += y, s1z += z;
-      sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+  const int nq = min(64, n - base);
+  for (int qi = 0; qi < nq; qi++) {
+    const int qidx = base + qi;
+    const float4 q = c.pts[qidx];
+    // ---- 1. bound from the 64 sorted neighbours
+    int w0 = min(max(qidx - 32, 0), max(n - 64, 0));
+    const int jw = w0 + lane;
+    unsigned long long key = ~0ull;
+    if (jw < n) {
+      const float4 t = c.pts[jw];
+      key = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[jw]);
     }
+    key = wave_sort_u64(key, lane);
+    unsigned long long tau_key;
+    {
+      const unsigned lo = __shfl((unsigned)key, k - 1, 64), hi = __shfl((unsigned)(key >> 32), k - 1, 64);
+      tau_key = ((unsigned long long)hi << 32) | lo;
+    }
+    float tau_d = __uint_as_float((unsigned)(tau_key >> 32));
+    // ---- 2. candidates
+    int cnt = 0;
+    for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
+      const int nb = min(GB_BATCH, ngroups - gb0);
+      if (ngroups > GB_BATCH || qi == 0) {  // group boxes: staged once per wave when they all fit
+        __syncthreads();
+        for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
+        __syncthreads();
+      }
+      for (int g0 = 0; g0 < nb; g0 += 64) {
+        const int gl = g0 + lane;
+        const bool pass = gl < nb && lb_point_box(lds_box(gbl, gl < nb ? gl : 0), q.x, q.y, q.z) <= tau_d;
+        unsigned long long gmask = __ballot(pass);
+        while (gmask) {
+          const int g = gb0 + g0 + __builtin_ctzll(gmask);
+          gmask &= gmask - 1;
+          n_groups++;
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int j = g * kGroupPts + h * 64 + lane;
+            unsigned long long ck = ~0ull;
+            if (j < n) {
+              const float4 t = c.pts[j];
+              ck = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[j]);
+            }
+            const bool in = ck <= tau_key;
+            const unsigned long long m = __ballot(in);
+            const int add = __popcll(m);
+            if (cnt + add > KT_CAP) {
+              // list full: tighten tau to the k-th smallest stored key and keep only the keys <= tau
+              // (tau only decreases, so nothing that belongs to the final answer is ever dropped)
+              unsigned long long last = 0;
+              bool first = true;
+              for (int r = 0; r < k; r++) {
+                unsigned long long bk = ~0ull;
+                for (int e = lane; e < cnt; e += 64) {
+                  const unsigned long long x = lst[e];
+                  if ((first || x > last) && x < bk) bk = x;
+                }
+                last = wave_min_u64(bk), first = false;
+              }
+              tau_key = last;
+              tau_d = __uint_as_float((unsigned)(tau_key >> 32));
+              const unsigned long long e0 = lane < cnt ? lst[lane] : ~0ull, e1 = lane + 64 < cnt ? lst[lane + 64] : ~0ull;
+              __syncthreads();
+              const unsigned long long m0 = __ballot(e0 <= tau_key), m1 = __ballot(e1 <= tau_key);
+              const unsigned long long below = (1ull << lane) - 1ull;
+              if (e0 <= tau_key) lst[__popcll(m0 & below)] = e0;
+              if (e1 <= tau_key) lst[__popcll(m0) + __popcll(m1 & below)] = e1;
+              cnt = __popcll(m0) + __popcll(m1);
+              __syncthreads();
+              n_compact++;
+            }
+            const bool in2 = ck <= tau_key;
+            const unsigned long long m2 = __ballot(in2);
+            if (in2) lst[cnt + __popcll(m2 & ((1ull << lane) - 1ull))] = ck;
+            cnt += __popcll(m2);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    n_cand += cnt;
+    // ---- 3. the k smallest keys -> lanes 0..k-1
+    unsigned long long mine;
+    if (cnt <= 64) {
+      mine = wave_sort_u64(lane < cnt ? lst[lane] : ~0ull, lane);
+    } else {
+      unsigned long long last = 0;
+      bool first = true;
+      mine = ~0ull;
+      for (int r = 0; r < k; r++) {
+        unsigned long long bk = ~0ull;
+        for (int e = lane; e < cnt; e += 64) {
+          const unsigned long long x = lst[e];
+          if ((first || x > last) && x < bk) bk = x;
+        }
+        last = wave_min_u64(bk), first = false;
+        if (lane == r) mine = last;
+      }
+    }
+    if (lane < k) {
+      if (mine == ~0ull) atomicExch(err_flag, 2);  // fewer than k candidates: impossible for n >= k
+      nbr[qi * KNN_NC + lane] = (int)(unsigned)mine;
+    }
+    __syncthreads();
+  }
+  if (stats && lane == 0) {
+    atomicAdd(stats + 4, (unsigned long long)n_groups), atomicAdd(stats + 7, 1ull);
+    atomicAdd(stats + 8, (unsigned long long)n_compact), atomicAdd(stats + 9, (unsigned long long)n_cand);
+  }
+
+  // ---- every lane finishes its own query
+  const int i = base + lane;
+  if (i >= n) return;
+  const float4 q = c.pts[i];
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  for (int r = 0; r < k; r++) {
+    const float4 p = c.opts[nbr[lane * KNN_NC + r]];
+    const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
+    s1x += x, s1y += y, s1z += z;
+    sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
   }
   const double ik = 1.0 / (double)k;
   const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;

@@ -579,6 +579,17 @@ int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* laun
   return 0;
 }
 
+int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]) {
+  if (!b || !out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  Engine& e = b->eng;
+  memset(out, 0, 16 * sizeof(unsigned long long));
+  if (!e.d_stats.p) return 0;
+  APD_HIP(hipMemcpyAsync(out, e.d_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e.stream));
+  APD_HIP(hipMemsetAsync(e.d_stats.p, 0, 16 * sizeof(unsigned long long), e.stream));
+  APD_HIP(hipStreamSynchronize(e.stream));
+  return 0;
+}
+
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   if (ticks) *ticks = b->eng.last_ticks;

@@ -88,7 +88,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks",
+    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
 ]
 
 _lib = None
@@ -149,6 +149,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
     L.apdgicp_batch_last_nn_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.apdgicp_batch_debug_stats.argtypes = [vp, vp]
     if path is None:
         _lib = L
     return L
@@ -482,6 +483,11 @@ class BatchAPDGICP:
         ms, n = C.c_double(), C.c_int64()
         _check(self.L.apdgicp_batch_last_nn_time(self.b, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def debug_stats(self):
+        out = np.zeros(16, dtype=np.uint64)
+        _check(self.L.apdgicp_batch_debug_stats(self.b, _ptr(out)))
+        return out
 
     def last_ticks(self):
         a, s, t = C.c_int(), C.c_int(), C.c_int()
