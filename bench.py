@@ -91,8 +91,7 @@ def main():
 
     class Engine:  # this rank's block through the C ABI
         def align_block(self, _indices):
-            for i, c in enumerate(d_clouds):      # fresh clouds every step: covariances are recomputed
-                batch.set_cloud(i, c)
+            batch.set_clouds(0, d_clouds)         # fresh clouds every step: covariances are recomputed
             batch.align_async(pairs_arr)
             batch.copy_results_to(d_res, P)
             return d_res

@@ -173,6 +173,10 @@ int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64
 /* replaces cloud `index` (0 <= index <= number of clouds; == appends) in place, reusing its device
  * buffers; its covariances are recomputed by the next align */
 int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
+/* sets clouds first_index .. first_index+count-1 in one call (one pack launch when on_device):
+ * xyz[i] / n[i] describe cloud first_index+i, all with the same stride */
+int apdgicp_batch_set_clouds(apdgicp_batch* b, int32_t first_index, int32_t count, const float* const* xyz, const int64_t* n,
+                             int64_t stride_bytes, int on_device);
 /* covariances of every cloud that does not have them yet (align does this lazily as well) */
 int apdgicp_batch_compute_covariances(apdgicp_batch* b);
 /* aligns all pairs; results[i] belongs to pairs[i].  `results` is host memory. */

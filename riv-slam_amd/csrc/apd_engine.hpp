@@ -221,6 +221,41 @@ class Engine {
     return 0;
   }
 
+  // many device-resident clouds at once: one pack launch instead of one per cloud
+  int set_clouds_device(int first, int count, const float* const* xyz, const int64_t* ns, int64_t stride_bytes) {
+    if (first < 0 || count <= 0 || first > (int)clouds.size()) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud range");
+    if (!xyz || !ns) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
+    APD_HIP(hipSetDevice(device));
+    if ((int)clouds.size() < first + count) clouds.resize(first + count);
+    bool grew = false;
+    int nmax = 0;
+    for (int q = 0; q < count; q++) {
+      if (!xyz[q] || ns[q] <= 0 || ns[q] > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud is null, empty or too large");
+      grew |= (size_t)ns[q] * 16 > clouds[first + q].opts.cap;
+      nmax = std::max<int>(nmax, (int)ns[q]);
+    }
+    APD_HIP(hipStreamSynchronize(stream));  // d_jobs reuse (and buffer growth)
+    std::vector<PackJob> jobs(count);
+    for (int q = 0; q < count; q++) {
+      Cloud& c = clouds[first + q];
+      APD_TRY(c.opts.ensure((size_t)ns[q] * 16));
+      jobs[q] = PackJob{(const char*)xyz[q], c.opts.as<float4>(), (long long)stride_bytes, (int)ns[q], 0};
+      c.n = (int)ns[q];
+      c.sorted = false;
+      c.cov_valid = false;
+      c.token = 0;
+    }
+    (void)grew;
+    APD_TRY(d_jobs.ensure(std::max(jobs.size() * sizeof(PackJob), (size_t)count * sizeof(SortJob))));
+    APD_HIP(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_pack_points_multi, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, stream, d_jobs.as<PackJob>());
+    APD_HIP(hipGetLastError());
+    APD_HIP(hipStreamSynchronize(stream));  // `jobs` is a local; the caller's buffers are free again
+    desc_dirty = true;
+    return 0;
+  }
+
   void clear_cloud(int slot) {
     if (slot < (int)clouds.size()) {
       clouds[slot].n = 0;

@@ -107,6 +107,21 @@ __global__ void k_pack_points(const char* raw, long long stride_bytes, int n, fl
 }
 
 // sorted SoA covariances -> n x Matrix4d (column-major) in the caller's point order
+struct PackJob {
+  const char* raw;
+  float4* out;
+  long long stride_bytes;
+  int n;
+  int pad_;
+};
+__global__ void k_pack_points_multi(const PackJob* jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= j.n) return;
+  const float* p = (const float*)(j.raw + (long long)i * j.stride_bytes);
+  j.out[i] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+
 __global__ void k_unpack_cov(const double* cov6, const int* perm, int n, double* out16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -519,6 +519,17 @@ int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, i
   });
 }
 
+int apdgicp_batch_set_clouds(apdgicp_batch* b, int32_t first_index, int32_t count, const float* const* xyz, const int64_t* n, int64_t stride_bytes,
+                             int on_device) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    if (on_device) return b->eng.set_clouds_device(first_index, count, xyz, n, stride_bytes);
+    if (!xyz || !n) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    for (int q = 0; q < count; q++) APD_TRY(b->eng.set_cloud(first_index + q, xyz[q], n[q], stride_bytes, 0, 0));
+    return 0;
+  });
+}
+
 int apdgicp_batch_compute_covariances(apdgicp_batch* b) {
   return guarded([&]() -> int {
     if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");

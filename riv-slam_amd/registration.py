@@ -86,7 +86,7 @@ SYMBOLS = [
     "apdgicp_get_mahalanobis", "apdgicp_align", "apdgicp_align_host_loop", "apdgicp_get_final_hessian",
     "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_synchronize",
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
-    "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
+    "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
     "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
 ]
@@ -143,6 +143,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_set_params.argtypes = [vp, C.POINTER(Params)]
     L.apdgicp_batch_add_cloud.argtypes = [vp, vp, i64, i64, i32]
     L.apdgicp_batch_set_cloud.argtypes = [vp, i32, vp, i64, i64, i32]
+    L.apdgicp_batch_set_clouds.argtypes = [vp, i32, i32, vp, vp, i64, i32]
     L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
     L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
     L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
@@ -438,6 +439,17 @@ class BatchAPDGICP:
         idx = _check(self.L.apdgicp_batch_set_cloud(self.b, index, p, n, stride, dev))
         self.n_clouds = max(self.n_clouds, idx + 1)
         return idx
+
+    def set_clouds(self, first_index: int, clouds):
+        """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride"""
+        args = [_cloud_arg(c) for c in clouds]
+        stride, dev = args[0][2], args[0][3]
+        if any(a[2] != stride or a[3] != dev for a in args):
+            raise ValueError("set_clouds needs one stride and one memory space")
+        ptrs = (C.c_void_p * len(args))(*[a[0] if isinstance(a[0], C.c_void_p) else a[0] for a in args])
+        ns = (C.c_int64 * len(args))(*[a[1] for a in args])
+        _check(self.L.apdgicp_batch_set_clouds(self.b, first_index, len(args), ptrs, ns, stride, dev))
+        self.n_clouds = max(self.n_clouds, first_index + len(args))
 
     def compute_covariances(self):
         _check(self.L.apdgicp_batch_compute_covariances(self.b))
