@@ -97,7 +97,7 @@ class Engine {
   std::vector<PairDesc> h_pairs;
   DevBuf d_desc, d_pairs, d_state, d_results, d_status, d_guess, d_ids, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_jobs, d_keys, d_box6, d_stats;
-  DevBuf b_nnpart, b_corr, b_sqd, b_maha, b_blkpart, b_errpart;
+  DevBuf b_nnpart, b_corr, b_nnidx, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
@@ -150,7 +150,7 @@ class Engine {
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
     for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &d_jobs,
-                      &d_keys, &d_box6, &d_stats, &b_nnpart, &b_corr, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_nnpart, &b_corr, &b_nnidx, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
@@ -396,7 +396,9 @@ class Engine {
     APD_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     if (knn_pruned) {
       const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)ids.size());
-      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
+      const int ngmax = std::min(GB_BATCH, (nmax + kGroupPts - 1) / kGroupPts);
+      const size_t lds = KT_CAP * 8 + 64 * params.k_correspondences * 4 + (size_t)ngmax * 6 * 4;
+      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), lds, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
                          params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
     } else {
       static bool attr_set = false;
@@ -465,12 +467,15 @@ class Engine {
     const size_t ns = work.nstride;
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
+    APD_TRY(b_nnidx.ensure((size_t)npairs * ns * 4));
+    APD_HIP(hipMemsetAsync(b_nnidx.p, 0xFF, (size_t)npairs * ns * 4, stream));  // -1: no warm start yet
     APD_TRY(b_sqd.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_maha.ensure((size_t)npairs * 6 * ns * 8));
     APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
     APD_TRY(b_errpart.ensure((size_t)npairs * work.nblk_max * 8));
     work.nnpart = b_nnpart.as<unsigned long long>();
     work.corr = b_corr.as<int>();
+    work.nnidx = b_nnidx.as<int>();
     work.sqd = b_sqd.as<float>();
     work.maha = b_maha.as<double>();
     work.blkpart = b_blkpart.as<double>();
@@ -552,6 +557,9 @@ class Engine {
   int run_align() {
     APD_HIP(hipSetDevice(device));
     nn_events_used = 0;
+    // every align starts cold (hints of an earlier run would still be valid bounds, but results must
+    // not depend on call history in any observable way, timing included)
+    APD_HIP(hipMemsetAsync(b_nnidx.p, 0xFF, (size_t)npairs * work.nstride * 4, stream));
     hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
                        params.max_iterations);
     const bool lm = params.optimizer == APDGICP_OPT_LM;

@@ -74,6 +74,8 @@ constexpr unsigned kTieBit = 0x80000000u;  // set in a chunk id when the minimum
 struct Work {
   unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
   int* corr;                   // [pair][nstride]   correspondences_ (A:156)
+  int* nnidx;                  // [pair][nstride]   nearest neighbour found by the previous linearize, ungated (-1: none):
+                               //                   a warm start for the pruned search, never an input of the result
   float* sqd;                  // [pair][nstride]   sq_distances_ (A:153)
   double* maha;                // [pair][6][nstride] mahalanobis_ upper triangle (A:191)
   double* blkpart;             // [pair][nblk_max][kRed]
@@ -501,15 +503,29 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   load_Tf(st[pair].x0, Tf);
   const float inf = __builtin_inff();
 
+  // Warm start: the neighbour found by the previous iteration is a real target point, so its
+  // distance at the new pose is a valid upper bound of the minimum and makes the pruning effective
+  // from the first group on.  It only changes which chunks are visited, never the result.
   float px[S], py[S], pz[S], best[S];
   unsigned bestc[S];
+  bool all_hinted = true;
 #pragma unroll
   for (int s = 0; s < S; s++) {
     const int i = base + s * 64 + lane;
-    const float4 p = src.pts[i < N ? i : N - 1];
+    const int ii = i < N ? i : N - 1;
+    const float4 p = src.pts[ii];
     px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
     best[s] = inf, bestc[s] = kNoChunk;
+    const int hint = w.nnidx[(size_t)pair * w.nstride + ii];
+    if (hint >= 0 && hint < M) {
+      const float4 t = tgt.pts[hint];
+      const float d = sqdist1(t.x, t.y, t.z, px[s], py[s], pz[s]);
+      if (d < inf) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
+    } else {
+      all_hinted = false;
+    }
   }
+  all_hinted = __all(all_hinted);
   const int ngroups = (M + kGroupPts - 1) / kGroupPts;
   const int nchunks = (M + kChunk - 1) / kChunk;
 
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
     __syncthreads();
     // seed: the group whose box contains the most points of this wave
     int seed = -1, seed_cnt = 0;
-    if (gb0 == 0) {
+    if (gb0 == 0 && !all_hinted) {
       for (int g = 0; g < nb; g++) {
         const Box gb = lds_box(gbl, g);
         int inside = 0;
@@ -635,28 +651,36 @@ constexpr int KT_CAP = 128;
 
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                        unsigned long long* stats) {
-  __shared__ float gbl[6 * GB_BATCH];
-  __shared__ unsigned long long lst[KT_CAP];
-  __shared__ int nbr[64 * KNN_NC];  // [query][slot]
+  // dynamic LDS: lst[KT_CAP] u64 | nbr[64][k] int | gbl[6 * min(ngroups, GB_BATCH)] float
+  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
+  unsigned long long* lst = knn_smem;
+  int* nbr = (int*)(lst + KT_CAP);
+  float* gbl = (float*)(nbr + 64 * k);
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
   const int base = blockIdx.x * 64;
   if (base >= n) return;
-  const float inf = __builtin_inff();
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
   unsigned n_groups = 0, n_compact = 0, n_cand = 0;
 
   const int nq = min(64, n - base);
+  // the sorted neighbourhood of the NEXT query is fetched while the current one is processed
+  float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+  int wp = 0;
+  {
+    const int jw = min(max(base - 32, 0), max(n - 64, 0)) + lane;
+    if (jw < n) wt = c.pts[jw], wp = c.perm[jw];
+  }
   for (int qi = 0; qi < nq; qi++) {
     const int qidx = base + qi;
     const float4 q = c.pts[qidx];
     // ---- 1. bound from the 64 sorted neighbours
-    int w0 = min(max(qidx - 32, 0), max(n - 64, 0));
-    const int jw = w0 + lane;
+    const int jw = min(max(qidx - 32, 0), max(n - 64, 0)) + lane;
     unsigned long long key = ~0ull;
-    if (jw < n) {
-      const float4 t = c.pts[jw];
-      key = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[jw]);
+    if (jw < n) key = dist_key(sqdist1(wt.x, wt.y, wt.z, q.x, q.y, q.z), wp);
+    if (qi + 1 < nq) {
+      const int jn = min(max(qidx + 1 - 32, 0), max(n - 64, 0)) + lane;
+      if (jn < n) wt = c.pts[jn], wp = c.perm[jn];
     }
     key = wave_sort_u64(key, lane);
     unsigned long long tau_key;
@@ -679,17 +703,29 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
         const bool pass = gl < nb && lb_point_box(lds_box(gbl, gl < nb ? gl : 0), q.x, q.y, q.z) <= tau_d;
         unsigned long long gmask = __ballot(pass);
         while (gmask) {
-          const int g = gb0 + g0 + __builtin_ctzll(gmask);
+          // two groups (4 x 64 candidates) per trip so that their loads are in flight together
+          const int ga = gb0 + g0 + __builtin_ctzll(gmask);
           gmask &= gmask - 1;
-          n_groups++;
+          int gbq = -1;
+          if (gmask) {
+            gbq = gb0 + g0 + __builtin_ctzll(gmask);
+            gmask &= gmask - 1;
+          }
+          n_groups += gbq >= 0 ? 2 : 1;
+          unsigned long long cks[4];
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int j = g * kGroupPts + h * 64 + lane;
-            unsigned long long ck = ~0ull;
-            if (j < n) {
+          for (int h = 0; h < 4; h++) {
+            const int g = h < 2 ? ga : gbq;
+            const int j = g * kGroupPts + (h & 1) * 64 + lane;
+            cks[h] = ~0ull;
+            if (g >= 0 && j < n) {
               const float4 t = c.pts[j];
-              ck = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[j]);
+              cks[h] = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[j]);
             }
+          }
+#pragma unroll
+          for (int h = 0; h < 4; h++) {
+            const unsigned long long ck = cks[h];
             const bool in = ck <= tau_key;
             const unsigned long long m = __ballot(in);
             const int add = __popcll(m);
@@ -748,7 +784,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
     }
     if (lane < k) {
       if (mine == ~0ull) atomicExch(err_flag, 2);  // fewer than k candidates: impossible for n >= k
-      nbr[qi * KNN_NC + lane] = (int)(unsigned)mine;
+      nbr[qi * k + lane] = (int)(unsigned)mine;
     }
     __syncthreads();
   }
@@ -763,7 +799,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
   const float4 q = c.pts[i];
   double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
   for (int r = 0; r < k; r++) {
-    const float4 p = c.opts[nbr[lane * KNN_NC + r]];
+    const float4 p = c.opts[nbr[lane * k + r]];
     const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
     s1x += x, s1y += y, s1z += z;
     sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
@@ -875,6 +911,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
       }
     }
     w.sqd[(size_t)pair * w.nstride + i] = m;
+    w.nnidx[(size_t)pair * w.nstride + i] = j;
     const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
     w.corr[(size_t)pair * w.nstride + i] = corr;
     if (corr >= 0) {
