@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libapdgicp_hip.so")
 SOURCES = ["apdgicp_hip.hip"]
 DEPS = ["apdgicp_hip.hip", "apd_engine.hpp", "apd_kernels.hpp", "apd_math.hpp", os.path.join("..", "..", "include", "apdgicp_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
+FLAGS = [*os.environ.get("APD_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
 def needs_build() -> bool:

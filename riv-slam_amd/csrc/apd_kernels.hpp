@@ -632,177 +632,225 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
+// k-th smallest (1-based) of the up-to-3 keys per lane (a key equal to ~0ull is "absent"), found by a
+// most-significant-bit-first radix select with ballots: no cross-lane data movement at all.
+// Bits [lo_bits, 32) of the low word are known to be zero (original indices are < 2^lo_bits).
+__device__ __forceinline__ unsigned long long wave_kth_smallest3(unsigned long long a, unsigned long long b, unsigned long long c, int kth,
+                                                                 int lo_bits) {
+  bool la = a != ~0ull, lb = b != ~0ull, lc = c != ~0ull;
+  unsigned long long prefix = 0;
+  for (int bit = 63; bit >= 0; bit--) {
+    if (bit < 32 && bit >= lo_bits) continue;
+    const bool za = ((a >> bit) & 1ull) == 0, zb = ((b >> bit) & 1ull) == 0, zc = ((c >> bit) & 1ull) == 0;
+    const int c0 = __popcll(__ballot(la && za)) + __popcll(__ballot(lb && zb)) + __popcll(__ballot(lc && zc));
+    if (kth <= c0) {
+      la = la && za, lb = lb && zb, lc = lc && zc;
+    } else {
+      kth -= c0;
+      la = la && !za, lb = lb && !zb, lc = lc && !zc;
+      prefix |= 1ull << bit;
+    }
+  }
+  return prefix;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+
 __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)orig; }
 
 // ----------------------------------------------------------------------------------------------
 // k_knn_cov_pruned: calculate_covariances (A:303-363) on Z-curve-sorted clouds; exact k-NN.
-// One wave owns 64 consecutive sorted queries and works through them ONE AT A TIME with the lanes
-// spread over the CANDIDATES (no divergence, coalesced loads, per-query pruning):
-//   1. tau_key = k-th smallest (distance, original index) key among the 64 sorted neighbours of the
-//      query (a wave bitonic sort): k distinct points lie within it, so it bounds the k-th neighbour;
-//   2. the group boxes (staged once per wave in LDS) are tested lane-parallel against tau; each
-//      surviving 128-point group is evaluated two candidates per lane, and the candidates with
-//      key <= tau_key are compacted into the query's LDS list with ballot/popcount;
-//   3. the list (normally < 64 keys) is sorted across the wave; the first k lanes hold the neighbours.
-// Neighbour indices are parked in LDS; after the 64 queries every lane finishes ITS query: gathers
-// the k points, accumulates the moments in fp64 relative to the query (exact differences),
-// cov = S2/k - m m^T (A:323-324), 3x3 Jacobi eigen-decomposition and the regularisation (A:326-357).
-constexpr int KT_CAP = 128;
+// One wave owns 64 consecutive sorted queries (spatial neighbours, so they need the same few
+// target groups) and alternates between two lane mappings:
+//   A  lane = query     : tau = k-th smallest of 32 strided class minima over the ~192 sorted
+//                         neighbours staged in LDS (k distinct points lie within tau, so it bounds the
+//                         k-th neighbour distance); then a 64-bit mask of the groups whose box is within tau
+//   B  lane = candidate : every group some query needs is loaded ONCE (2 candidates per lane,
+//                         coalesced); for each query that needs it (uniform loop, query broadcast by
+//                         readlane) the 128 keys (distance bits << 32 | original index) are compared
+//                         with the query's tau and the hits are compacted into its LDS list with
+//                         ballot/popcount -- no divergence.  A full list is tightened in place to its k
+//                         smallest keys (tau only decreases, nothing of the final answer is dropped).
+//   C  lane = query     : k rounds of min-extraction over the own list (u64 order == the reference's
+//                         (distance, index) order), gather of the k points, moments in fp64 relative
+//                         to the query (exact differences), cov = S2/k - m m^T (A:323-324), 3x3 Jacobi
+//                         eigen-decomposition and the regularisation (A:326-357).
+constexpr int KQ_CAP = 48, KQ_STRIDE = 49, KQ_WIN = 192;
+constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 * 4;
 
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                        unsigned long long* stats) {
-  // dynamic LDS: lst[KT_CAP] u64 | nbr[64][k] int | gbl[6 * min(ngroups, GB_BATCH)] float
-  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
-  unsigned long long* lst = knn_smem;
-  int* nbr = (int*)(lst + KT_CAP);
-  float* gbl = (float*)(nbr + 64 * k);
+  __shared__ unsigned long long lst[64 * KQ_STRIDE];  // [query][slot], padded row
+  __shared__ float4 wtile[KQ_WIN];                    // xyz + original index bits
+  __shared__ float gbl[6 * 64];
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
   const int base = blockIdx.x * 64;
   if (base >= n) return;
+  const float inf = __builtin_inff();
+  const int i = base + lane;
+  const bool valid = i < n;
+  const float4 q = c.pts[valid ? i : n - 1];
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
-  unsigned n_groups = 0, n_compact = 0, n_cand = 0;
+  unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
 
-  const int nq = min(64, n - base);
-  // the sorted neighbourhood of the NEXT query is fetched while the current one is processed
-  float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-  int wp = 0;
-  {
-    const int jw = min(max(base - 32, 0), max(n - 64, 0)) + lane;
-    if (jw < n) wt = c.pts[jw], wp = c.perm[jw];
+  // ---- A: bound from the sorted neighbourhood
+  const int w0 = min(max(base - (KQ_WIN - 64) / 2, 0), max(n - KQ_WIN, 0));
+  for (int e = lane; e < KQ_WIN; e += 64) {
+    const int j = w0 + e;
+    float4 t = make_float4(inf, inf, inf, 0.f);
+    if (j < n) t = c.pts[j];
+    wtile[e] = t;
   }
-  for (int qi = 0; qi < nq; qi++) {
-    const int qidx = base + qi;
-    const float4 q = c.pts[qidx];
-    // ---- 1. bound from the 64 sorted neighbours
-    const int jw = min(max(qidx - 32, 0), max(n - 64, 0)) + lane;
-    unsigned long long key = ~0ull;
-    if (jw < n) key = dist_key(sqdist1(wt.x, wt.y, wt.z, q.x, q.y, q.z), wp);
-    if (qi + 1 < nq) {
-      const int jn = min(max(qidx + 1 - 32, 0), max(n - 64, 0)) + lane;
-      if (jn < n) wt = c.pts[jn], wp = c.perm[jn];
+  int cnt = 0;  // entries in this lane's (= query's) list
+  int idx_bits = 1;
+  while ((1 << idx_bits) < n) idx_bits++;
+  __syncthreads();
+  float cm[KNN_NC];
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
+  for (int e0 = 0; e0 < KQ_WIN; e0 += KNN_NC) {
+#pragma unroll
+    for (int s = 0; s < KNN_NC; s++) {
+      const float4 t = wtile[e0 + s];
+      cm[s] = fminf(cm[s], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
     }
-    key = wave_sort_u64(key, lane);
-    unsigned long long tau_key;
+  }
+#pragma unroll
+  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int a = 0; a < KNN_NC; a++) {
+        const int l = a ^ j;
+        if (l > a) {
+          const bool up = (a & kk) == 0;
+          const float x = cm[a], y = cm[l];
+          const float lo = fminf(x, y), hi = fmaxf(x, y);
+          cm[a] = up ? lo : hi;
+          cm[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+  float tau_d = inf;
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++)
+    if (s == k - 1) tau_d = cm[s];
+  if (!valid) tau_d = -1.f;
+  unsigned tau_hi = __float_as_uint(tau_d), tau_lo = 0xFFFFFFFFu;  // tau key = (tau_hi << 32) | tau_lo
+
+  // ---- B
+  for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {
+    const int nb = min(64, ngroups - gb0);
+    __syncthreads();
+    for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
+    __syncthreads();
+    unsigned long long gneed = 0;
     {
-      const unsigned lo = __shfl((unsigned)key, k - 1, 64), hi = __shfl((unsigned)(key >> 32), k - 1, 64);
-      tau_key = ((unsigned long long)hi << 32) | lo;
+      const float td = __uint_as_float(tau_hi);
+      for (int g = 0; g < nb; g++)
+        if (lb_point_box(lds_box(gbl, g), q.x, q.y, q.z) <= td) gneed |= 1ull << g;
+      if (!valid) gneed = 0;
     }
-    float tau_d = __uint_as_float((unsigned)(tau_key >> 32));
-    // ---- 2. candidates
-    int cnt = 0;
-    for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
-      const int nb = min(GB_BATCH, ngroups - gb0);
-      if (ngroups > GB_BATCH || qi == 0) {  // group boxes: staged once per wave when they all fit
-        __syncthreads();
-        for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
-        __syncthreads();
-      }
-      for (int g0 = 0; g0 < nb; g0 += 64) {
-        const int gl = g0 + lane;
-        const bool pass = gl < nb && lb_point_box(lds_box(gbl, gl < nb ? gl : 0), q.x, q.y, q.z) <= tau_d;
-        unsigned long long gmask = __ballot(pass);
-        while (gmask) {
-          // two groups (4 x 64 candidates) per trip so that their loads are in flight together
-          const int ga = gb0 + g0 + __builtin_ctzll(gmask);
-          gmask &= gmask - 1;
-          int gbq = -1;
-          if (gmask) {
-            gbq = gb0 + g0 + __builtin_ctzll(gmask);
-            gmask &= gmask - 1;
-          }
-          n_groups += gbq >= 0 ? 2 : 1;
-          unsigned long long cks[4];
-#pragma unroll
-          for (int h = 0; h < 4; h++) {
-            const int g = h < 2 ? ga : gbq;
-            const int j = g * kGroupPts + (h & 1) * 64 + lane;
-            cks[h] = ~0ull;
-            if (g >= 0 && j < n) {
-              const float4 t = c.pts[j];
-              cks[h] = dist_key(sqdist1(t.x, t.y, t.z, q.x, q.y, q.z), c.perm[j]);
+    for (int g = 0; g < nb; g++) {
+      unsigned long long qm = __ballot((gneed >> g) & 1ull);
+      if (!qm) continue;
+      n_groups++;
+      const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
+      float4 c0 = make_float4(inf, inf, inf, 0.f), c1 = c0;
+      unsigned o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
+      if (j0 < n) c0 = c.pts[j0], o0 = (unsigned)c.perm[j0];
+      if (j1 < n) c1 = c.pts[j1], o1 = (unsigned)c.perm[j1];
+      while (qm) {
+        const int qq = __builtin_ctzll(qm);
+        qm &= qm - 1;
+        n_pairs++;
+        // broadcast of query qq through SGPRs (v_readlane), no LDS traffic
+        const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
+        unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
+        const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
+        const unsigned long long k1 = ((unsigned long long)__float_as_uint(sqdist1(c1.x, c1.y, c1.z, qx, qy, qz)) << 32) | o1;
+        unsigned long long* row = lst + qq * KQ_STRIDE;
+        int cntq = __builtin_amdgcn_readlane(cnt, qq);
+        unsigned long long m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
+        if (cntq + __popcll(m0) + __popcll(m1) > KQ_CAP) {
+          // List full: tau becomes the k-th smallest key of (stored keys U this group's hits); only
+          // keys <= tau survive.  tau only decreases, so nothing of the final answer is ever dropped,
+          // and exactly k keys remain afterwards (keys are unique), which always fits.
+          const unsigned long long mine = lane < cntq ? row[lane] : ~0ull;  // KQ_CAP <= 64: one entry per lane
+          const unsigned long long h0 = k0 <= tk ? k0 : ~0ull, h1 = k1 <= tk ? k1 : ~0ull;
+#ifdef APD_KNN_ROUNDS
+          {
+            unsigned long long last = 0;
+            bool first = true;
+            for (int r = 0; r < k; r++) {
+              unsigned long long cand = ~0ull;
+              if ((first || mine > last) && mine < cand) cand = mine;
+              if ((first || h0 > last) && h0 < cand) cand = h0;
+              if ((first || h1 > last) && h1 < cand) cand = h1;
+              last = wave_min_u64(cand), first = false;
             }
+            tk = last < tk ? last : tk;
           }
-#pragma unroll
-          for (int h = 0; h < 4; h++) {
-            const unsigned long long ck = cks[h];
-            const bool in = ck <= tau_key;
-            const unsigned long long m = __ballot(in);
-            const int add = __popcll(m);
-            if (cnt + add > KT_CAP) {
-              // list full: tighten tau to the k-th smallest stored key and keep only the keys <= tau
-              // (tau only decreases, so nothing that belongs to the final answer is ever dropped)
-              unsigned long long last = 0;
-              bool first = true;
-              for (int r = 0; r < k; r++) {
-                unsigned long long bk = ~0ull;
-                for (int e = lane; e < cnt; e += 64) {
-                  const unsigned long long x = lst[e];
-                  if ((first || x > last) && x < bk) bk = x;
-                }
-                last = wave_min_u64(bk), first = false;
-              }
-              tau_key = last;
-              tau_d = __uint_as_float((unsigned)(tau_key >> 32));
-              const unsigned long long e0 = lane < cnt ? lst[lane] : ~0ull, e1 = lane + 64 < cnt ? lst[lane + 64] : ~0ull;
-              __syncthreads();
-              const unsigned long long m0 = __ballot(e0 <= tau_key), m1 = __ballot(e1 <= tau_key);
-              const unsigned long long below = (1ull << lane) - 1ull;
-              if (e0 <= tau_key) lst[__popcll(m0 & below)] = e0;
-              if (e1 <= tau_key) lst[__popcll(m0) + __popcll(m1 & below)] = e1;
-              cnt = __popcll(m0) + __popcll(m1);
-              __syncthreads();
-              n_compact++;
-            }
-            const bool in2 = ck <= tau_key;
-            const unsigned long long m2 = __ballot(in2);
-            if (in2) lst[cnt + __popcll(m2 & ((1ull << lane) - 1ull))] = ck;
-            cnt += __popcll(m2);
-          }
+#else
+          tk = wave_kth_smallest3(mine, h0, h1, k, idx_bits);
+#endif
+          const unsigned long long keep = __ballot(mine <= tk);
+          if (mine <= tk) row[__popcll(keep & ((1ull << lane) - 1ull))] = mine;
+          cntq = __popcll(keep);
+          if (lane == qq) tau_hi = (unsigned)(tk >> 32), tau_lo = (unsigned)tk;
+          m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
+          n_compact++;
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int total = cntq + __popcll(m0) + __popcll(m1);
+        if (total > KQ_CAP) {  // impossible by construction (total == k after a tightening); never silently wrong
+          if (lane == 0) atomicExch(err_flag, 4);
+        } else {
+          if (k0 <= tk) row[cntq + __popcll(m0 & below)] = k0;
+          if (k1 <= tk) row[cntq + __popcll(m0) + __popcll(m1 & below)] = k1;
+          if (lane == qq) cnt = total;
         }
       }
     }
-    __syncthreads();
-    n_cand += cnt;
-    // ---- 3. the k smallest keys -> lanes 0..k-1
-    unsigned long long mine;
-    if (cnt <= 64) {
-      mine = wave_sort_u64(lane < cnt ? lst[lane] : ~0ull, lane);
-    } else {
-      unsigned long long last = 0;
-      bool first = true;
-      mine = ~0ull;
-      for (int r = 0; r < k; r++) {
-        unsigned long long bk = ~0ull;
-        for (int e = lane; e < cnt; e += 64) {
-          const unsigned long long x = lst[e];
-          if ((first || x > last) && x < bk) bk = x;
-        }
-        last = wave_min_u64(bk), first = false;
-        if (lane == r) mine = last;
-      }
-    }
-    if (lane < k) {
-      if (mine == ~0ull) atomicExch(err_flag, 2);  // fewer than k candidates: impossible for n >= k
-      nbr[qi * k + lane] = (int)(unsigned)mine;
-    }
-    __syncthreads();
   }
+  __syncthreads();
   if (stats && lane == 0) {
     atomicAdd(stats + 4, (unsigned long long)n_groups), atomicAdd(stats + 7, 1ull);
-    atomicAdd(stats + 8, (unsigned long long)n_compact), atomicAdd(stats + 9, (unsigned long long)n_cand);
+    atomicAdd(stats + 8, (unsigned long long)n_compact), atomicAdd(stats + 9, (unsigned long long)n_pairs);
   }
+  if (!valid) return;
 
-  // ---- every lane finishes its own query
-  const int i = base + lane;
-  if (i >= n) return;
-  const float4 q = c.pts[i];
+  // ---- C
+  const unsigned long long* row = lst + lane * KQ_STRIDE;
   double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-  for (int r = 0; r < k; r++) {
-    const float4 p = c.opts[nbr[lane * k + r]];
-    const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
-    s1x += x, s1y += y, s1z += z;
-    sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+  {
+    unsigned long long last = 0;
+    bool first = true;
+    float4 pend = q;  // software pipeline: the gather of round r is consumed in round r+1
+    bool have = false;
+    for (int r = 0; r <= k; r++) {
+      unsigned long long bk = ~0ull;
+      if (r < k) {
+        for (int a = 0; a < cnt; a++) {
+          const unsigned long long x = row[a];
+          if ((first || x > last) && x < bk) bk = x;
+        }
+        if (bk == ~0ull) {
+          atomicExch(err_flag, 2);
+          break;
+        }
+        last = bk, first = false;
+      }
+      const float4 nxt = r < k ? c.opts[(unsigned)bk] : q;
+      if (have) {
+        const double x = (double)pend.x - (double)q.x, y = (double)pend.y - (double)q.y, z = (double)pend.z - (double)q.z;
+        s1x += x, s1y += y, s1z += z;
+        sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+      }
+      pend = nxt, have = true;
+    }
   }
   const double ik = 1.0 / (double)k;
   const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;

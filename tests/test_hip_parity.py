@@ -400,3 +400,81 @@ def test_batch_is_deterministic(reg, scene):
     r1 = b.align([(i0, i1)] * 7, [gs] * 7)
     r2 = b.align([(i0, i1)] * 7, [gs] * 7)
     assert np.array_equal(r1["T"], r2["T"]) and np.all(r1["T"] == r1["T"][0])
+
+
+# ------------------------------------------------------------------ exact pruning == brute force
+def _fresh(reg, mode, **kw):
+    """a handle whose engine was created with the given NN/kNN mode (read from the environment at creation)"""
+    import os
+    old = {k: os.environ.get(k) for k in ("APDGICP_NN_MODE", "APDGICP_KNN_MODE")}
+    os.environ["APDGICP_NN_MODE"] = os.environ["APDGICP_KNN_MODE"] = mode
+    try:
+        return reg.FastAPDGICP(reg.default_params(**kw))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_pruned_search_is_bitwise_the_brute_force_search(reg, scene):
+    """The Z-curve/bounding-box pruning only skips work: covariances, correspondences, distances, H, b and
+    the final pose must be IDENTICAL to the LDS-tiled brute-force kernels (north_star's formulation)."""
+    for idx, (n, m, kind) in enumerate(((2048, 2048, "odometry"), (3000, 5000, "loop"), (8192, 8192, "odometry"))):
+        src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(6, idx), kind)
+        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+        a, b = _fresh(reg, "pruned", **kw), _fresh(reg, "brute", **kw)
+        for h in (a, b):
+            h.setInputSource(src)
+            h.setInputTarget(tgt)
+        assert np.array_equal(a.getSourceCovariances(), b.getSourceCovariances())
+        assert np.array_equal(a.getTargetCovariances(), b.getTargetCovariances())
+        for T in (np.eye(4), guess.astype(np.float64)):
+            ra, rb = a.linearize(T), b.linearize(T)
+            ca, sa = a.correspondences()
+            cb, sb = b.correspondences()
+            assert np.array_equal(ca, cb) and np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+        Ta, Tb = a.align(guess), b.align(guess)
+        assert np.array_equal(Ta, Tb) and info_of(a) == info_of(b)
+
+
+def test_exact_ties_resolve_to_the_lowest_original_index(reg):
+    """A source point exactly midway between two target points (equal fp32 distances, far apart on the
+    Z-curve) and duplicated target points: the oracle's rule is (distance, index) lexicographic."""
+    rng = np.random.default_rng(11)
+    filler = rng.uniform(-40, 40, size=(3000, 3)).astype(np.float32) + np.float32(100.0)
+    pairs_l = np.stack([np.full(64, -1.0), np.arange(64) * 2.0, np.zeros(64)], axis=1).astype(np.float32)
+    pairs_r = pairs_l * np.array([-1, 1, 1], dtype=np.float32)
+    tgt = np.concatenate([filler[:1500], pairs_r, filler[1500:], pairs_l, pairs_r[:16]])  # right copies come first; 16 exact duplicates last
+    src = np.concatenate([np.stack([np.zeros(64), np.arange(64) * 2.0, np.zeros(64)], axis=1).astype(np.float32), filler[:500] + np.float32(0.25)])
+    o = R.RefAPDGICP(R.default_params(max_correspondence_distance=3.0))
+    o.setInputSource(src)
+    o.setInputTarget(tgt)
+    o.linearize(np.eye(4))
+    co, so = o.correspondences()
+    assert np.array_equal(co[:64], 1500 + np.arange(64))      # lowest index among the tied targets
+    for mode in ("pruned", "brute"):
+        g = _fresh(reg, mode, max_correspondence_distance=3.0)
+        g.setInputSource(src)
+        g.setInputTarget(tgt)
+        g.linearize(np.eye(4))
+        cg, sg = g.correspondences()
+        assert np.array_equal(cg, co), mode
+        assert np.array_equal(sg.view(np.uint32), so.view(np.uint32)), mode
+        assert np.abs(g.getTargetCovariances()[:, :3, :3] - o.covariances("target")).max() <= 1e-10, mode
+
+
+def test_large_cloud_generic_sort_path(reg, scene):
+    """> 16384 points: the clouds are sorted by the global-memory bitonic path instead of the LDS one."""
+    src, tgt, _, guess = scene.make_pair(20000, 24000, scene.pair_seed(6, 9), "odometry")
+    kw = dict(max_correspondence_distance=2.0, azimuth_variance_deg=1.0, max_iterations=3)
+    g, o = both(reg, src, tgt, **kw)
+    c1, H1, b1 = g.linearize(guess.astype(np.float64))
+    c2, H2, b2 = o.linearize(guess.astype(np.float64))
+    cg, sg = g.correspondences()
+    co, so = o.correspondences()
+    assert np.array_equal(cg, co) and np.array_equal(sg.view(np.uint32), so.view(np.uint32))
+    assert rel_err(H1, H2) < 5e-6 and rel_err(b1, b2) < 5e-6
+    assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10

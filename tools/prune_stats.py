@@ -13,4 +13,4 @@ for p in range(P):
 r = b.align([(2*i,2*i+1) for i in range(P)], g)
 st = b.debug_stats()
 print("NN: groups/wave %.1f chunks tested/wave %.1f scanned/wave %.1f waves %d (per launch: 20 launches)" % (st[0]/st[3], st[1]/st[3], st[2]/st[3], st[3]))
-print("KNN: groups/query %.2f waves %d compactions/wave %.3f cand/query %.1f" % (st[4]/st[7]/64, st[7], st[8]/st[7], st[9]/st[7]/64))
+print("KNN: groups loaded/wave %.1f  (query,group) pairs/wave %.1f  compactions/wave %.2f  waves %d" % (st[4]/st[7], st[9]/st[7], st[8]/st[7], st[7]))
