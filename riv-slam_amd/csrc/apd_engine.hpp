@@ -72,6 +72,24 @@ inline int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
+// A small host->device table that is re-uploaded only when its contents change.  The host copy lives
+// in the object, so the asynchronous copy never reads a dead local; a changed table is uploaded after
+// a stream synchronisation (kernels still queued may be reading the old one).
+struct CachedTable {
+  DevBuf dev;
+  std::vector<char> host;
+  int upload(const void* data, size_t bytes, hipStream_t stream) {
+    if (dev.p && host.size() == bytes && (bytes == 0 || memcmp(host.data(), data, bytes) == 0)) return 0;
+    APD_HIP(hipStreamSynchronize(stream));
+    host.assign((const char*)data, (const char*)data + bytes);
+    APD_TRY(dev.ensure(std::max<size_t>(bytes, 16)));
+    if (bytes) APD_HIP(hipMemcpyAsync(dev.p, host.data(), bytes, hipMemcpyHostToDevice, stream));
+    return 0;
+  }
+  template <typename T>
+  T* as() const { return (T*)dev.p; }
+};
+
 class Engine {
  public:
   struct Cloud {
@@ -95,8 +113,10 @@ class Engine {
   // batch state
   int npairs = 0, nmax_src = 0;
   std::vector<PairDesc> h_pairs;
-  DevBuf d_desc, d_pairs, d_state, d_results, d_status, d_guess, d_ids, d_errflag, d_probe, d_stage, d_T;
-  DevBuf d_jobs, d_keys, d_box6, d_stats;
+  std::vector<float> h_guesses;
+  DevBuf d_state, d_results, d_status, d_errflag, d_probe, d_stage, d_T;
+  DevBuf d_keys, d_box6, d_stats;
+  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs;
   DevBuf b_nnpart, b_corr, b_nnidx, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
@@ -126,7 +146,7 @@ class Engine {
       APD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       own_stream = true;
     }
-    APD_HIP(hipHostMalloc((void**)&h_status, 65536 * sizeof(int), hipHostMallocDefault));
+    APD_HIP(hipHostMalloc((void**)&h_status, 65540 * sizeof(int), hipHostMallocDefault));
     APD_HIP(hipHostMalloc((void**)&h_probe, 64 * sizeof(double), hipHostMallocDefault));
     APD_HIP(hipEventCreateWithFlags(&ev_poll, hipEventDisableTiming));
     APD_TRY(d_errflag.ensure(sizeof(int)));
@@ -149,7 +169,8 @@ class Engine {
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
-    for (DevBuf* b : {&d_desc, &d_pairs, &d_state, &d_results, &d_status, &d_guess, &d_ids, &d_errflag, &d_probe, &d_stage, &d_T, &d_jobs,
+    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs}) t->dev.release();
+    for (DevBuf* b : {&d_state, &d_results, &d_status, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_nnpart, &b_corr, &b_nnidx, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
@@ -235,7 +256,7 @@ class Engine {
       grew |= (size_t)ns[q] * 16 > clouds[first + q].opts.cap;
       nmax = std::max<int>(nmax, (int)ns[q]);
     }
-    APD_HIP(hipStreamSynchronize(stream));  // d_jobs reuse (and buffer growth)
+    if (grew) APD_HIP(hipStreamSynchronize(stream));  // a buffer about to be re-allocated may still be in use
     std::vector<PackJob> jobs(count);
     for (int q = 0; q < count; q++) {
       Cloud& c = clouds[first + q];
@@ -246,12 +267,11 @@ class Engine {
       c.cov_valid = false;
       c.token = 0;
     }
-    (void)grew;
-    APD_TRY(d_jobs.ensure(std::max(jobs.size() * sizeof(PackJob), (size_t)count * sizeof(SortJob))));
-    APD_HIP(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_pack_points_multi, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, stream, d_jobs.as<PackJob>());
+    APD_TRY(d_packjobs.upload(jobs.data(), jobs.size() * sizeof(PackJob), stream));
+    hipLaunchKernelGGL(k_pack_points_multi, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, stream, d_packjobs.as<PackJob>());
     APD_HIP(hipGetLastError());
-    APD_HIP(hipStreamSynchronize(stream));  // `jobs` is a local; the caller's buffers are free again
+    // device-resident inputs: the caller's buffers are free again once the stream has passed this point
+    // (apdgicp_batch_synchronize), no host-side wait here
     desc_dirty = true;
     return 0;
   }
@@ -302,17 +322,14 @@ class Engine {
       desc_dirty = true;
     }
     if (!small.empty()) {
-      APD_HIP(hipStreamSynchronize(stream));  // d_jobs reuse
-      APD_TRY(d_jobs.ensure(small.size() * sizeof(SortJob)));
-      APD_HIP(hipMemcpyAsync(d_jobs.p, small.data(), small.size() * sizeof(SortJob), hipMemcpyHostToDevice, stream));
+      APD_TRY(d_sortjobs.upload(small.data(), small.size() * sizeof(SortJob), stream));
       static bool attr_set = false;
       if (!attr_set) {
         APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
         attr_set = true;
       }
-      hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_jobs.as<SortJob>());
+      hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_sortjobs.as<SortJob>());
       APD_HIP(hipGetLastError());
-      APD_HIP(hipStreamSynchronize(stream));  // `small` is a local
     }
     for (int id : large) {  // generic path: keys in global memory, one launch per bitonic stage
       Cloud& c = clouds[id];
@@ -356,10 +373,7 @@ class Engine {
       h[i].n = clouds[i].n;
       h[i].pad_ = 0;
     }
-    APD_HIP(hipStreamSynchronize(stream));
-    APD_TRY(d_desc.ensure(std::max<size_t>(1, h.size()) * sizeof(CloudDesc)));
-    APD_HIP(hipMemcpyAsync(d_desc.p, h.data(), h.size() * sizeof(CloudDesc), hipMemcpyHostToDevice, stream));
-    APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(d_desc.upload(h.data(), h.size() * sizeof(CloudDesc), stream));
     desc_dirty = false;
     return 0;
   }
@@ -382,6 +396,7 @@ class Engine {
   }
 
   // calculate_covariances for every listed cloud that lacks them (A:122-127, A:303-363)
+  bool defer_errflag = false;  // set by the align paths: the flag is then read together with the final status
   int compute_covariances(const std::vector<int>& ids_in, bool force = false) {
     std::vector<int> ids;
     int nmax = 0;
@@ -396,9 +411,7 @@ class Engine {
     if (ids.empty()) return 0;
     APD_HIP(hipSetDevice(device));
     APD_TRY(upload_desc());
-    APD_HIP(hipStreamSynchronize(stream));
-    APD_TRY(d_ids.ensure(ids.size() * sizeof(int)));
-    APD_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), stream));
     if (knn_pruned) {
       const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)ids.size());
       hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
@@ -414,7 +427,7 @@ class Engine {
                          params.regularization, d_errflag.as<int>());
     }
     APD_HIP(hipGetLastError());
-    APD_TRY(check_errflag("k_knn_cov"));
+    if (!defer_errflag) APD_TRY(check_errflag("k_knn_cov"));
     for (int id : ids) clouds[id].cov_valid = true;
     return 0;
   }
@@ -424,7 +437,8 @@ class Engine {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
     h_pairs.resize(n);
-    std::vector<float> guesses((size_t)n * 16);
+    std::vector<float>& guesses = h_guesses;
+    guesses.resize((size_t)n * 16);
     std::vector<int> need;
     nmax_src = 0;
     for (int64_t i = 0; i < n; i++) {
@@ -436,18 +450,19 @@ class Engine {
       need.push_back(s), need.push_back(t);
       nmax_src = std::max(nmax_src, clouds[s].n);
     }
-    APD_TRY(compute_covariances(need));
+    defer_errflag = true;
+    const int rc_cov = compute_covariances(need);
+    defer_errflag = false;
+    APD_TRY(rc_cov);
     APD_TRY(upload_desc());
     npairs = (int)n;
-    APD_HIP(hipStreamSynchronize(stream));
-    APD_TRY(d_pairs.ensure(n * sizeof(PairDesc)));
+    if ((size_t)n * sizeof(PairState) > d_state.cap) APD_HIP(hipStreamSynchronize(stream));
     APD_TRY(d_state.ensure(n * sizeof(PairState)));
     APD_TRY(d_results.ensure(n * sizeof(ResultRec)));
-    APD_TRY(d_status.ensure(n * sizeof(int)));
-    APD_TRY(d_guess.ensure(n * 16 * sizeof(float)));
-    APD_HIP(hipMemcpyAsync(d_pairs.p, h_pairs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
-    if (with_guess) APD_HIP(hipMemcpyAsync(d_guess.p, guesses.data(), guesses.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    APD_HIP(hipStreamSynchronize(stream));  // `guesses` is a local
+    APD_TRY(d_status.ensure((n + 1) * sizeof(int)));
+    APD_TRY(d_pairs.upload(h_pairs.data(), n * sizeof(PairDesc), stream));
+    (void)with_guess;
+    APD_TRY(d_guess.upload(guesses.data(), guesses.size() * sizeof(float), stream));
 
     // launch shape of the NN kernel: S sources per lane, T target splits (tunable for experiments)
     const int nchunks_min = 1;
@@ -567,7 +582,9 @@ class Engine {
                        params.max_iterations);
     const bool lm = params.optimizer == APDGICP_OPT_LM;
     const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
-    const int chunk = std::max(1, env_int("APDGICP_POLL_TICKS", lm ? 4 : 8));
+    // LM: the loop length is data dependent, poll every few ticks.  GN runs max_iterations ticks unless a
+    // pair hits an exactly-zero step, so one poll at the end is enough.
+    const int chunk = std::max(1, env_int("APDGICP_POLL_TICKS", lm ? 4 : std::min(64, std::max(1, params.max_iterations))));
     long long ticks = 0;
     bool all_done = params.max_iterations <= 0;
     while (!all_done && ticks < tick_cap) {
@@ -575,13 +592,20 @@ class Engine {
       const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
       for (int t = 0; t < todo; t++) APD_TRY(launch_tick());
       ticks += todo;
-      hipLaunchKernelGGL(k_copy_status, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_state.as<PairState>(), d_status.as<int>(), npairs);
-      APD_HIP(hipMemcpyAsync(h_status, d_status.p, npairs * sizeof(int), hipMemcpyDeviceToHost, stream));
+      hipLaunchKernelGGL(k_copy_status, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_state.as<PairState>(), d_status.as<int>(), npairs,
+                         d_errflag.as<int>());
+      APD_HIP(hipMemcpyAsync(h_status, d_status.p, (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
       APD_HIP(hipEventRecord(ev_poll, stream));
       APD_HIP(hipEventSynchronize(ev_poll));
       all_done = true;
       for (int p = 0; p < npairs; p++) all_done &= (h_status[p] == ST_DONE);
+      if (h_status[npairs]) {
+        const int flag = h_status[npairs];
+        APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+        if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, "device error flag " + std::to_string(flag) + " (covariance k-NN)");
+      }
     }
+    if (params.max_iterations <= 0) APD_TRY(check_errflag("k_knn_cov"));
     last_ticks = (int)ticks;
     hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), (int*)nullptr,
                        npairs);

@@ -1286,9 +1286,10 @@ __global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out,
   if (status_out) status_out[p] = s.status;
 }
 
-__global__ void k_copy_status(const PairState* st, int* status_out, int npairs) {
+__global__ void k_copy_status(const PairState* st, int* status_out, int npairs, const int* err_flag) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < npairs) status_out[p] = st[p].status;
+  if (p == 0) status_out[npairs] = *err_flag;  // the device error flag rides along with the poll
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}

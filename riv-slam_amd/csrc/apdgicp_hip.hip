@@ -284,8 +284,7 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
     float g[16];
     if (guess) memcpy(g, guess, sizeof(g));
     else identity16(g);
-    APD_HIP(hipMemcpyAsync(e.d_guess.p, g, sizeof(g), hipMemcpyHostToDevice, e.stream));
-    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_guess.upload(g, sizeof(g), e.stream));
     APD_TRY(e.run_align());
     APD_HIP(hipMemcpyAsync(out, e.d_results.p, sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
