@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank (self-test of the N>1 path)")
     args = ap.parse_args()
 
     import torch
@@ -60,9 +61,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     ge.build()
@@ -101,7 +105,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +121,7 @@ def main():
         nn_launches += k
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -245,7 +249,7 @@ def main():
                 out["parity"] = {"pairs_checked": done, "max_t_err_m": worst_t, "max_r_err_rad": worst_r, "tolerance": "1e-3 m / 1e-4 rad"}
                 assert worst_t <= 1e-3 and worst_r <= 1e-4, (worst_t, worst_r)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -44,7 +44,7 @@ class ShardedBatchAligner:
         b, e = parts[self.rank]
         per = parts[0][1] - parts[0][0]
         local = self.engine.align_block(list(range(b, e)))
-        if self.world == 1:
+        if self.world == 1 and not self.dist.is_initialized():
             return local
         # fixed-size contribution per rank (pad the short tail block) -> one all_gather_into_tensor
         pad = torch.zeros((per, RESULT_BYTES), dtype=torch.uint8, device=local.device)

@@ -478,3 +478,22 @@ def test_large_cloud_generic_sort_path(reg, scene):
     assert np.array_equal(cg, co) and np.array_equal(sg.view(np.uint32), so.view(np.uint32))
     assert rel_err(H1, H2) < 5e-6 and rel_err(b1, b2) < 5e-6
     assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
+
+
+def test_c5_dense_submap_correspondences(reg, scene):
+    """BASELINE configs[4]: 100k-point source against a 500k-point accumulated map (generic sort path,
+    many group-box batches).  One linearize + 2 GN iterations against the CPU oracle."""
+    src, tgt, _, guess = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
+    kw = dict(optimizer=1, max_iterations=2, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
+              max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    g, o = both(reg, src, tgt, **kw)
+    c1, H1, b1 = g.linearize(guess.astype(np.float64))
+    c2, H2, b2 = o.linearize(guess.astype(np.float64))
+    cg, sg = g.correspondences()
+    co, so = o.correspondences()
+    assert np.array_equal(sg.view(np.uint32), so.view(np.uint32))
+    assert np.array_equal(cg, co)
+    assert rel_err(H1, H2) < 5e-6 and rel_err(b1, b2) < 5e-6 and abs(c1 - c2) < 5e-6 * c2
+    T, To = g.align(guess), o.align(guess)
+    te, re_ = scene.pose_error(To, T)
+    assert te <= T_TOL and re_ <= R_TOL
