@@ -413,9 +413,15 @@ class Engine {
     APD_TRY(upload_desc());
     APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), stream));
     if (knn_pruned) {
-      const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)ids.size());
-      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
-                         params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+      // queries per wave: 64 amortises the group loads best; fewer queries per wave shorten the per-wave
+      // dependency chain and shrink its LDS lists, which wins whenever the GPU is not already full
+      long long total = 0;
+      for (int id : ids) total += clouds[id].n;
+      int qpw = env_int("APDGICP_KNN_QPW", 0);
+      if (qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : 8;  // measured: r01 sweep
+      const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)ids.size());
+      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
+                         params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {
       static bool attr_set = false;
       if (!attr_set) {

@@ -677,24 +677,29 @@ __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { retu
 constexpr int KQ_CAP = 48, KQ_STRIDE = 49, KQ_WIN = 192;
 constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 * 4;
 
+// qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
+// smaller lists (more waves per CU); lanes >= qpw only help in the lane = candidate phase.
+__host__ __device__ constexpr int knn_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4; }
+
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
-                                                       unsigned long long* stats) {
-  __shared__ unsigned long long lst[64 * KQ_STRIDE];  // [query][slot], padded row
-  __shared__ float4 wtile[KQ_WIN];                    // xyz + original index bits
-  __shared__ float gbl[6 * 64];
+                                                       unsigned long long* stats, int qpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
+  unsigned long long* lst = knn_smem;                            // [query][slot], padded row
+  float4* wtile = (float4*)(lst + qpw * KQ_STRIDE);              // sorted neighbourhood
+  float* gbl = (float*)(wtile + KQ_WIN);                         // 64 group boxes
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
-  const int base = blockIdx.x * 64;
+  const int base = blockIdx.x * qpw;
   if (base >= n) return;
   const float inf = __builtin_inff();
   const int i = base + lane;
-  const bool valid = i < n;
+  const bool valid = lane < qpw && i < n;
   const float4 q = c.pts[valid ? i : n - 1];
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
   unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
 
   // ---- A: bound from the sorted neighbourhood
-  const int w0 = min(max(base - (KQ_WIN - 64) / 2, 0), max(n - KQ_WIN, 0));
+  const int w0 = min(max(base - (KQ_WIN - qpw) / 2, 0), max(n - KQ_WIN, 0));
   for (int e = lane; e < KQ_WIN; e += 64) {
     const int j = w0 + e;
     float4 t = make_float4(inf, inf, inf, 0.f);

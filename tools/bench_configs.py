@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json's other configs (not the driver's bench line):
+C2 single-pair latency, C3 one scan vs 8 keyframes, C5 100k x 500k ms per GN iteration; each with the
+pose error against the CPU oracle where the oracle finishes quickly.  Prints one JSON object."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa
+reg = importlib.import_module("riv-slam_amd.registration")
+scene = importlib.import_module("riv-slam_amd.scene")
+import ref as R  # noqa
+
+GN = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0,
+          azimuth_variance_deg=1.0)
+LM_LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+out = {}
+
+
+def timed(f, reps):
+    f()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps * 1e3
+
+
+# ---- C2: one 8k x 8k registration at a time (both clouds fresh / target cached), GN-20 and LM with the launch parameters
+s, t, _, g = scene.make_pair(8192, 8192, scene.pair_seed(2, 0), "odometry")
+ds, dt = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+for tag, kw in (("gn20", GN), ("lm_launch", LM_LAUNCH)):
+    h = reg.FastAPDGICP(reg.default_params(**kw))
+
+    def fresh():
+        h.setInputTarget(dt)
+        h.setInputSource(ds)
+        h.align(g)
+
+    def cached():
+        h.setInputTarget(dt, token=7)
+        h.setInputSource(ds)
+        h.align(g)
+    o = R.RefAPDGICP(R.default_params(**kw))
+    o.setInputSource(s), o.setInputTarget(t)
+    t0 = time.perf_counter()
+    To = o.align(g)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    ms_f, ms_c = timed(fresh, 10), timed(cached, 10)
+    te, re_ = scene.pose_error(To, h.getFinalTransformation())
+    out[f"C2_{tag}"] = {"ms_both_fresh": round(ms_f, 3), "ms_target_cached": round(ms_c, 3), "n_linearize": int(h.result.n_linearize),
+                        "cpu_oracle_ms": round(cpu_ms, 1), "cpu_threads": o.num_threads, "t_err_m": te, "r_err_rad": re_}
+
+# ---- C3: one scan against 8 keyframes, targets cached
+b = reg.BatchAPDGICP(reg.default_params(**LM_LAUNCH))
+src_i = b.add_cloud(ds)
+tg, gs = [], []
+for kf in range(8):
+    s2, t2, _, g2 = scene.make_pair(8192, 8192, scene.pair_seed(3, kf), "odometry")
+    tg.append(b.add_cloud(torch.from_numpy(t2).cuda()))
+    gs.append(g2)
+b.compute_covariances()
+pairs = b.make_pairs([(src_i, k) for k in tg], gs)
+
+
+def c3():
+    b.set_cloud(src_i, ds)       # a new scan: source covariances recomputed, keyframe covariances cached
+    b.align(pairs)
+ms = timed(c3, 10)
+out["C3_1x8"] = {"ms_per_batch": round(ms, 3), "registrations_per_s": round(8e3 / ms, 1)}
+
+# ---- C5: 100k x 500k
+s5, t5, _, g5 = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
+d5s, d5t = torch.from_numpy(s5).cuda(), torch.from_numpy(t5).cuda()
+h = reg.FastAPDGICP(reg.default_params(**GN))
+h.setInputTarget(d5t, token=5)
+h.setInputSource(d5s, token=6)
+t0 = time.perf_counter()
+h.align(g5)
+first = (time.perf_counter() - t0) * 1e3
+
+
+def c5():
+    h.align(g5)                 # covariances cached: 20 GN iterations only
+ms = timed(c5, 3)
+o = R.RefAPDGICP(R.default_params(**GN))
+o.setInputSource(s5), o.setInputTarget(t5)
+t0 = time.perf_counter()
+To = o.align(g5)
+cpu_ms = (time.perf_counter() - t0) * 1e3
+te, re_ = scene.pose_error(To, h.getFinalTransformation())
+out["C5_100k_x_500k"] = {"ms_first_align_incl_sort_and_covariances": round(first, 1), "ms_per_align_cached": round(ms, 2),
+                         "ms_per_gn_iter": round(ms / 20, 3), "cpu_oracle_ms_incl_covariances": round(cpu_ms, 1), "cpu_threads": o.num_threads,
+                         "t_err_m": te, "r_err_rad": re_}
+print(json.dumps(out, indent=1))
