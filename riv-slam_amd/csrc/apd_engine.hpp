@@ -122,6 +122,8 @@ class Engine {
   int nn_S = 2;
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
+  bool fuse_lm = false;    // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=1): measured neutral (r01)
+  DevBuf b_ticket;
   int* h_status = nullptr;   // pinned
   double* h_probe = nullptr; // pinned, 48 doubles
   hipEvent_t ev_poll = nullptr;
@@ -161,6 +163,7 @@ class Engine {
     nn_pruned = !(m && std::string(m) == "brute");
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
+    fuse_lm = env_int("APDGICP_FUSE", 0) != 0;
     return set_params(p);
   }
 
@@ -171,7 +174,7 @@ class Engine {
     for (auto& c : clouds) c.release_all();
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs}) t->dev.release();
     for (DevBuf* b : {&d_state, &d_results, &d_status, &d_errflag, &d_probe, &d_stage, &d_T,
-                      &d_keys, &d_box6, &d_stats, &b_nnpart, &b_corr, &b_nnidx, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnidx, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
@@ -505,6 +508,9 @@ class Engine {
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();
     work.stats = d_stats.as<unsigned long long>();
+    APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
+    APD_HIP(hipMemsetAsync(b_ticket.p, 0, (size_t)2 * npairs * sizeof(int), stream));
+    work.ticket = b_ticket.as<int>();
     return 0;
   }
 
@@ -537,16 +543,17 @@ class Engine {
     return 0;
   }
 
-  int launch_linearize(bool want_Hb) {
+  int launch_linearize(int mode /* 0 cost only, 1 H/b/cost, 2 + fused GN/LM step */) {
     const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
     hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
-                       consts(), want_Hb ? 1 : 0);
+                       consts(), mode);
     return 0;
   }
 
-  int launch_error() {
+  int launch_error(bool fuse) {
     const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
-    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work);
+    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                       consts(), fuse ? 1 : 0);
     return 0;
   }
 
@@ -554,12 +561,14 @@ class Engine {
   int launch_tick() {
     const Consts c = consts();
     APD_TRY(launch_nn());
-    APD_TRY(launch_linearize(true));
-    hipLaunchKernelGGL(k_lm_solve, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work, c);
+    APD_TRY(launch_linearize(fuse_lm ? 2 : 1));
+    if (!fuse_lm)
+      hipLaunchKernelGGL(k_lm_solve, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work, c);
     if (params.optimizer == APDGICP_OPT_LM) {
-      APD_TRY(launch_error());
-      hipLaunchKernelGGL(k_lm_decide, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
-                         c);
+      APD_TRY(launch_error(fuse_lm));
+      if (!fuse_lm)
+        hipLaunchKernelGGL(k_lm_decide, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+                           c);
     }
     return 0;
   }
@@ -629,7 +638,7 @@ class Engine {
     APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_LIN, 0);
     APD_TRY(launch_nn());
-    APD_TRY(launch_linearize(H && b));
+    APD_TRY(launch_linearize(H && b ? 1 : 0));
     hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
                        d_probe.as<double>(), 0);
     APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -647,7 +656,7 @@ class Engine {
     APD_HIP(hipSetDevice(device));
     APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_ERR, 1);
-    APD_TRY(launch_error());
+    APD_TRY(launch_error(false));
     hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
                        d_probe.as<double>(), 1);
     APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));

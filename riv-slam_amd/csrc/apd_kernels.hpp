@@ -81,6 +81,7 @@ struct Work {
   double* blkpart;             // [pair][nblk_max][kRed]
   double* errpart;             // [pair][nblk_max]
   int nstride, nblk_max, T;
+  int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
 };
 
@@ -895,7 +896,33 @@ __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][
 // 21+6+1 sums per block.  fp64 throughout after the NN, as in the reference.
 constexpr int LIN_BLK = 256;
 
-__global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w, Consts cst,
+__device__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid);
+__device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
+
+// Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  Every block
+// publishes its partials with an agent-scope release before taking the ticket, the last one acquires
+// before reading them (cdna_hip_programming.md G16: placement-independent, one fence pair per block).
+__device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int tid) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nblk - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next tick
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// want_Hb: 0 = cost only, 1 = H, b, cost, 2 = also run the GN/LM step (k_lm_solve's work) in the last block
+__global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
   const int pair = blockIdx.y;
@@ -981,7 +1008,9 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
       const double s_z = dist * cst.sin_el / cos_aoa;
       const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
       const double azimuth = (double)atan2f(pty, ptx);
-      const double ce = cos(elevation), se = sin(elevation), caz = cos(azimuth), saz = sin(azimuth);
+      double ce, se, caz, saz;
+      sincos(elevation, &se, &ce);
+      sincos(azimuth, &saz, &caz);
       // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
       const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
       const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
@@ -1050,12 +1079,16 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv * 29 + tid];
     w.blkpart[((size_t)pair * w.nblk_max + blockIdx.x) * kRed + tid] = s;
   }
+  if (want_Hb == 2) {
+    const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
+    if (last_block_of_pair(w.ticket + pair, nblk, tid)) lm_solve_body(st[pair], w, pair, nblk, cst, red, tid);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
 // k_error: compute_error (A:275-298) at the trial pose xi with the FROZEN correspondences and
 // Mahalanobis matrices of the last linearize.
-__global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+__global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst, int fuse) {
   __shared__ double red[LIN_BLK / 64];
   const int pair = blockIdx.y;
   if (st[pair].status != ST_NEED_ERR) return;
@@ -1086,6 +1119,10 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv];
     w.errpart[(size_t)pair * w.nblk_max + blockIdx.x] = s;
+  }
+  if (fuse) {
+    const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
+    if (last_block_of_pair(w.ticket + gridDim.y + pair, nblk, tid) && tid == 0) lm_decide_body(st[pair], w, pair, nblk, cst);
   }
 }
 
@@ -1141,14 +1178,9 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
   }
 }
 
-// after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error)
-__global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
-  __shared__ double lds[32];
-  const int pair = blockIdx.x, tid = threadIdx.x;
-  if (st[pair].status != ST_NEED_LIN) return;
-  const int N = clouds[pairs[pair].src].n;
-  const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
-  PairState& s = st[pair];
+// after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
+// block (>= 64 threads, uniformly); lds: >= 32 doubles.
+__device__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid) {
   gather_linearize(s, w, pair, nblk, lds, tid);
   if (tid != 0) return;
   s.n_lin += 1;
@@ -1175,14 +1207,8 @@ __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const 
   s.status = ST_NEED_ERR;
 }
 
-// after k_error: L:145-172
-__global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
-  const int pair = blockIdx.x, tid = threadIdx.x;
-  if (st[pair].status != ST_NEED_ERR) return;
-  if (tid != 0) return;
-  const int N = clouds[pairs[pair].src].n;
-  const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
-  PairState& s = st[pair];
+// after k_error: L:145-172 (one lane)
+__device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c) {
   double yi = 0.0;
   for (int b = 0; b < nblk; b++) yi += w.errpart[(size_t)pair * w.nblk_max + b];
   s.yi = yi;
@@ -1210,6 +1236,23 @@ __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const
   s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
   for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
   step_done(s, c, true);
+}
+
+// the same two steps as stand-alone kernels (APDGICP_FUSE=0, and the reference for A/B timing)
+__global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
+  __shared__ double lds[32];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (st[pair].status != ST_NEED_LIN) return;
+  const int N = clouds[pairs[pair].src].n;
+  lm_solve_body(st[pair], w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid);
+}
+
+__global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (st[pair].status != ST_NEED_ERR) return;
+  if (tid != 0) return;
+  const int N = clouds[pairs[pair].src].n;
+  lm_decide_body(st[pair], w, pair, (N + LIN_BLK - 1) / LIN_BLK, c);
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false

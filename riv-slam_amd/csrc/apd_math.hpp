@@ -1,7 +1,8 @@
 // Small fixed-size fp64 algebra shared by the APD-GICP kernels (device) and the host-loop debug
 // path (host).  Everything is written with static indices so that it stays in registers on gfx950
-// (runtime-indexed private arrays go to scratch).  Compiled with -ffp-contract=off: no expression
-// in this project is fused unless it calls fma() explicitly.
+// (runtime-indexed private arrays go to scratch).  Compiled with -ffp-contract=off: no expression in this
+// project is fused.  (Tried in r01: local FMA contraction of the fp64 helpers buys 4 % on k_linearize and
+// moves an ill-conditioned far-range LM run by 2e-4 rad, beyond the 1e-4 parity bar -- not worth it.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
