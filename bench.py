@@ -135,7 +135,7 @@ def main():
         assert len(recs) == total_pairs and int(recs["n_linearize"].min()) == GN_ITERS
         # ---- roofline of the nearest-neighbour kernel: ALGORITHMIC fp32 flops = 8*N*M per pair per launch
         avg_nn_ms = nn_ms / max(1, nn_launches)
-        flops_per_launch = 8.0 * n * n * P
+        flops_per_launch = 8.0 * n * n * P * GN_ITERS * args.steps / max(1, nn_launches)   # a launch covers one pair group
         achieved_tf = flops_per_launch / (avg_nn_ms * 1e-3) / 1e12 if avg_nn_ms > 0 else 0.0
         # whole-registration algorithmic bytes, SURVEY 8d: B_reg = 40(N+M) + L(108N + 16M)
         b_reg = 40.0 * (2 * n) + GN_ITERS * (108.0 * n + 16.0 * n)
@@ -193,7 +193,8 @@ def main():
             if os.environ.get("APDGICP_NN_MODE", "pruned") != "brute":
                 bs = one_step({"APDGICP_STATS": "1"})
                 st = bs.debug_stats()      # counters of the second step only would need a reset; use per-launch averages
-                launches2 = 2 * GN_ITERS
+                _ms_s, launches2 = bs.last_nn_time()
+                launches2 = 2 * max(1, launches2)                   # two steps were run
                 chunks_scanned = float(st[2]) / launches2          # wave-level 16-target chunk scans per launch
                 executed = chunks_scanned * 16 * 64 * 8.0          # x 64 lanes (queries) x 8 flop
                 out["roofline"]["executed_flops_per_launch"] = executed
@@ -202,7 +203,7 @@ def main():
                 del bs
             bf = one_step({"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute"})
             ms_b, k_b = bf.last_nn_time()
-            tf_b = flops_per_launch / (ms_b / max(1, k_b) * 1e-3) / 1e12
+            tf_b = 8.0 * n * n * P * GN_ITERS / max(1, k_b) / (ms_b / max(1, k_b) * 1e-3) / 1e12
             _, sb, tb = bf.last_ticks()
             out["roofline_bruteforce"] = {"kernel": f"k_nn_partial<{sb}> (every pair evaluated, LDS-tiled, T={tb} target splits)", "bound": "mfma",
                                           "achieved": round(tf_b, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -124,6 +124,12 @@ class Engine {
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
   bool fuse_lm = false;    // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=1): measured neutral (r01)
   DevBuf b_ticket;
+  // pair groups: the tick kernels of each group run on their own stream so that one group's short serial
+  // kernels (k_lm_solve) and launch gaps overlap with the other group's wide ones
+  std::vector<hipStream_t> gstreams;
+  std::vector<hipEvent_t> gevents;
+  hipEvent_t ev_main = nullptr;
+  int ngroups_cfg = 2;
   int* h_status = nullptr;   // pinned
   double* h_probe = nullptr; // pinned, 48 doubles
   hipEvent_t ev_poll = nullptr;
@@ -164,6 +170,16 @@ class Engine {
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 0) != 0;
+    ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 2)));
+    APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+    for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
+      hipStream_t st_;
+      hipEvent_t ev_;
+      APD_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+      APD_HIP(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+      gstreams.push_back(st_);
+      gevents.push_back(ev_);
+    }
     return set_params(p);
   }
 
@@ -179,6 +195,9 @@ class Engine {
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
     if (ev_poll) e = hipEventDestroy(ev_poll);
+    if (ev_main) e = hipEventDestroy(ev_main);
+    for (auto st_ : gstreams) e = hipStreamSynchronize(st_), e = hipStreamDestroy(st_);
+    for (auto ev_ : gevents) e = hipEventDestroy(ev_);
     for (auto& pr : nn_events) e = hipEventDestroy(pr.first), e = hipEventDestroy(pr.second);
     if (own_stream && stream) e = hipStreamDestroy(stream);
     (void)e;
@@ -511,12 +530,21 @@ class Engine {
     APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
     APD_HIP(hipMemsetAsync(b_ticket.p, 0, (size_t)2 * npairs * sizeof(int), stream));
     work.ticket = b_ticket.as<int>();
+    work.pair0 = 0;
+    work.npairs = npairs;
     return 0;
   }
 
-  int launch_nn() {
+  // A launch covers the pairs [p0, p0 + np) on stream `st`.
+  struct Span {
+    int p0, np;
+    hipStream_t st;
+  };
+  Span whole() const { return Span{0, npairs, stream}; }
+
+  int launch_nn(Span sp) {
     const int src_blocks = nn_pruned ? (nmax_src + 64 * nn_S - 1) / (64 * nn_S) : (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
-    const dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)npairs : (unsigned)work.T, nn_pruned ? 1u : (unsigned)npairs);
+    const dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)work.T, nn_pruned ? 1u : (unsigned)sp.np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_nn) {
       if (nn_events_used == nn_events.size()) {
@@ -527,48 +555,55 @@ class Engine {
       }
       e0 = nn_events[nn_events_used].first, e1 = nn_events[nn_events_used].second;
       nn_events_used++;
-      APD_HIP(hipEventRecord(e0, stream));
+      APD_HIP(hipEventRecord(e0, sp.st));
     }
     const CloudDesc* cd = d_desc.as<CloudDesc>();
     const PairDesc* pd = d_pairs.as<PairDesc>();
     const PairState* st = d_state.as<PairState>();
+    Work w = work;
+    w.pair0 = sp.p0;
     if (nn_pruned) {
-      if (nn_S == 1) hipLaunchKernelGGL(k_nn_pruned<1>, grid, dim3(64), 0, stream, cd, pd, st, work);
-      else if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, stream, cd, pd, st, work);
-      else hipLaunchKernelGGL(k_nn_pruned<4>, grid, dim3(64), 0, stream, cd, pd, st, work);
-    } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
-    else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
-    else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, stream, cd, pd, st, work);
-    if (profile_nn) APD_HIP(hipEventRecord(e1, stream));
+      if (nn_S == 1) hipLaunchKernelGGL(k_nn_pruned<1>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
+      else if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
+      else hipLaunchKernelGGL(k_nn_pruned<4>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
+    } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
+    else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
+    else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
+    if (profile_nn) APD_HIP(hipEventRecord(e1, sp.st));
     return 0;
   }
 
-  int launch_linearize(int mode /* 0 cost only, 1 H/b/cost, 2 + fused GN/LM step */) {
-    const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
-    hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+  int launch_linearize(Span sp, int mode /* 0 cost only, 1 H/b/cost, 2 + fused GN/LM step */) {
+    const dim3 grid((unsigned)work.nblk_max, (unsigned)sp.np);
+    Work w = work;
+    w.pair0 = sp.p0;
+    hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
                        consts(), mode);
     return 0;
   }
 
-  int launch_error(bool fuse) {
-    const dim3 grid((unsigned)work.nblk_max, (unsigned)npairs);
-    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
+  int launch_error(Span sp, bool fuse) {
+    const dim3 grid((unsigned)work.nblk_max, (unsigned)sp.np);
+    Work w = work;
+    w.pair0 = sp.p0;
+    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
                        consts(), fuse ? 1 : 0);
     return 0;
   }
 
-  // one tick of every pair's state machine
-  int launch_tick() {
+  // one tick of the state machines of the pairs in `sp`
+  int launch_tick(Span sp) {
     const Consts c = consts();
-    APD_TRY(launch_nn());
-    APD_TRY(launch_linearize(fuse_lm ? 2 : 1));
+    Work w = work;
+    w.pair0 = sp.p0;
+    APD_TRY(launch_nn(sp));
+    APD_TRY(launch_linearize(sp, fuse_lm ? 2 : 1));
     if (!fuse_lm)
-      hipLaunchKernelGGL(k_lm_solve, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work, c);
+      hipLaunchKernelGGL(k_lm_solve, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w, c);
     if (params.optimizer == APDGICP_OPT_LM) {
-      APD_TRY(launch_error(fuse_lm));
+      APD_TRY(launch_error(sp, fuse_lm));
       if (!fuse_lm)
-        hipLaunchKernelGGL(k_lm_decide, dim3(npairs), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
-                           c);
+        hipLaunchKernelGGL(k_lm_decide, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w, c);
     }
     return 0;
   }
@@ -605,7 +640,21 @@ class Engine {
     while (!all_done && ticks < tick_cap) {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
-      for (int t = 0; t < todo; t++) APD_TRY(launch_tick());
+      // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
+      const int ng = std::max(1, std::min<int>((int)gstreams.size() + 1, npairs / 2));
+      if (ng > 1) {
+        APD_HIP(hipEventRecord(ev_main, stream));
+        for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
+      }
+      for (int t = 0; t < todo; t++)
+        for (int g = 0; g < ng; g++) {
+          const int p0 = (int)((long long)npairs * g / ng), p1 = (int)((long long)npairs * (g + 1) / ng);
+          APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+        }
+      for (int g = 1; g < ng; g++) {
+        APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
+        APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
+      }
       ticks += todo;
       hipLaunchKernelGGL(k_copy_status, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_state.as<PairState>(), d_status.as<int>(), npairs,
                          d_errflag.as<int>());
@@ -637,8 +686,8 @@ class Engine {
     APD_HIP(hipSetDevice(device));
     APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_LIN, 0);
-    APD_TRY(launch_nn());
-    APD_TRY(launch_linearize(H && b ? 1 : 0));
+    APD_TRY(launch_nn(whole()));
+    APD_TRY(launch_linearize(whole(), H && b ? 1 : 0));
     hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
                        d_probe.as<double>(), 0);
     APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -656,7 +705,7 @@ class Engine {
     APD_HIP(hipSetDevice(device));
     APD_HIP(hipMemcpyAsync(d_T.p, T, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, stream, d_state.as<PairState>(), d_T.as<double>(), (int)ST_NEED_ERR, 1);
-    APD_TRY(launch_error(false));
+    APD_TRY(launch_error(whole(), false));
     hipLaunchKernelGGL(k_probe_reduce, dim3(1), dim3(64), 0, stream, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), work,
                        d_probe.as<double>(), 1);
     APD_HIP(hipMemcpyAsync(h_probe, d_probe.p, 44 * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -81,6 +81,7 @@ struct Work {
   double* blkpart;             // [pair][nblk_max][kRed]
   double* errpart;             // [pair][nblk_max]
   int nstride, nblk_max, T;
+  int pair0, npairs;           // this launch covers pairs [pair0, pair0 + gridDim pairs) of npairs (one stream per pair group)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
 };
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
   // used and each coordinate pair sits in one 64-bit register pair for the v_pk op_sel splats.
   __shared__ float4 txy[NN_TILE / 2];
   __shared__ float2 tz[NN_TILE / 2];
-  const int pair = blockIdx.z;
+  const int pair = w.pair0 + blockIdx.z;
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   __shared__ float2 tz[kGroupPts / 2];
   __shared__ float cbl[6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
-  const int pair = blockIdx.y;
+  const int pair = w.pair0 + blockIdx.y;
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
@@ -925,7 +926,7 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
-  const int pair = blockIdx.y;
+  const int pair = w.pair0 + blockIdx.y;
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
@@ -1090,7 +1091,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
 // Mahalanobis matrices of the last linearize.
 __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst, int fuse) {
   __shared__ double red[LIN_BLK / 64];
-  const int pair = blockIdx.y;
+  const int pair = w.pair0 + blockIdx.y;
   if (st[pair].status != ST_NEED_ERR) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
@@ -1122,7 +1123,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   }
   if (fuse) {
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
-    if (last_block_of_pair(w.ticket + gridDim.y + pair, nblk, tid) && tid == 0) lm_decide_body(st[pair], w, pair, nblk, cst);
+    if (last_block_of_pair(w.ticket + w.npairs + pair, nblk, tid) && tid == 0) lm_decide_body(st[pair], w, pair, nblk, cst);
   }
 }
 
@@ -1241,14 +1242,14 @@ __device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, 
 // the same two steps as stand-alone kernels (APDGICP_FUSE=0, and the reference for A/B timing)
 __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
   __shared__ double lds[32];
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_LIN) return;
   const int N = clouds[pairs[pair].src].n;
   lm_solve_body(st[pair], w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid);
 }
 
 __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_ERR) return;
   if (tid != 0) return;
   const int N = clouds[pairs[pair].src].n;

@@ -438,7 +438,7 @@ int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range
     for (int q = 0; q < 16; q++) T16[q] = (double)T[q];
     APD_HIP(hipMemcpyAsync(e.d_T.p, T16, sizeof(T16), hipMemcpyHostToDevice, e.stream));
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, e.stream, e.d_state.as<PairState>(), e.d_T.as<double>(), (int)ST_NEED_LIN, 0);
-    APD_TRY(e.launch_nn());
+    APD_TRY(e.launch_nn(e.whole()));
     APD_HIP(hipMemsetAsync(e.d_probe.p, 0, 2 * sizeof(double), e.stream));
     hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
                        max_range, e.d_probe.as<double>());
