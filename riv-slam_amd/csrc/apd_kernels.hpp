@@ -247,7 +247,7 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
           const float d = sqdist1(t.x, t.y, t.z, q.x, q.y, q.z);
           const int j = t0 + jj;
           if (d <= tau_d) {
-            const int o = c.perm[j];  // ties are ordered by the caller's ORIGINAL index, like the oracle
+            const int o = c.perm[j];  // ties are ordered by the caller's ORIGINAL index, like the reference restatement
             if (d < tau_d || o <= tau_i) {
               if (cnt < KNN_CAP) {
                 lst_i[cnt * KNN_BLK + tid] = o;
