@@ -871,19 +871,34 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
 }
 
 // ----------------------------------------------------------------------------------------------
-// block reduction of R doubles per lane: wave shuffle tree, then LDS across the block's waves.
-// Fixed order -> bitwise reproducible (the reference's per-thread slots are not, A:262-269).
+// block reduction of R doubles per lane: DPP wave reduction (no LDS traffic), then LDS across the
+// block's waves.  Fixed order -> bitwise reproducible (the reference's per-thread slots are not, A:262-269).
+//
+// wave_sum_to_lane63: inclusive row scans (row_shr 1,2,4,8 inside each 16-lane row, out-of-row sources
+// read as 0), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 -- the classic gfx9
+// cross-lane reduction; lane 63 ends up with the sum of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);  // lanes without a source (or masked rows) receive +0.0
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 template <int R, int BLK>
 __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][R] */, int tid) {
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    double x = v[r];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    v[r] = x;
-  }
+  for (int r = 0; r < R; r++) v[r] = wave_sum_to_lane63(v[r]);
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) {
+  if (lane == 63) {
 #pragma unroll
     for (int r = 0; r < R; r++) lds[wave * R + r] = v[r];
   }
