@@ -53,6 +53,11 @@ typedef enum {
   APDGICP_REG_FROBENIUS = 4
 } apdgicp_regularization;
 
+/* apdgicp_params.flags.  PLAIN_GICP: drop the range-dependent polar noise covariance (cov_dist, A:167-184), which turns the
+ * cost into upstream fast_gicp::FastGICP (gicp/impl/fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T) -- the FAST_GICP branch of
+ * select_registration_method() (registrations.cpp:28-37). */
+enum { APDGICP_FLAG_PLAIN_GICP = 1 };
+
 /* fast_gicp::LSQ_OPTIMIZER_TYPE, gicp/lsq_registration.hpp:13 (reference default: LM, L:17) */
 typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
 
@@ -65,7 +70,7 @@ typedef struct {
   int32_t lm_max_iterations;            /* L:19 ; default 10 */
   int32_t optimizer;                    /* apdgicp_optimizer ; default LM */
   int32_t regularization;               /* apdgicp_regularization ; default PLANE, A:25 */
-  int32_t reserved;
+  int32_t flags;                        /* APDGICP_FLAG_*; default 0 */
   double max_correspondence_distance;   /* pcl setMaxCorrespondenceDistance ; default FLT_MAX, A:23 */
   double transformation_epsilon;        /* pcl setTransformationEpsilon ; default 5e-4, L:15 */
   double rotation_epsilon;              /* setRotationEpsilon, L:30 ; default 2e-3 */
@@ -186,6 +191,13 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
  * gather results with RCCL.  apdgicp_batch_synchronize() waits for the stream. */
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results);
 int apdgicp_batch_synchronize(apdgicp_batch* b);
+/* pcl getFitnessScore(max_range) of every pair at the given poses (T: n_pairs x 16 floats, column-major;
+ * NULL = the poses found by the last align of the same pair list): mean squared nearest-neighbour distance of the
+ * transformed source over the points with squared distance <= max_range, DBL_MAX when none qualifies.  One NN launch
+ * for the whole batch -- the per-candidate getFitnessScore of LoopDetector::matching (loop_detector.cpp:415).
+ * inliers may be NULL. */
+int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, const float* T, double max_range,
+                          double* scores, int64_t* inliers);
 /* copies the n_pairs result records of the last align into caller memory (device pointer when
  * dst_on_device != 0, e.g. a tensor that RCCL will all-gather) and waits for the copy */
 int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int dst_on_device);

@@ -44,6 +44,7 @@ class Params:
     lm_max_iterations: int = 10
     optimizer: int = OPT_LM
     regularization: int = REG_PLANE
+    flags: int = 0   # bit 0: plain GICP (cov_dist omitted), gicp/impl/fast_gicp_impl.hpp
     max_correspondence_distance: float = float(np.finfo(np.float32).max)
     transformation_epsilon: float = 5e-4
     rotation_epsilon: float = 2e-3
@@ -236,6 +237,8 @@ class FastAPDGICP:
             Rz = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.0]])
             A = (Rz @ Ry) @ np.diag([s_x, s_y, s_z])                           # :174-181
             cov_r = A @ A.T                                                    # :182
+            if p.flags & 1:
+                cov_r = np.zeros((3, 3))                                       # upstream FastGICP
             RCR = (self.target_covs[j] + cov_r) + R @ (self.source_covs[i] + cov_r) @ R.T  # :188
             M[i] = np.linalg.inv(RCR)                                          # :191-192
         self.correspondences, self.sq_distances, self.mahalanobis = corr, sq, M

@@ -41,7 +41,7 @@ struct RefParams {  // independent mirror of include/apdgicp_hip.h:apdgicp_param
   int32_t lm_max_iterations;
   int32_t optimizer;       // 0 = LevenbergMarquardt, 1 = GaussNewton (L:17, lsq_registration.hpp:13)
   int32_t regularization;  // gicp_settings.hpp:6 NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS
-  int32_t reserved;
+  int32_t flags;           // bit 0: plain GICP (no cov_dist), gicp/impl/fast_gicp_impl.hpp update_correspondences
   double max_correspondence_distance;
   double transformation_epsilon;
   double rotation_epsilon;
@@ -454,7 +454,8 @@ void update_correspondences(Ref& r, const M4& T) {
     const double s[3] = {s_x, s_y, s_z};
     for (int p = 0; p < 3; p++)
       for (int q = 0; q < 3; q++) Am.m[p][q] = Rot.m[p][q] * s[q];
-    const M3 cov_r = mul(Am, transpose(Am));  // A:182
+    M3 cov_r = mul(Am, transpose(Am));  // A:182
+    if (r.p.flags & 1) cov_r = M3{};      // upstream FastGICP: RCR = cov_B + T cov_A T^T
     const M3 RCR = add(add(cov_B, cov_r), mul(mul(R, add(cov_A, cov_r)), Rt));  // A:188
     r.maha[i] = inverse(RCR);                                                    // A:191-192
   }

@@ -21,7 +21,7 @@ class RefParams(C.Structure):
         ("lm_max_iterations", C.c_int32),
         ("optimizer", C.c_int32),
         ("regularization", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("max_correspondence_distance", C.c_double),
         ("transformation_epsilon", C.c_double),
         ("rotation_epsilon", C.c_double),

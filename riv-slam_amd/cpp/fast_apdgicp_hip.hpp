@@ -92,6 +92,8 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   void setDebugPrint(bool) {}
   /// not in the reference (its optimizer enum is protected without a setter, lsq_registration.hpp:78)
   void setOptimizer(apdgicp_optimizer o) { params_.optimizer = o; }
+  /// upstream fast_gicp::FastGICP cost (no APD covariance): the FAST_GICP branch of the factory (registrations.cpp:28-37)
+  void setPlainGICP(bool on) { params_.flags = on ? (params_.flags | APDGICP_FLAG_PLAIN_GICP) : (params_.flags & ~APDGICP_FLAG_PLAIN_GICP); }
 
   // ---- cache management (fast_apdgicp_impl.hpp:68-108)
   virtual void swapSourceAndTarget() {

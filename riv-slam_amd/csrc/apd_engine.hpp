@@ -223,6 +223,7 @@ class Engine {
     c.lm_max_iterations = params.lm_max_iterations;
     c.optimizer = params.optimizer;
     c.regularization = params.regularization;
+    c.plain_gicp = (params.flags & APDGICP_FLAG_PLAIN_GICP) ? 1 : 0;
     c.thr2 = params.max_correspondence_distance * params.max_correspondence_distance;
     c.trans_eps = params.transformation_epsilon;
     c.rot_eps = params.rotation_epsilon;

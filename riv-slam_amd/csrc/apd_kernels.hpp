@@ -45,6 +45,7 @@ struct PairDesc {
 
 struct Consts {
   int k, max_iterations, lm_max_iterations, optimizer, regularization;
+  int plain_gicp;    // APDGICP_FLAG_PLAIN_GICP: no APD covariance (upstream FastGICP cost)
   double thr2;       // corr_dist_threshold_^2 in double (A:156)
   double trans_eps, rot_eps, lm_init_lambda_factor;
   double dist_var, sin_az, sin_el;  // A:169-171
@@ -912,8 +913,8 @@ __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][
 // 21+6+1 sums per block.  fp64 throughout after the NN, as in the reference.
 constexpr int LIN_BLK = 256;
 
-__device__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid);
-__device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
+__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid);
+__device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
 
 // Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  Every block
 // publishes its partials with an agent-scope release before taking the ticket, the last one acquires
@@ -1038,6 +1039,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
       cd.yy = a10 * a10 + a11 * a11 + a12 * a12;
       cd.yz = a10 * a20 + a12 * a22;
       cd.zz = a20 * a20 + a22 * a22;
+      if (cst.plain_gicp) cd = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T
       const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
       const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
       double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
@@ -1196,7 +1198,7 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 
 // after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
 // block (>= 64 threads, uniformly); lds: >= 32 doubles.
-__device__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid) {
+__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid) {
   gather_linearize(s, w, pair, nblk, lds, tid);
   if (tid != 0) return;
   s.n_lin += 1;
@@ -1224,7 +1226,7 @@ __device__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, c
 }
 
 // after k_error: L:145-172 (one lane)
-__device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c) {
+__device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c) {
   double yi = 0.0;
   for (int b = 0; b < nblk; b++) yi += w.errpart[(size_t)pair * w.nblk_max + b];
   s.yi = yi;
@@ -1254,21 +1256,36 @@ __device__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, 
   step_done(s, c, true);
 }
 
-// the same two steps as stand-alone kernels (APDGICP_FUSE=0, and the reference for A/B timing)
+// The two steps as stand-alone kernels, one 64-lane block per pair.  The 1 KB PairState is staged in LDS
+// (one coalesced round trip in, one out) so that the serial bookkeeping of lane 0 never waits on global memory.
+static_assert(sizeof(PairState) % 8 == 0, "PairState is copied as doubles");
+__device__ __forceinline__ void state_copy(double* dst, const double* src, int tid) {
+  for (int q = tid; q < (int)(sizeof(PairState) / 8); q += 64) dst[q] = src[q];
+}
+
 __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
   __shared__ double lds[32];
+  __shared__ PairState ls;
   const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_LIN) return;
   const int N = clouds[pairs[pair].src].n;
-  lm_solve_body(st[pair], w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid);
+  state_copy((double*)&ls, (const double*)&st[pair], tid);
+  __syncthreads();
+  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid);
+  __syncthreads();
+  state_copy((double*)&st[pair], (const double*)&ls, tid);
 }
 
 __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
+  __shared__ PairState ls;
   const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_ERR) return;
-  if (tid != 0) return;
   const int N = clouds[pairs[pair].src].n;
-  lm_decide_body(st[pair], w, pair, (N + LIN_BLK - 1) / LIN_BLK, c);
+  state_copy((double*)&ls, (const double*)&st[pair], tid);
+  __syncthreads();
+  if (tid == 0) lm_decide_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c);
+  __syncthreads();
+  state_copy((double*)&st[pair], (const double*)&ls, tid);
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false
@@ -1292,6 +1309,19 @@ __global__ void k_init_state(PairState* st, const float* guesses /* n x 16 colum
   s.nu = 2.0;
   s.status = max_iterations > 0 ? ST_NEED_LIN : ST_DONE;
   s.converged = 0, s.iter = 0, s.inner = 0, s.n_lin = 0, s.n_err = 0, s.failed = 0, s.n_matched = 0;
+}
+
+// batch probe support: x0 of every pair := T[pair] (column-major float 4x4), status := NEED_LIN
+__global__ void k_set_poses(PairState* st, const float* T16, int npairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  PairState& s = st[p];
+  if (T16) {
+    const float* g = T16 + 16 * p;
+    for (int r = 0; r < 3; r++)
+      for (int c2 = 0; c2 < 4; c2++) s.x0.m[4 * r + c2] = (double)g[r + 4 * c2];
+  }
+  s.status = ST_NEED_LIN;
 }
 
 // probe support: put pair 0 into a given state at pose T (column-major double 4x4)
@@ -1367,17 +1397,21 @@ __global__ void k_transform_points(const float4* pts /* original order */, int n
   o[2] = T16[2] * p.x + T16[6] * p.y + T16[10] * p.z + T16[14];
 }
 
-// fitness (pcl::Registration::getFitnessScore): per-point gated 1-NN squared distance from the
-// merged nn partials of a probe at T; out[0] += d2 (double), out[1] += 1
+// fitness (pcl::Registration::getFitnessScore): per pair, sum and count of the nearest-neighbour squared
+// distances <= max_range2 taken from the merged nn partials of a search at the pose in st[pair].x0.
+// out[2*pair] += d2 (double), out[2*pair+1] += 1
 __global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out) {
   __shared__ double red[(LIN_BLK / 64) * 2];
-  const int N = clouds[pairs[0].src].n, tid = threadIdx.x;
+  const int pair = w.pair0 + blockIdx.y;
+  const int N = clouds[pairs[pair].src].n, tid = threadIdx.x;
+  if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
   double acc[2] = {0.0, 0.0};
   if (i < N) {
     unsigned long long bestp = ~0ull;
+    const unsigned long long* part = w.nnpart + (size_t)pair * w.T * w.nstride + i;
     for (int sp = 0; sp < w.T; sp++) {
-      const unsigned long long v = w.nnpart[(size_t)sp * w.nstride + i];
+      const unsigned long long v = part[(size_t)sp * w.nstride];
       bestp = v < bestp ? v : bestp;
     }
     const float m = __uint_as_float((unsigned)(bestp >> 32));
@@ -1387,8 +1421,8 @@ __global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, co
   if (tid == 0) {
     double a = 0, b = 0;
     for (int wv = 0; wv < LIN_BLK / 64; wv++) a += red[wv * 2], b += red[wv * 2 + 1];
-    atomicAdd(out, a);
-    atomicAdd(out + 1, b);
+    atomicAdd(out + 2 * pair, a);
+    atomicAdd(out + 2 * pair + 1, b);
   }
 }
 

@@ -1,6 +1,7 @@
 // libapdgicp_hip.so -- the C ABI declared in include/apdgicp_hip.h, on top of apd::Engine.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC (see build.py)
 #include <cstddef>
+#include <limits>
 #include <new>
 
 #include "apd_engine.hpp"
@@ -88,7 +89,7 @@ void apdgicp_default_params(apdgicp_params* p) {
   p->lm_max_iterations = 10;                 // L:19
   p->optimizer = APDGICP_OPT_LM;             // L:17
   p->regularization = APDGICP_REG_PLANE;     // A:25
-  p->reserved = 0;
+  p->flags = 0;
   p->max_correspondence_distance = (double)FLT_MAX;  // A:23
   p->transformation_epsilon = 5e-4;          // L:15
   p->rotation_epsilon = 2e-3;                // L:14
@@ -440,7 +441,7 @@ int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range
     hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, e.stream, e.d_state.as<PairState>(), e.d_T.as<double>(), (int)ST_NEED_LIN, 0);
     APD_TRY(e.launch_nn(e.whole()));
     APD_HIP(hipMemsetAsync(e.d_probe.p, 0, 2 * sizeof(double), e.stream));
-    hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
+    hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max, 1), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
                        max_range, e.d_probe.as<double>());
     APD_HIP(hipMemcpyAsync(e.h_probe, e.d_probe.p, 2 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
@@ -556,6 +557,39 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
     Engine& e = b->eng;
     APD_HIP(hipMemcpyAsync(results, e.d_results.p, n_pairs * sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, const float* T, double max_range, double* scores,
+                          int64_t* inliers) {
+  return guarded([&]() -> int {
+    if (!b || !pairs || !scores) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    Engine& e = b->eng;
+    const bool same = e.npairs == n_pairs && (int64_t)e.h_pairs.size() == n_pairs;
+    bool same_pairs = same;
+    for (int64_t i = 0; same_pairs && i < n_pairs; i++)
+      same_pairs = e.h_pairs[i].src == pairs[i].source_cloud && e.h_pairs[i].tgt == pairs[i].target_cloud;
+    if (!T && !same_pairs) return fail(APDGICP_ERR_NO_INPUT, "T == NULL needs a previous align of the same pair list");
+    if (!same_pairs) APD_TRY(e.setup_pairs(pairs, n_pairs, true));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n_pairs * (16 * sizeof(float) + 2 * sizeof(double))));
+    double* d_out = e.d_stage.as<double>();
+    float* d_T = (float*)(d_out + 2 * n_pairs);
+    if (T) APD_HIP(hipMemcpyAsync(d_T, T, (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    APD_HIP(hipMemsetAsync(d_out, 0, (size_t)n_pairs * 2 * sizeof(double), e.stream));
+    hipLaunchKernelGGL(k_set_poses, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, e.stream, e.d_state.as<PairState>(), T ? d_T : (const float*)nullptr,
+                       (int)n_pairs);
+    APD_TRY(e.launch_nn(e.whole()));
+    hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max, (unsigned)n_pairs), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(),
+                       e.d_pairs.as<PairDesc>(), e.work, max_range, d_out);
+    std::vector<double> h((size_t)n_pairs * 2);
+    APD_HIP(hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    for (int64_t i = 0; i < n_pairs; i++) {
+      scores[i] = h[2 * i + 1] > 0 ? h[2 * i] / h[2 * i + 1] : std::numeric_limits<double>::max();
+      if (inliers) inliers[i] = (int64_t)h[2 * i + 1];
+    }
     return 0;
   });
 }

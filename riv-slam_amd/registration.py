@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libapdgicp_hip.so")
 
 REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = 0, 1, 2, 3, 4
 OPT_LM, OPT_GN = 0, 1
+FLAG_PLAIN_GICP = 1  # upstream fast_gicp::FastGICP cost (no APD covariance)
 SOURCE, TARGET = 0, 1
 
 
@@ -39,7 +40,7 @@ class Params(C.Structure):
         ("lm_max_iterations", C.c_int32),
         ("optimizer", C.c_int32),
         ("regularization", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("max_correspondence_distance", C.c_double),
         ("transformation_epsilon", C.c_double),
         ("rotation_epsilon", C.c_double),
@@ -87,7 +88,7 @@ SYMBOLS = [
     "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_synchronize",
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
-    "apdgicp_batch_align_async", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
+    "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
     "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
 ]
 
@@ -146,6 +147,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_set_clouds.argtypes = [vp, i32, i32, vp, vp, i64, i32]
     L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
     L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
+    L.apdgicp_batch_fitness.argtypes = [vp, vp, i64, vp, dbl, vp, vp]
     L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
     L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
     L.apdgicp_batch_last_nn_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
@@ -477,6 +479,19 @@ class BatchAPDGICP:
         dptr = C.c_void_p()
         _check(self.L.apdgicp_batch_align_async(self.b, arr, len(arr), C.byref(dptr)))
         return dptr.value, len(arr) * RESULT_DTYPE.itemsize
+
+    def fitness(self, pairs, T=None, max_range: float = float(np.finfo(np.float64).max), guesses=None):
+        """getFitnessScore(max_range) of every pair at poses T ([n,4,4] row-major numpy; None = the poses of the
+        last align of the same pair list).  Returns (scores float64[n], inliers int64[n])."""
+        arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
+        n = len(arr)
+        Tc = None
+        if T is not None:
+            Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(n, 4, 4).transpose(0, 2, 1)).reshape(n, 16)
+        scores = np.zeros(n, dtype=np.float64)
+        inl = np.zeros(n, dtype=np.int64)
+        _check(self.L.apdgicp_batch_fitness(self.b, arr, n, _ptr(Tc) if Tc is not None else None, max_range, _ptr(scores), _ptr(inl)))
+        return scores, inl
 
     def synchronize(self):
         _check(self.L.apdgicp_batch_synchronize(self.b))

@@ -497,3 +497,60 @@ def test_c5_dense_submap_correspondences(reg, scene):
     T, To = g.align(guess), o.align(guess)
     te, re_ = scene.pose_error(To, T)
     assert te <= T_TOL and re_ <= R_TOL
+
+
+# ------------------------------------------------------------------ SURVEY 8f rows
+def test_plain_gicp_mode(reg, golden, scene):
+    """f4: APDGICP_FLAG_PLAIN_GICP == upstream fast_gicp::FastGICP (cov_dist = 0); without the fp32 atan2f the
+    smooth outputs agree much tighter."""
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    kw = dict(max_correspondence_distance=2.5, flags=reg.FLAG_PLAIN_GICP)
+    g, o = both(reg, src, tgt, **kw)
+    c1, H1, b1 = g.linearize(guess.astype(np.float64))
+    c2, H2, b2 = o.linearize(guess.astype(np.float64))
+    assert np.array_equal(g.correspondences()[0], o.correspondences()[0])
+    assert rel_err(H1, H2) < 1e-10 and rel_err(b1, b2) < 1e-9 and abs(c1 - c2) < 1e-10 * c2
+    T, To = g.align(guess), o.align(guess)
+    assert info_of(g) == [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error]
+    te, re_ = scene.pose_error(To, T)
+    assert te <= T_TOL and re_ <= R_TOL
+
+
+def test_batch_fitness_and_candidate_verifier(reg, scene, pkg):
+    """f1/f2: batched getFitnessScore and the LoopDetector::matching selection rule (loop_detector.cpp:404-431)."""
+    import apdgicp_np as O
+    lv = importlib.import_module("riv-slam_amd.loop_verifier")
+    cands, guesses = [], []
+    tgt = None
+    for i in range(4):
+        s, t, _, g = scene.make_pair(2048, 2048, scene.pair_seed(9, 0 if i != 2 else 50), "odometry")
+        if tgt is None:
+            tgt = t
+        # candidate 2 comes from another scene (must lose), candidates 1 and 3 are noisy copies of candidate 0
+        noise = (0.0, 0.02, 0.0, 0.05)[i]
+        cands.append(s + np.float32(noise) * np.random.default_rng(3 + i).standard_normal(s.shape).astype(np.float32))
+        guesses.append(g)
+    kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    loop, scores, results = lv.verify_candidates(b, tgt, cands, guesses, fitness_score_max_range=4.0, fitness_score_thresh=10.0)
+    # scores against an independent evaluation of pcl's definition
+    for i, c in enumerate(cands):
+        T = reg.result_matrix(results[i])
+        pt = O.transform_points_f32(T.astype(np.float64), c)
+        _, sq = O.nn1(pt, tgt)
+        sel = sq.astype(np.float64) <= 4.0
+        assert abs(scores[i] - sq[sel].astype(np.float64).mean()) < 1e-9 * scores[i]
+    conv = [bool(r["converged"]) for r in results]
+    want = -1
+    for i in range(4):   # loop_detector.cpp:416: `if(!converged || score > best_score) continue;` -> the later of equal scores wins
+        if conv[i] and (want < 0 or scores[i] <= scores[want]):
+            want = i
+    assert loop is not None and loop.candidate == want and loop.candidate != 2
+    assert np.array_equal(loop.relative_pose, reg.result_matrix(results[want]))
+    none, _, _ = lv.verify_candidates(b, tgt, cands, guesses, fitness_score_max_range=4.0, fitness_score_thresh=1e-9)
+    assert none is None
+    # explicit poses: identity
+    s2, _ = b.fitness([(1, 0)], np.eye(4)[None], 4.0)
+    _, sq = O.nn1(cands[0], tgt)
+    sel = sq.astype(np.float64) <= 4.0
+    assert abs(s2[0] - sq[sel].astype(np.float64).mean()) < 1e-9 * s2[0]

@@ -174,3 +174,24 @@ def test_scene_is_deterministic(scene):
         assert np.array_equal(x, y)
     r = np.linalg.norm(a[0], axis=1)
     assert r.min() > 1.5 and r.max() < 103
+
+
+def test_plain_gicp_mode_restatements_agree(golden):
+    """flags bit 0 = upstream FastGICP cost (cov_dist dropped, fast_gicp_impl.hpp): both restatements, and
+    the difference to the APD cost is real."""
+    src, tgt = golden["lin_source"][:700], golden["lin_target"][:700]
+    kw = dict(max_correspondence_distance=2.5, flags=1)
+    r = R.RefAPDGICP(R.default_params(**kw))
+    n = O.FastAPDGICP(O.Params(**kw))
+    a = R.RefAPDGICP(R.default_params(max_correspondence_distance=2.5))
+    for o in (r, n, a):
+        o.setInputSource(src)
+        o.setInputTarget(tgt)
+    n.source_covs, n.target_covs = r.covariances("source"), r.covariances("target")
+    T = golden["lin_guess"].astype(np.float64)
+    cr, Hr, br = r.linearize(T)
+    cn, Hn, bn = n.linearize(T)
+    ca, Ha, ba = a.linearize(T)
+    assert rel_err(Hr, Hn) < 1e-10 and rel_err(br, bn) < 1e-9 and abs(cr - cn) < 1e-10 * cr   # no atan2f in this mode
+    assert rel_err(Ha, Hr) > 1e-2                                                            # APD term matters
+    assert np.array_equal(r.correspondences()[0], a.correspondences()[0])                    # same nearest neighbours
