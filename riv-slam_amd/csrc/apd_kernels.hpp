@@ -533,19 +533,44 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   const int nchunks = (M + kChunk - 1) / kChunk;
 
   unsigned n_groups = 0, n_ctest = 0, n_cscan = 0;
-  auto scan_group = [&](int g) {
-    n_groups++;
-    __syncthreads();  // single-wave block: orders the reuse of the LDS tile
-    stage_group(txy, tz, cbl, tgt.pts, tgt.cbox, g, M, nchunks, lane);
+  // registers of the group in flight: loaded from L2 while the previous group is scanned out of LDS
+  float4 pa = make_float4(inf, inf, inf, 0.f), pb = pa;
+  float pc = inf;
+  auto fetch_group = [&](int g) {
+    const int j = g * kGroupPts + 2 * lane;
+    pa = j < M ? tgt.pts[j] : make_float4(inf, inf, inf, 0.f);
+    pb = j + 1 < M ? tgt.pts[j + 1] : make_float4(inf, inf, inf, 0.f);
+    if (lane < 6 * kGroupChunks) {
+      const int c = g * kGroupChunks + lane / 6;
+      pc = c < nchunks ? ((const float*)tgt.cbox)[(size_t)g * kGroupChunks * 6 + lane] : inf;
+    }
+  };
+  auto commit_group = [&]() {  // registers -> the wave's LDS tile ({x0,x1,y0,y1} + {z0,z1} pairs, 8 chunk boxes)
+    __syncthreads();           // single-wave block: the previous scan is done with the tile
+    txy[lane] = make_float4(pa.x, pb.x, pa.y, pb.y);
+    tz[lane] = make_float2(pa.z, pb.z);
+    if (lane < 6 * kGroupChunks) cbl[lane] = pc;
     __syncthreads();
-    const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
-    for (int ch = 0; ch < cend; ch++) {
-      const Box cb = lds_box(cbl, ch);
-      bool need = false;
+  };
+  auto lane_needs = [&](const Box& bx) {
+    bool need = false;
 #pragma unroll
-      for (int s = 0; s < S; s++) need |= lb_point_box(cb, px[s], py[s], pz[s]) <= best[s];
-      n_ctest++;
-      if (!__any(need)) continue;
+    for (int s = 0; s < S; s++) need |= lb_point_box(bx, px[s], py[s], pz[s]) <= best[s];
+    return need;
+  };
+  auto scan_tile = [&](int g) {
+    n_groups++;
+    const int cend = min(kGroupChunks, nchunks - g * kGroupChunks);
+    // all 8 chunk tests first (independent LDS reads, no branches), then only the scans that are needed
+    unsigned cmask = 0;
+#pragma unroll
+    for (int ch = 0; ch < kGroupChunks; ch++)
+      if (__any(lane_needs(lds_box(cbl, ch)))) cmask |= 1u << ch;
+    cmask &= (1u << cend) - 1u;
+    n_ctest += cend;
+    while (cmask) {
+      const int ch = __builtin_ctz(cmask);
+      cmask &= cmask - 1;
       n_cscan++;
       float m[S];
 #pragma unroll
@@ -571,31 +596,59 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   };
 
   for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
-    const int nb = min(GB_BATCH, ngroups - gb0);
+    const int nbb = min(GB_BATCH, ngroups - gb0);
     __syncthreads();
-    for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
+    for (int e = lane; e < 6 * nbb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
     __syncthreads();
-    // seed: the group whose box contains the most points of this wave
-    int seed = -1, seed_cnt = 0;
-    if (gb0 == 0 && !all_hinted) {
-      for (int g = 0; g < nb; g++) {
-        const Box gb = lds_box(gbl, g);
-        int inside = 0;
+    for (int sb = 0; sb < nbb; sb += 64) {  // 64 groups at a time: their need bits fit one mask
+      const int nb = min(64, nbb - sb);
+      const float* boxes = gbl + 6 * sb;
+      const int g0 = gb0 + sb;
+      // cold start only: scan first the group whose box contains the most points of this wave
+      int seed = -1;
+      if (g0 == 0 && !all_hinted) {
+        int seed_cnt = 0;
+        for (int g = 0; g < nb; g++) {
+          const Box gb = lds_box(boxes, g);
+          int inside = 0;
 #pragma unroll
-        for (int s = 0; s < S; s++) inside += lb_point_box(gb, px[s], py[s], pz[s]) == 0.f ? 1 : 0;
-        const int cntg = __popcll(__ballot(inside > 0));
-        if (cntg > seed_cnt) seed_cnt = cntg, seed = g;
+          for (int s = 0; s < S; s++) inside += lb_point_box(gb, px[s], py[s], pz[s]) == 0.f ? 1 : 0;
+          const int cntg = __popcll(__ballot(inside > 0));
+          if (cntg > seed_cnt) seed_cnt = cntg, seed = g;
+        }
+        if (seed >= 0) {
+          fetch_group(g0 + seed);
+          commit_group();
+          scan_tile(g0 + seed);
+        }
       }
-      if (seed >= 0) scan_group(seed);
-    }
-    for (int g = 0; g < nb; g++) {
-      if (g == seed) continue;
-      const Box gb = lds_box(gbl, g);
-      bool need = false;
+      // candidate groups with the bounds known now (4 tests per trip keep the LDS reads in flight); a
+      // candidate is re-tested against the then-current `best` just before its scan
+      unsigned long long cand = 0;
+      for (int g = 0; g < nb; g += 4) {
 #pragma unroll
-      for (int s = 0; s < S; s++) need |= lb_point_box(gb, px[s], py[s], pz[s]) <= best[s];
-      if (!__any(need)) continue;
-      scan_group(gb0 + g);
+        for (int u = 0; u < 4; u++) {
+          const int gg = min(g + u, nb - 1);
+          if (__any(lane_needs(lds_box(boxes, gg)))) cand |= 1ull << gg;
+        }
+      }
+      if (seed >= 0) cand &= ~(1ull << seed);
+      // software pipeline: group k+1 travels L2 -> registers while group k is scanned out of LDS
+      int cur = cand ? __builtin_ctzll(cand) : -1;
+      if (cur >= 0) {
+        cand &= cand - 1;
+        fetch_group(g0 + cur);
+      }
+      while (cur >= 0) {
+        commit_group();
+        const int nxt = cand ? __builtin_ctzll(cand) : -1;
+        if (nxt >= 0) {
+          cand &= cand - 1;
+          fetch_group(g0 + nxt);
+        }
+        if (__any(lane_needs(lds_box(boxes, cur)))) scan_tile(g0 + cur);
+        cur = nxt;
+      }
     }
   }
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
