@@ -90,7 +90,7 @@ def main():
 
     params = bench_params(reg)
     batch = reg.BatchAPDGICP(params, device=local_rank)
-    batch.set_profiling(True)
+    batch.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
     pairs_arr = batch.make_pairs(pair_idx, guesses)
     d_res = torch.zeros((P, sharded.RESULT_BYTES), dtype=torch.uint8, device="cuda")
 
@@ -109,16 +109,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    nn_ms, nn_launches = 0.0, 0
+    nn_ms, nn_launches, nn_pairs = 0.0, 0, 0
     for _ in range(args.warmup):
         gathered = aligner.align(total_pairs)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gathered = aligner.align(total_pairs)
-        ms, k = batch.last_nn_time()
+        ms, k, pr = batch.last_nn_profile()
         nn_ms += ms
         nn_launches += k
+        nn_pairs += pr
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -135,7 +136,7 @@ def main():
         assert len(recs) == total_pairs and int(recs["n_linearize"].min()) == GN_ITERS
         # ---- roofline of the nearest-neighbour kernel: ALGORITHMIC fp32 flops = 8*N*M per pair per launch
         avg_nn_ms = nn_ms / max(1, nn_launches)
-        flops_per_launch = 8.0 * n * n * P * GN_ITERS * args.steps / max(1, nn_launches)   # a launch covers one pair group
+        flops_per_launch = 8.0 * n * n * nn_pairs / max(1, nn_launches)   # a launch covers one pair group (P / 2 pairs)
         achieved_tf = flops_per_launch / (avg_nn_ms * 1e-3) / 1e12 if avg_nn_ms > 0 else 0.0
         # whole-registration algorithmic bytes, SURVEY 8d: B_reg = 40(N+M) + L(108N + 16M)
         b_reg = 40.0 * (2 * n) + GN_ITERS * (108.0 * n + 16.0 * n)
@@ -193,17 +194,17 @@ def main():
             if os.environ.get("APDGICP_NN_MODE", "pruned") != "brute":
                 bs = one_step({"APDGICP_STATS": "1"})
                 st = bs.debug_stats()      # counters of the second step only would need a reset; use per-launch averages
-                _ms_s, launches2 = bs.last_nn_time()
-                launches2 = 2 * max(1, launches2)                   # two steps were run
-                chunks_scanned = float(st[2]) / launches2          # wave-level 16-target chunk scans per launch
+                pairs_per_launch = nn_pairs / max(1, nn_launches)
+                waves_per_launch = (n / 64.0) * pairs_per_launch
+                chunks_scanned = float(st[2]) / max(1.0, float(st[3])) * waves_per_launch   # 16-target chunk scans per launch
                 executed = chunks_scanned * 16 * 64 * 8.0          # x 64 lanes (queries) x 8 flop
                 out["roofline"]["executed_flops_per_launch"] = executed
                 out["roofline"]["executed_fraction_of_algorithmic"] = round(executed / flops_per_launch, 5)
                 out["roofline"]["executed_TFLOPs"] = round(executed / (avg_nn_ms * 1e-3) / 1e12, 2)
                 del bs
-            bf = one_step({"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute"})
-            ms_b, k_b = bf.last_nn_time()
-            tf_b = 8.0 * n * n * P * GN_ITERS / max(1, k_b) / (ms_b / max(1, k_b) * 1e-3) / 1e12
+            bf = one_step({"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute", "APDGICP_STREAMS": "1", "APDGICP_PROFILE_STRIDE": "1"})
+            ms_b, k_b, pr_b = bf.last_nn_profile()
+            tf_b = 8.0 * n * n * pr_b / max(1e-9, ms_b * 1e-3) / 1e12
             _, sb, tb = bf.last_ticks()
             out["roofline_bruteforce"] = {"kernel": f"k_nn_partial<{sb}> (every pair evaluated, LDS-tiled, T={tb} target splits)", "bound": "mfma",
                                           "achieved": round(tf_b, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

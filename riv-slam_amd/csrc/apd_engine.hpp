@@ -139,7 +139,10 @@ class Engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_events;
   size_t nn_events_used = 0;
   double last_nn_ms = 0;
-  long long last_nn_launches = 0;
+  long long last_nn_launches = 0, last_nn_pairs = 0, nn_pairs_acc = 0;
+  // events cost ~5 % of a batched step when every launch is bracketed, so only the launches of every
+  // `profile_stride`-th tick are timed, with a phase that rotates from align to align (unbiased over ticks)
+  int profile_stride = 5, profile_phase = 0, cur_tick = 0;
   int last_ticks = 0;
 
   int init(const apdgicp_params* p, int dev, void* strm) {
@@ -547,7 +550,9 @@ class Engine {
     const int src_blocks = nn_pruned ? (nmax_src + 64 * nn_S - 1) / (64 * nn_S) : (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
     const dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)work.T, nn_pruned ? 1u : (unsigned)sp.np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile_nn) {
+    const bool timed = profile_nn && ((cur_tick + profile_phase) % profile_stride == 0);
+    if (timed) {
+      nn_pairs_acc += sp.np;
       if (nn_events_used == nn_events.size()) {
         hipEvent_t a, b;
         APD_HIP(hipEventCreate(&a));
@@ -570,7 +575,7 @@ class Engine {
     } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
     else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
     else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
-    if (profile_nn) APD_HIP(hipEventRecord(e1, sp.st));
+    if (timed) APD_HIP(hipEventRecord(e1, sp.st));
     return 0;
   }
 
@@ -612,6 +617,7 @@ class Engine {
   int collect_nn_profile() {
     last_nn_ms = 0;
     last_nn_launches = 0;
+    last_nn_pairs = nn_pairs_acc;
     for (size_t i = 0; i < nn_events_used; i++) {
       float ms = 0;
       APD_HIP(hipEventElapsedTime(&ms, nn_events[i].first, nn_events[i].second));
@@ -626,6 +632,10 @@ class Engine {
   int run_align() {
     APD_HIP(hipSetDevice(device));
     nn_events_used = 0;
+    nn_pairs_acc = 0;
+    cur_tick = 0;
+    profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 5));
+    profile_phase = (profile_phase + 1) % profile_stride;
     // every align starts cold (hints of an earlier run would still be valid bounds, but results must
     // not depend on call history in any observable way, timing included)
     APD_HIP(hipMemsetAsync(b_nnidx.p, 0xFF, (size_t)npairs * work.nstride * 4, stream));
@@ -647,7 +657,7 @@ class Engine {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
       }
-      for (int t = 0; t < todo; t++)
+      for (int t = 0; t < todo; t++, cur_tick++)
         for (int g = 0; g < ng; g++) {
           const int p0 = (int)((long long)npairs * g / ng), p1 = (int)((long long)npairs * (g + 1) / ng);
           APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));

@@ -634,6 +634,14 @@ int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]) {
   return 0;
 }
 
+int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  if (total_ms) *total_ms = b->eng.last_nn_ms;
+  if (launches) *launches = b->eng.last_nn_launches;
+  if (pairs_covered) *pairs_covered = b->eng.last_nn_pairs;
+  return 0;
+}
+
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   if (ticks) *ticks = b->eng.last_ticks;

@@ -89,7 +89,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
+    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
 ]
 
 _lib = None
@@ -151,6 +151,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
     L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
     L.apdgicp_batch_last_nn_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.apdgicp_batch_last_nn_profile.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.apdgicp_batch_debug_stats.argtypes = [vp, vp]
     if path is None:
@@ -515,6 +516,11 @@ class BatchAPDGICP:
         out = np.zeros(16, dtype=np.uint64)
         _check(self.L.apdgicp_batch_debug_stats(self.b, _ptr(out)))
         return out
+
+    def last_nn_profile(self):
+        ms, n, pr = C.c_double(), C.c_int64(), C.c_int64()
+        _check(self.L.apdgicp_batch_last_nn_profile(self.b, C.byref(ms), C.byref(n), C.byref(pr)))
+        return ms.value, n.value, pr.value
 
     def last_ticks(self):
         a, s, t = C.c_int(), C.c_int(), C.c_int()
