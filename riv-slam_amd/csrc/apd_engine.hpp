@@ -446,8 +446,16 @@ class Engine {
       int qpw = env_int("APDGICP_KNN_QPW", 0);
       if (qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : 8;  // measured: r01 sweep
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)ids.size());
-      hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
-                         params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
+      static const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
+      if (coop && qpw == 16)
+        hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
+                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+      else if (coop && qpw == 8)
+        hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
+                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+      else
+        hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
+                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {
       static bool attr_set = false;
       if (!attr_set) {
@@ -580,7 +588,7 @@ class Engine {
   }
 
   int launch_linearize(Span sp, int mode /* 0 cost only, 1 H/b/cost, 2 + fused GN/LM step */) {
-    const dim3 grid((unsigned)work.nblk_max, (unsigned)sp.np);
+    const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
     hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
@@ -589,7 +597,7 @@ class Engine {
   }
 
   int launch_error(Span sp, bool fuse) {
-    const dim3 grid((unsigned)work.nblk_max, (unsigned)sp.np);
+    const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
     hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,

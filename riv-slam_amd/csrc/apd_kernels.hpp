@@ -688,26 +688,46 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
-// k-th smallest (1-based) of the up-to-3 keys per lane (a key equal to ~0ull is "absent"), found by a
-// most-significant-bit-first radix select with ballots: no cross-lane data movement at all.
-// Bits [lo_bits, 32) of the low word are known to be zero (original indices are < 2^lo_bits).
+// Threshold for the kth smallest (1-based) of the up-to-3 keys per lane (a key equal to ~0ull is
+// "absent"): returns tk such that exactly kth keys are <= tk.  Most-significant-bit-first radix select
+// on wave-uniform ballot masks -- no cross-lane data movement.  The descent stops as soon as every
+// key still in play is selected (tk = prefix | ones below; typically after ~15-20 of the 32 + lo_bits
+// steps), so tk need not be a key itself.  Bits [lo_bits, 32) of the low word are known to be zero
+// (original indices are < 2^lo_bits).  Needs kth <= number of present keys.
 __device__ __forceinline__ unsigned long long wave_kth_smallest3(unsigned long long a, unsigned long long b, unsigned long long c, int kth,
                                                                  int lo_bits) {
-  bool la = a != ~0ull, lb = b != ~0ull, lc = c != ~0ull;
-  unsigned long long prefix = 0;
-  for (int bit = 63; bit >= 0; bit--) {
-    if (bit < 32 && bit >= lo_bits) continue;
-    const bool za = ((a >> bit) & 1ull) == 0, zb = ((b >> bit) & 1ull) == 0, zc = ((c >> bit) & 1ull) == 0;
-    const int c0 = __popcll(__ballot(la && za)) + __popcll(__ballot(lb && zb)) + __popcll(__ballot(lc && zc));
+  unsigned long long la = __ballot(a != ~0ull), lb = __ballot(b != ~0ull), lc = __ballot(c != ~0ull);
+  int live = __popcll(la) + __popcll(lb) + __popcll(lc);
+  const unsigned ah = (unsigned)(a >> 32), bh = (unsigned)(b >> 32), ch = (unsigned)(c >> 32);
+  const unsigned al = (unsigned)a, bl = (unsigned)b, cl = (unsigned)c;
+  unsigned pre_hi = 0, pre_lo = 0;
+  for (int bit = 31; bit >= 0; bit--) {
+    const unsigned m = 1u << bit;
+    if (live == kth) return ((unsigned long long)(pre_hi | (m | (m - 1u))) << 32) | 0xFFFFFFFFull;
+    const unsigned long long za = la & __ballot((ah & m) == 0), zb = lb & __ballot((bh & m) == 0), zc = lc & __ballot((ch & m) == 0);
+    const int c0 = __popcll(za) + __popcll(zb) + __popcll(zc);
     if (kth <= c0) {
-      la = la && za, lb = lb && zb, lc = lc && zc;
+      la = za, lb = zb, lc = zc, live = c0;
     } else {
-      kth -= c0;
-      la = la && !za, lb = lb && !zb, lc = lc && !zc;
-      prefix |= 1ull << bit;
+      kth -= c0, live -= c0;
+      la &= ~za, lb &= ~zb, lc &= ~zc;
+      pre_hi |= m;
     }
   }
-  return prefix;
+  for (int bit = lo_bits - 1; bit >= 0; bit--) {
+    const unsigned m = 1u << bit;
+    if (live == kth) return ((unsigned long long)pre_hi << 32) | (pre_lo | (m | (m - 1u)));
+    const unsigned long long za = la & __ballot((al & m) == 0), zb = lb & __ballot((bl & m) == 0), zc = lc & __ballot((cl & m) == 0);
+    const int c0 = __popcll(za) + __popcll(zb) + __popcll(zc);
+    if (kth <= c0) {
+      la = za, lb = zb, lc = zc, live = c0;
+    } else {
+      kth -= c0, live -= c0;
+      la &= ~za, lb &= ~zb, lc &= ~zc;
+      pre_lo |= m;
+    }
+  }
+  return ((unsigned long long)pre_hi << 32) | pre_lo;
 }
 __device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 
@@ -925,6 +945,290 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_knn_cov_coop<L>: the same algorithm with L = 4 or 8 lanes per query (64/L queries per wave) in the
+// lane = query phases, so those phases cost 1/L of the instructions and stop being one long serial
+// chain per lane:
+//   A  the L lanes of a query split the 32 distance classes of the staged neighbourhood (32/L class
+//      minima per lane, exchanged through LDS; every lane then runs the same 32-key sorting network)
+//      and the 64 group-box tests (64/L per lane, masks merged with DPP butterflies);
+//   B  unchanged (lane = candidate); the query state (tau, count) is kept identical in the L lanes;
+//   C  each lane keeps KQ_CAP/L list entries in REGISTERS; a round is a register-only local minimum
+//      plus a DPP butterfly over the L lanes -- no LDS reads inside the k rounds.  All L lanes
+//      accumulate the moments of the same neighbours in rank order, so the result is bitwise the one of
+//      the single-lane formulation.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// butterflies over aligned groups of L lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then (L == 8)
+// row_half_mirror, which pairs every lane with one of the other quad once the quads are uniform
+template <int L>
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
+  unsigned long long o = dpp_u64<0xB1>(v);
+  v = o < v ? o : v;
+  o = dpp_u64<0x4E>(v);
+  v = o < v ? o : v;
+  if (L == 8) {
+    o = dpp_u64<0x141>(v);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+template <int L>
+__device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v) {
+  v |= dpp_u64<0xB1>(v);
+  v |= dpp_u64<0x4E>(v);
+  if (L == 8) v |= dpp_u64<0x141>(v);
+  return v;
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
+                                                     unsigned long long* stats) {
+  constexpr int QPW = 64 / L, NCL = KNN_NC / L, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
+  static_assert(L == 4 || L == 8, "L lanes per query");
+  static_assert(KQ_CAP % L == 0 && KQ_WIN % KNN_NC == 0, "layout");
+  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
+  unsigned long long* lst = knn_smem;                            // [query][slot], padded row
+  float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
+  float4* wtile = (float4*)(lst + QPW * KQ_STRIDE);              // sorted neighbourhood
+  float* gbl = (float*)(wtile + KQ_WIN);                         // 64 group boxes
+  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  const int n = c.n, lane = threadIdx.x;
+  const int base = blockIdx.x * QPW;
+  if (base >= n) return;
+  const float inf = __builtin_inff();
+  const int slot = lane / L, sub = lane % L, owner = lane - sub;
+  const int i = base + slot;
+  const bool valid = i < n;
+  const float4 q = c.pts[valid ? i : n - 1];
+  const int ngroups = (n + kGroupPts - 1) / kGroupPts;
+  unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
+  if ((blockIdx.x & 63) != 0) stats = nullptr;  // diagnostics sample every 64th wave (the atomics would dominate otherwise)
+
+  long long tA = 0, tG = 0, tB = 0, tC = 0, tm = stats ? clock64() : 0;
+  // ---- A: bound from the sorted neighbourhood
+  const int w0 = min(max(base - (KQ_WIN - QPW) / 2, 0), max(n - KQ_WIN, 0));
+  for (int e = lane; e < KQ_WIN; e += 64) {
+    const int j = w0 + e;
+    float4 t = make_float4(inf, inf, inf, 0.f);
+    if (j < n) t = c.pts[j];
+    wtile[e] = t;
+  }
+  for (int e = lane; e < 6 * min(64, ngroups); e += 64) gbl[e] = ((const float*)c.gbox)[e];  // boxes of the first 64 groups
+  int cnt = 0;  // entries in this query's list (same value in its L lanes)
+  int idx_bits = 1;
+  while ((1 << idx_bits) < n) idx_bits++;
+  __syncthreads();
+  {
+    float cmp[NCL];  // minima of the classes sub + L*m
+#pragma unroll
+    for (int m = 0; m < NCL; m++) cmp[m] = inf;
+    for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
+#pragma unroll
+      for (int m = 0; m < NCL; m++) {
+        const float4 t = wtile[sub + L * (t0 + m)];
+        cmp[m] = fminf(cmp[m], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NCL; m++) cml[slot * (KNN_NC + 1) + sub + L * m] = cmp[m];
+  }
+  __syncthreads();
+  float cm[KNN_NC];
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++) cm[s] = cml[slot * (KNN_NC + 1) + s];
+  __syncthreads();  // cml aliases the lists
+#pragma unroll
+  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int a = 0; a < KNN_NC; a++) {
+        const int l = a ^ j;
+        if (l > a) {
+          const bool up = (a & kk) == 0;
+          const float x = cm[a], y = cm[l];
+          const float lo = fminf(x, y), hi = fmaxf(x, y);
+          cm[a] = up ? lo : hi;
+          cm[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+  float tau_d = inf;
+#pragma unroll
+  for (int s = 0; s < KNN_NC; s++)
+    if (s == k - 1) tau_d = cm[s];
+  if (!valid) tau_d = -1.f;
+  unsigned tau_hi = __float_as_uint(tau_d), tau_lo = 0xFFFFFFFFu;  // tau key = (tau_hi << 32) | tau_lo
+
+  if (stats) { const long long t = clock64(); tA += t - tm, tm = t; }
+  // ---- B
+  for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {
+    const int nb = min(64, ngroups - gb0);
+    if (gb0 > 0) {
+      __syncthreads();
+      for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
+      __syncthreads();
+    }
+    unsigned long long gneed = 0;
+    {
+      const float td = __uint_as_float(tau_hi);
+#pragma unroll
+      for (int t = 0; t < 64 / L; t++) {
+        const int g = sub + L * t;
+        if (g < nb && lb_point_box(lds_box(gbl, g), q.x, q.y, q.z) <= td) gneed |= 1ull << g;
+      }
+      gneed = group_or_u64<L>(gneed);
+      if (!valid) gneed = 0;
+    }
+    if (stats) { const long long t = clock64(); tG += t - tm, tm = t; }
+    // groups some query of this wave needs (uniform), walked with the next group's loads in flight
+    unsigned long long gany = 0;
+    for (int g = 0; g < nb; g++)
+      if (__ballot(((gneed >> g) & 1ull) != 0)) gany |= 1ull << g;
+    float4 c0, c1, d0, d1;
+    unsigned o0, o1, p0, p1;
+    auto fetch = [&](int g, float4& a0, float4& a1, unsigned& b0, unsigned& b1) {
+      const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
+      a0 = make_float4(inf, inf, inf, 0.f), a1 = a0, b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+      if (j0 < n) a0 = c.pts[j0], b0 = (unsigned)c.perm[j0];
+      if (j1 < n) a1 = c.pts[j1], b1 = (unsigned)c.perm[j1];
+    };
+    int g = -1;
+    if (gany) {
+      g = __builtin_ctzll(gany);
+      gany &= gany - 1;
+      fetch(g, d0, d1, p0, p1);
+    }
+    while (g >= 0) {
+      c0 = d0, c1 = d1, o0 = p0, o1 = p1;
+      unsigned long long qm = __ballot(((gneed >> g) & 1ull) != 0 && sub == 0);
+      g = -1;
+      if (gany) {
+        g = __builtin_ctzll(gany);
+        gany &= gany - 1;
+        fetch(g, d0, d1, p0, p1);
+      }
+      n_groups++;
+      while (qm) {
+        const int qq = __builtin_ctzll(qm);  // owner lane of the query
+        qm &= qm - 1;
+        n_pairs++;
+        const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
+        unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
+                                (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
+        const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
+        const unsigned long long k1 = ((unsigned long long)__float_as_uint(sqdist1(c1.x, c1.y, c1.z, qx, qy, qz)) << 32) | o1;
+        unsigned long long* row = lst + (qq / L) * KQ_STRIDE;
+        int cntq = __builtin_amdgcn_readlane(cnt, qq);
+        unsigned long long m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
+        if (cntq + __popcll(m0) + __popcll(m1) > KQ_CAP) {
+          // List full: tau becomes the k-th smallest key of (stored keys U this group's hits); only
+          // keys <= tau survive.  tau only decreases, so nothing of the final answer is ever dropped,
+          // and exactly k keys remain afterwards (keys are unique), which always fits.
+          const unsigned long long mine = lane < cntq ? row[lane] : ~0ull;  // KQ_CAP <= 64: one entry per lane
+          const unsigned long long h0 = k0 <= tk ? k0 : ~0ull, h1 = k1 <= tk ? k1 : ~0ull;
+          tk = wave_kth_smallest3(mine, h0, h1, k, idx_bits);
+          const unsigned long long keep = __ballot(mine <= tk);
+          if (mine <= tk) row[__popcll(keep & ((1ull << lane) - 1ull))] = mine;
+          cntq = __popcll(keep);
+          if (owner == qq) tau_hi = (unsigned)(tk >> 32), tau_lo = (unsigned)tk;
+          m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
+          n_compact++;
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int total = cntq + __popcll(m0) + __popcll(m1);
+        if (total > KQ_CAP) {  // impossible by construction (total == k after a tightening); never silently wrong
+          if (lane == 0) atomicExch(err_flag, 4);
+        } else {
+          if (k0 <= tk) row[cntq + __popcll(m0 & below)] = k0;
+          if (k1 <= tk) row[cntq + __popcll(m0) + __popcll(m1 & below)] = k1;
+          if (owner == qq) cnt = total;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (stats) { const long long t = clock64(); tB += t - tm, tm = t; }
+  if (stats && lane == 0) {
+    atomicAdd(stats + 4, (unsigned long long)n_groups), atomicAdd(stats + 7, 1ull);
+    atomicAdd(stats + 8, (unsigned long long)n_compact), atomicAdd(stats + 9, (unsigned long long)n_pairs);
+  }
+  if (!valid) return;  // whole groups leave together: the butterflies below never see a missing partner
+
+  // ---- C
+  unsigned long long e[EPL];
+  {
+    const unsigned long long* row = lst + slot * KQ_STRIDE;
+#pragma unroll
+    for (int t = 0; t < EPL; t++) {
+      const int a = sub + L * t;
+      e[t] = a < cnt ? row[a] : ~0ull;
+    }
+  }
+  // k rounds of selection in registers; the winners' indices go to LDS (the row is free: its keys are in e[])
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int* sel = (int*)(lst + slot * KQ_STRIDE);
+  {
+    unsigned long long lb = 0;  // keys below lb were taken in earlier rounds
+    for (int r = 0; r < k; r++) {
+      unsigned long long bk = ~0ull;
+#pragma unroll
+      for (int t = 0; t < EPL; t++) {
+        const unsigned long long x = e[t];
+        if (x >= lb && x < bk) bk = x;
+      }
+      bk = group_min_u64<L>(bk);
+      if (bk == ~0ull) {
+        atomicExch(err_flag, 2);
+        bk = (unsigned long long)(unsigned)i;  // keeps the gathers in range
+      }
+      lb = bk + 1ull;
+      if (sub == 0) sel[r] = (int)(unsigned)bk;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // gathers: lane sub fetches the neighbours of rank sub, sub+L, ... -- all loads in flight together
+  float4 nbv[KNN_NC / L];
+#pragma unroll
+  for (int t = 0; t < KNN_NC / L; t++) {
+    const int r = sub + L * t;
+    nbv[t] = q;
+    if (r < k) nbv[t] = c.opts[sel[r]];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float* nbl = (float*)(lst + slot * KQ_STRIDE);  // [rank][xyz], overwrites sel (already consumed)
+#pragma unroll
+  for (int t = 0; t < KNN_NC / L; t++) {
+    const int r = sub + L * t;
+    if (r < k) nbl[3 * r] = nbv[t].x, nbl[3 * r + 1] = nbv[t].y, nbl[3 * r + 2] = nbv[t].z;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // moments in rank order (every lane of the query computes the same sums)
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  for (int r = 0; r < k; r++) {
+    const double x = (double)nbl[3 * r] - (double)q.x, y = (double)nbl[3 * r + 1] - (double)q.y, z = (double)nbl[3 * r + 2] - (double)q.z;
+    s1x += x, s1y += y, s1z += z;
+    sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+  }
+  if (stats && lane == 0) { tC = clock64() - tm; atomicAdd(stats + 10, (unsigned long long)tA), atomicAdd(stats + 11, (unsigned long long)tG), atomicAdd(stats + 12, (unsigned long long)tB), atomicAdd(stats + 13, (unsigned long long)tC); }
+  if (sub != 0) return;
+  const double ik = 1.0 / (double)k;
+  const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
+  Sym3 pc;
+  pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
+  pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
+  Sym3 out;
+  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+  double* cov = c.cov;
+  cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
+}
+
+// ----------------------------------------------------------------------------------------------
 // block reduction of R doubles per lane: DPP wave reduction (no LDS traffic), then LDS across the
 // block's waves.  Fixed order -> bitwise reproducible (the reference's per-thread slots are not, A:262-269).
 //
@@ -959,6 +1263,127 @@ __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][
   __syncthreads();
 }
 
+// The per-point part of update_correspondences + linearize (A:137-258) once the 1-NN search has produced the
+// minimum distance m and the chunk it was found in: exact index, gate, APD covariance, RCR^-1, e, J, H, b.
+// acc[29] receives this point's contribution (zero when it has no correspondence).
+__device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
+                                                int want_Hb, int pair, int i, const float4 p, float ptx, float pty, float ptz, float m,
+                                                unsigned chunk, bool tie, double* acc) {
+  const int N = src.n, M = tgt.n;
+  int j = -1;
+  if (chunk != kNoChunk) {
+    // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
+    int jorig = 0x7fffffff;
+    if (!tie) {
+      float4 t[kChunk];
+#pragma unroll
+      for (int jj = 0; jj < kChunk; jj++) {
+        const int g = (int)chunk * kChunk + jj;
+        t[jj] = tgt.pts[g < M ? g : M - 1];
+      }
+#pragma unroll
+      for (int jj = 0; jj < kChunk; jj++) {
+        const int g = (int)chunk * kChunk + jj;
+        const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
+        if (g < M && d == m) {
+          const int o = tgt.perm[g];
+          if (o < jorig) jorig = o, j = g;
+        }
+      }
+    } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
+      for (int g = 0; g < M; g++) {
+        const float4 t = tgt.pts[g];
+        if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
+          const int o = tgt.perm[g];
+          if (o < jorig) jorig = o, j = g;
+        }
+      }
+    }
+  }
+  w.sqd[(size_t)pair * w.nstride + i] = m;
+  w.nnidx[(size_t)pair * w.nstride + i] = j;
+  const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
+  w.corr[(size_t)pair * w.nstride + i] = corr;
+  if (corr >= 0) {
+    const double* ca = src.cov;
+    const double* cb = tgt.cov;
+    const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
+    const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
+    // APD sensor-noise covariance from the transformed point (A:167-184)
+    const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
+    const double aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
+    const double cos_aoa = cos(aoa);
+    const double s_x = dist * cst.dist_var / 400;
+    const double s_y = dist * cst.sin_az / cos_aoa;
+    const double s_z = dist * cst.sin_el / cos_aoa;
+    const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
+    const double azimuth = (double)atan2f(pty, ptx);
+    double ce, se, caz, saz;
+    sincos(elevation, &se, &ce);
+    sincos(azimuth, &saz, &caz);
+    // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
+    const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
+    const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
+    const double a20 = -se * s_x, a22 = ce * s_z;  // a21 = 0
+    Sym3 cd;
+    cd.xx = a00 * a00 + a01 * a01 + a02 * a02;
+    cd.xy = a00 * a10 + a01 * a11 + a02 * a12;
+    cd.xz = a00 * a20 + a02 * a22;
+    cd.yy = a10 * a10 + a11 * a11 + a12 * a12;
+    cd.yz = a10 * a20 + a12 * a22;
+    cd.zz = a20 * a20 + a22 * a22;
+    if (cst.plain_gicp) cd = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T
+    const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
+    const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
+    double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
+    mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
+    mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
+
+    const float4 q = tgt.pts[corr];
+    const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
+    const double vx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];   // transed_mean_A, A:236
+    const double vy = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+    const double vz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+    const double ex = (double)q.x - vx, ey = (double)q.y - vy, ez = (double)q.z - vz;  // A:237
+    const double mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
+    const double mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
+    const double mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
+    acc[27] = ex * mex + ey * mey + ez * mez;  // A:240
+    acc[28] = 1.0;
+    if (want_Hb) {
+      // J = [skew(v) | -I] (A:248-250).  MA = M * skew(v), columns:
+      const double m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;     // MA[:,0]
+      const double m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;  // MA[:,1]
+      const double m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;     // MA[:,2]
+      // H upper triangle, row-major order (0,0),(0,1)...(0,5),(1,1)...(5,5)
+      // rotation block skew^T M skew: row p = skew[:,p] . MA[:,q]
+      acc[0] = vz * m0y - vy * m0z;    // (0,0)
+      acc[1] = vz * m1y - vy * m1z;    // (0,1)
+      acc[2] = vz * m2y - vy * m2z;    // (0,2)
+      acc[3] = -m0x;                   // (0,3) = -(MA)[0][0]   (top-right block = -MA^T)
+      acc[4] = -m0y;                   // (0,4) = -(MA)[1][0]
+      acc[5] = -m0z;                   // (0,5)
+      acc[6] = -vz * m1x + vx * m1z;   // (1,1)
+      acc[7] = -vz * m2x + vx * m2z;   // (1,2)
+      acc[8] = -m1x;                   // (1,3)
+      acc[9] = -m1y;                   // (1,4)
+      acc[10] = -m1z;                  // (1,5)
+      acc[11] = vy * m2x - vx * m2y;   // (2,2)
+      acc[12] = -m2x;                  // (2,3)
+      acc[13] = -m2y;                  // (2,4)
+      acc[14] = -m2z;                  // (2,5)
+      acc[15] = Mi.xx, acc[16] = Mi.xy, acc[17] = Mi.xz;  // (3,3),(3,4),(3,5)
+      acc[18] = Mi.yy, acc[19] = Mi.yz;                   // (4,4),(4,5)
+      acc[20] = Mi.zz;                                    // (5,5)
+      // b = J^T M e : rotation part skew^T (Me), translation part -(Me)   (A:254)
+      acc[21] = vz * mey - vy * mez;
+      acc[22] = -vz * mex + vx * mez;
+      acc[23] = vy * mex - vx * mey;
+      acc[24] = -mex, acc[25] = -mey, acc[26] = -mez;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_linearize: one lane per source point.  Merges the split partials, re-scans the winning chunk
 // for the exact correspondence, applies the gate (A:156), builds the APD covariance (A:167-184),
@@ -966,7 +1391,8 @@ __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][
 // 21+6+1 sums per block.  fp64 throughout after the NN, as in the reference.
 constexpr int LIN_BLK = 256;
 
-__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid);
+__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
+                                              double* stage = nullptr);
 __device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
 
 // Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  Every block
@@ -999,7 +1425,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
-  const int N = src.n, M = tgt.n, tid = threadIdx.x;
+  const int N = src.n, tid = threadIdx.x;
   if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
   const Rigid T = st[pair].x0;
@@ -1030,118 +1456,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     load_Tf(T, Tf);
     const float4 p = src.pts[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
-    int j = -1;
-    if (chunk != kNoChunk) {
-      // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
-      int jorig = 0x7fffffff;
-      if (!tie) {
-        float4 t[kChunk];
-#pragma unroll
-        for (int jj = 0; jj < kChunk; jj++) {
-          const int g = (int)chunk * kChunk + jj;
-          t[jj] = tgt.pts[g < M ? g : M - 1];
-        }
-#pragma unroll
-        for (int jj = 0; jj < kChunk; jj++) {
-          const int g = (int)chunk * kChunk + jj;
-          const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
-          if (g < M && d == m) {
-            const int o = tgt.perm[g];
-            if (o < jorig) jorig = o, j = g;
-          }
-        }
-      } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
-        for (int g = 0; g < M; g++) {
-          const float4 t = tgt.pts[g];
-          if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
-            const int o = tgt.perm[g];
-            if (o < jorig) jorig = o, j = g;
-          }
-        }
-      }
-    }
-    w.sqd[(size_t)pair * w.nstride + i] = m;
-    w.nnidx[(size_t)pair * w.nstride + i] = j;
-    const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
-    w.corr[(size_t)pair * w.nstride + i] = corr;
-    if (corr >= 0) {
-      const double* ca = src.cov;
-      const double* cb = tgt.cov;
-      const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
-      const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
-      // APD sensor-noise covariance from the transformed point (A:167-184)
-      const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
-      const double aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
-      const double cos_aoa = cos(aoa);
-      const double s_x = dist * cst.dist_var / 400;
-      const double s_y = dist * cst.sin_az / cos_aoa;
-      const double s_z = dist * cst.sin_el / cos_aoa;
-      const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
-      const double azimuth = (double)atan2f(pty, ptx);
-      double ce, se, caz, saz;
-      sincos(elevation, &se, &ce);
-      sincos(azimuth, &saz, &caz);
-      // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
-      const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
-      const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
-      const double a20 = -se * s_x, a22 = ce * s_z;  // a21 = 0
-      Sym3 cd;
-      cd.xx = a00 * a00 + a01 * a01 + a02 * a02;
-      cd.xy = a00 * a10 + a01 * a11 + a02 * a12;
-      cd.xz = a00 * a20 + a02 * a22;
-      cd.yy = a10 * a10 + a11 * a11 + a12 * a12;
-      cd.yz = a10 * a20 + a12 * a22;
-      cd.zz = a20 * a20 + a22 * a22;
-      if (cst.plain_gicp) cd = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T
-      const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
-      const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
-      double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
-      mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
-      mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
-
-      const float4 q = tgt.pts[corr];
-      const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
-      const double vx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];   // transed_mean_A, A:236
-      const double vy = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
-      const double vz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
-      const double ex = (double)q.x - vx, ey = (double)q.y - vy, ez = (double)q.z - vz;  // A:237
-      const double mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
-      const double mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
-      const double mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
-      acc[27] = ex * mex + ey * mey + ez * mez;  // A:240
-      acc[28] = 1.0;
-      if (want_Hb) {
-        // J = [skew(v) | -I] (A:248-250).  MA = M * skew(v), columns:
-        const double m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;     // MA[:,0]
-        const double m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;  // MA[:,1]
-        const double m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;     // MA[:,2]
-        // H upper triangle, row-major order (0,0),(0,1)...(0,5),(1,1)...(5,5)
-        // rotation block skew^T M skew: row p = skew[:,p] . MA[:,q]
-        acc[0] = vz * m0y - vy * m0z;    // (0,0)
-        acc[1] = vz * m1y - vy * m1z;    // (0,1)
-        acc[2] = vz * m2y - vy * m2z;    // (0,2)
-        acc[3] = -m0x;                   // (0,3) = -(MA)[0][0]   (top-right block = -MA^T)
-        acc[4] = -m0y;                   // (0,4) = -(MA)[1][0]
-        acc[5] = -m0z;                   // (0,5)
-        acc[6] = -vz * m1x + vx * m1z;   // (1,1)
-        acc[7] = -vz * m2x + vx * m2z;   // (1,2)
-        acc[8] = -m1x;                   // (1,3)
-        acc[9] = -m1y;                   // (1,4)
-        acc[10] = -m1z;                  // (1,5)
-        acc[11] = vy * m2x - vx * m2y;   // (2,2)
-        acc[12] = -m2x;                  // (2,3)
-        acc[13] = -m2y;                  // (2,4)
-        acc[14] = -m2z;                  // (2,5)
-        acc[15] = Mi.xx, acc[16] = Mi.xy, acc[17] = Mi.xz;  // (3,3),(3,4),(3,5)
-        acc[18] = Mi.yy, acc[19] = Mi.yz;                   // (4,4),(4,5)
-        acc[20] = Mi.zz;                                    // (5,5)
-        // b = J^T M e : rotation part skew^T (Me), translation part -(Me)   (A:254)
-        acc[21] = vz * mey - vy * mez;
-        acc[22] = -vz * mex + vx * mez;
-        acc[23] = vy * mex - vx * mey;
-        acc[24] = -mex, acc[25] = -mey, acc[26] = -mez;
-      }
-    }
+    linearize_point(src, tgt, T, w, cst, want_Hb, pair, i, p, ptx, pty, ptz, m, chunk, tie, acc);
   }
   block_reduce<29, LIN_BLK>(acc, red, tid);
   if (tid < 29) {
@@ -1231,11 +1546,26 @@ __device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok
 }
 
 // sums the block partials of k_linearize in block order (deterministic) into s.H / s.b / s.y0
-__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid) {
-  if (tid < 29) {
+// stage (optional, kGatherRows * kRed doubles of LDS, 64-thread callers only): the rows are fetched with
+// coalesced loads that are all in flight together, kGatherRows at a time, and summed out of LDS -- the
+// same order of additions without one memory round trip per row.
+constexpr int kGatherRows = 128;
+__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid, double* stage = nullptr) {
+  const double* p = w.blkpart + (size_t)pair * w.nblk_max * kRed;
+  if (stage) {
     double v = 0.0;
-    const double* p = w.blkpart + (size_t)pair * w.nblk_max * kRed + tid;
-    for (int b = 0; b < nblk; b++) v += p[(size_t)b * kRed];
+    for (int b0 = 0; b0 < nblk; b0 += kGatherRows) {
+      const int rows = min(kGatherRows, nblk - b0), cnt = rows * kRed;
+      __syncthreads();
+      for (int e = tid; e < cnt; e += 64) stage[e] = p[(size_t)b0 * kRed + e];
+      __syncthreads();
+      if (tid < 29)
+        for (int b = 0; b < rows; b++) v += stage[b * kRed + tid];
+    }
+    if (tid < 29) lds[tid] = v;
+  } else if (tid < 29) {
+    double v = 0.0;
+    for (int b = 0; b < nblk; b++) v += p[(size_t)b * kRed + tid];
     lds[tid] = v;
   }
   __syncthreads();
@@ -1251,8 +1581,9 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 
 // after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
 // block (>= 64 threads, uniformly); lds: >= 32 doubles.
-__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid) {
-  gather_linearize(s, w, pair, nblk, lds, tid);
+__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
+                                              double* stage) {
+  gather_linearize(s, w, pair, nblk, lds, tid, stage);
   if (tid != 0) return;
   s.n_lin += 1;
   if (c.optimizer == 1) {  // step_gn
@@ -1319,12 +1650,13 @@ __device__ __forceinline__ void state_copy(double* dst, const double* src, int t
 __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
   __shared__ double lds[32];
   __shared__ PairState ls;
+  __shared__ double stage[kGatherRows * kRed];
   const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_LIN) return;
   const int N = clouds[pairs[pair].src].n;
   state_copy((double*)&ls, (const double*)&st[pair], tid);
   __syncthreads();
-  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid);
+  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid, stage);
   __syncthreads();
   state_copy((double*)&st[pair], (const double*)&ls, tid);
 }

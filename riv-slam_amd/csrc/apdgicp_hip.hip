@@ -44,12 +44,6 @@ void identity16(float* g) {
   g[0] = g[5] = g[10] = g[15] = 1.f;
 }
 
-Rigid rigid_from_colmajor(const double* T) {
-  Rigid r;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 4; j++) r.m[4 * i + j] = T[i + 4 * j];
-  return r;
-}
 void rigid_to_colmajor(const Rigid& r, double* T) {
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 4; j++) T[i + 4 * j] = r.m[4 * i + j];
