@@ -216,6 +216,30 @@ int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_l
  * [4..9] covariance k-NN: groups, chunks tested, chunks scanned, waves, sweep rounds, candidates kept */
 int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]);
 
+/* ------------------------------------------------------------------ scan-to-submap target assembly
+ * The step in front of registration_s2m->setInputTarget in scan-to-map mode
+ * (scan_matching_odometry_nodelet.cpp:606-618): the clouds of the last <= max_submap_frames keyframes are
+ * transformed by their poses relative to the newest keyframe (pcl::transformPointCloud with a Matrix4d),
+ * concatenated, and downsampled by downsample() (:412-422) -- pcl::VoxelGrid with the configured leaf
+ * (preprocessing_nodelet.cpp:137-144, "VOXELGRID").  Everything stays on the device; the result can be handed to
+ * apdgicp_set_target / apdgicp_batch_set_cloud as a device pointer (16-byte stride). */
+typedef struct apdgicp_submap apdgicp_submap;
+int apdgicp_submap_create(int device, void* stream, apdgicp_submap** out);
+int apdgicp_submap_destroy(apdgicp_submap* s);
+/* xyz[c]: first coordinate of cloud c (n_points[c] points, stride_bytes apart, host or device memory as on_device says);
+ * intensity_offset_bytes: distance from a point's x to its intensity field (16 for pcl::PointXYZI), < 0: none (0 is kept);
+ * rel_poses: n_clouds x 16 doubles, column-major 4x4 (keyframes[i].odom^-1 * keyframes.back().odom, :609), NULL = identity;
+ * leaf: voxel size per axis (downsample_resolution), NULL or leaf[0] <= 0: no downsampling (downsample_method NONE);
+ * n_out: number of points of the assembled cloud.  Non-finite points are skipped by the voxel filter, as PCL does for
+ * non-dense clouds.  Fails with APDGICP_ERR_UNSUPPORTED when the leaf is too small for the extent (PCL's
+ * "Leaf size is too small" warning, where it returns the input unfiltered). */
+int apdgicp_submap_assemble(apdgicp_submap* s, int n_clouds, const void* const* xyz, const int64_t* n_points, int64_t stride_bytes,
+                            int64_t intensity_offset_bytes, int on_device, const double* rel_poses, const float* leaf, int64_t* n_out);
+/* device pointer to the last assembled cloud: n points of {x, y, z, intensity} floats, valid until the next assemble */
+int apdgicp_submap_points(apdgicp_submap* s, const float** device_xyzi, int64_t* n);
+/* copies the last assembled cloud ({x, y, z, intensity} per point) into caller memory */
+int apdgicp_submap_copy(apdgicp_submap* s, float* dst_xyzi, int64_t capacity_points, int dst_on_device);
+
 #ifdef __cplusplus
 }
 #endif

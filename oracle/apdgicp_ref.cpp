@@ -747,4 +747,88 @@ int ref_knn_kdtree(void* h, int which, const float* q, int k, int* out_idx, floa
   for (int i = 0; i < (int)heap.size(); i++) out_idx[i] = heap[i].idx, out_d[i] = heap[i].d;
   return (int)heap.size();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Scan-to-submap target assembly, restated from
+//   /root/reference/radar_graph_slam/apps/scan_matching_odometry_nodelet.cpp:606-618 (transform + concatenate)
+//   and :412-422 (downsample() -> pcl::VoxelGrid, preprocessing_nodelet.cpp:137-144)
+// PCL is not part of the reference tree (ROS noetic: PCL 1.10); its algorithm as published:
+//   common/impl/transforms.hpp  detail::Transformer<double>::se3   out = (float)(m00*x + m01*y + m02*z + m03) in double
+//   filters/impl/voxel_grid.hpp VoxelGrid<PointT>::applyFilter      getMinMax3D over finite points, inverse_leaf = 1/leaf
+//       (float), min_b = floor(min*inverse_leaf), div_b = max_b - min_b + 1, idx = ijk . (1, div_b.x, div_b.x*div_b.y),
+//       std::sort on idx (operator< compares idx only), one CentroidPoint (float sums of x, y, z, intensity, then / n)
+//       per run of equal idx, in ascending idx; "Leaf size is too small" when dx*dy*dz > INT_MAX (returns -1 here).
+// clouds: n_clouds arrays of n[c] x 4 floats {x, y, z, intensity}; poses: n_clouds x 16 doubles column-major (null: identity);
+// out: room for sum(n) x 4 floats; out_idx / out_cnt (optional): voxel index and population of every output point.
+struct VoxIdx {
+  unsigned idx, pt;
+  bool operator<(const VoxIdx& o) const { return idx < o.idx; }
+};
+long long ref_submap_assemble(int n_clouds, const float* const* clouds, const long long* n, const double* poses, const float* leaf, float* out,
+                              int* out_idx, int* out_cnt) {
+  std::vector<float> cat;  // x, y, z, intensity
+  for (int c = 0; c < n_clouds; c++) {
+    double T[16];
+    for (int q = 0; q < 16; q++) T[q] = poses ? poses[16 * c + q] : (q % 5 == 0 ? 1.0 : 0.0);
+    for (long long i = 0; i < n[c]; i++) {
+      const float* p = clouds[c] + 4 * i;
+      const double x = p[0], y = p[1], z = p[2];
+      cat.push_back((float)(T[0] * x + T[4] * y + T[8] * z + T[12]));
+      cat.push_back((float)(T[1] * x + T[5] * y + T[9] * z + T[13]));
+      cat.push_back((float)(T[2] * x + T[6] * y + T[10] * z + T[14]));
+      cat.push_back(p[3]);
+    }
+  }
+  const long long N = (long long)cat.size() / 4;
+  if (!leaf || !(leaf[0] > 0.f)) {  // downsample(): no filter configured -> the cloud itself
+    std::memcpy(out, cat.data(), cat.size() * sizeof(float));
+    return N;
+  }
+  const float inv[3] = {1.f / leaf[0], 1.f / leaf[1], 1.f / leaf[2]};
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  bool any = false;
+  for (long long i = 0; i < N; i++) {
+    const float* p = &cat[4 * i];
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    any = true;
+    for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], p[a]), mx[a] = std::max(mx[a], p[a]);
+  }
+  if (!any) return 0;
+  long long d[3];
+  int min_b[3], div_b[3];
+  for (int a = 0; a < 3; a++) {
+    d[a] = (long long)((mx[a] - mn[a]) * inv[a]) + 1;
+    min_b[a] = (int)std::floor(mn[a] * inv[a]);
+    div_b[a] = (int)std::floor(mx[a] * inv[a]) - min_b[a] + 1;
+  }
+  if ((double)d[0] * (double)d[1] * (double)d[2] > (double)INT32_MAX) return -1;  // PCL multiplies in int64 (wraps for absurd leaves)
+  const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+  std::vector<VoxIdx> iv;
+  iv.reserve(N);
+  for (long long i = 0; i < N; i++) {
+    const float* p = &cat[4 * i];
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    const int i0 = (int)std::floor(p[0] * inv[0]) - min_b[0], i1 = (int)std::floor(p[1] * inv[1]) - min_b[1],
+              i2 = (int)std::floor(p[2] * inv[2]) - min_b[2];
+    iv.push_back(VoxIdx{(unsigned)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), (unsigned)i});
+  }
+  std::sort(iv.begin(), iv.end(), std::less<VoxIdx>());
+  long long nout = 0;
+  for (size_t a = 0; a < iv.size();) {
+    size_t b = a;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+    while (b < iv.size() && iv[b].idx == iv[a].idx) {
+      const float* p = &cat[4 * (size_t)iv[b].pt];
+      sx += p[0], sy += p[1], sz += p[2], sw += p[3];
+      b++;
+    }
+    const float fn = (float)(b - a);
+    out[4 * nout] = sx / fn, out[4 * nout + 1] = sy / fn, out[4 * nout + 2] = sz / fn, out[4 * nout + 3] = sw / fn;
+    if (out_idx) out_idx[nout] = (int)iv[a].idx;
+    if (out_cnt) out_cnt[nout] = (int)(b - a);
+    nout++;
+    a = b;
+  }
+  return nout;
+}
 }

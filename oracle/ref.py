@@ -75,6 +75,8 @@ def lib():
         L.ref_get_final_hessian.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_knn_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_knn_kdtree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_submap_assemble.restype = C.c_longlong
+        L.ref_submap_assemble.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -189,3 +191,28 @@ class RefAPDGICP:
         qq = np.ascontiguousarray(q, dtype=np.float32)
         n = self.L.ref_knn_kdtree(self.h, 0 if which == "source" else 1, _ptr(qq), k, _ptr(idx), _ptr(d))
         return idx[:n], d[:n]
+
+
+def submap_assemble(clouds, rel_poses=None, leaf=None):
+    """scan_matching_odometry_nodelet.cpp:606-618 + downsample() (:412-422) on the CPU.
+    clouds: list of [n, 4] float32 {x, y, z, intensity}; rel_poses: list of 4x4 (row-major numpy) or None;
+    leaf: float or 3 floats or None.  Returns (points [m, 4] float32, voxel index [m], population [m])."""
+    L = lib()
+    cs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 4) for c in clouds]
+    ptrs = (C.c_void_p * len(cs))(*[c.ctypes.data for c in cs])
+    ns = np.array([c.shape[0] for c in cs], dtype=np.int64)
+    poses = None
+    if rel_poses is not None:
+        poses = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T.reshape(-1) for T in rel_poses]))
+    lf = None
+    if leaf is not None:
+        lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, dtype=np.float32), (3,)))
+    total = int(ns.sum())
+    out = np.empty((max(total, 1), 4), dtype=np.float32)
+    idx = np.zeros(max(total, 1), dtype=np.int32)
+    cnt = np.zeros(max(total, 1), dtype=np.int32)
+    m = L.ref_submap_assemble(len(cs), ptrs, _ptr(ns), _ptr(poses) if poses is not None else None,
+                              _ptr(lf) if lf is not None else None, _ptr(out), _ptr(idx), _ptr(cnt))
+    if m < 0:
+        raise RuntimeError("Leaf size is too small for the input dataset")
+    return out[:m].copy(), idx[:m].copy(), cnt[:m].copy()

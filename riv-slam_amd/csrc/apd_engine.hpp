@@ -113,6 +113,7 @@ class Engine {
   // batch state
   int npairs = 0, nmax_src = 0;
   std::vector<PairDesc> h_pairs;
+  std::vector<CloudDesc> h_desc;  // host copy of the descriptor table (valid while !desc_dirty)
   std::vector<float> h_guesses;
   DevBuf d_state, d_results, d_status, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
@@ -387,7 +388,8 @@ class Engine {
   int upload_desc() {
     APD_TRY(sort_clouds());
     if (!desc_dirty) return 0;
-    std::vector<CloudDesc> h(clouds.size());
+    std::vector<CloudDesc>& h = h_desc;
+    h.resize(clouds.size());
     for (size_t i = 0; i < clouds.size(); i++) {
       if (clouds[i].n > 0) APD_TRY(clouds[i].cov.ensure((size_t)clouds[i].n * 6 * sizeof(double)));
       h[i].pts = clouds[i].pts.as<float4>();
@@ -485,7 +487,7 @@ class Engine {
       const int s = pairs[i].source_cloud, t = pairs[i].target_cloud;
       if (s < 0 || t < 0 || s >= (int)clouds.size() || t >= (int)clouds.size() || clouds[s].n <= 0 || clouds[t].n <= 0)
         return fail(APDGICP_ERR_NO_INPUT, "pair references a cloud that is not set");
-      h_pairs[i] = PairDesc{s, t};
+      h_pairs[i].src = s, h_pairs[i].tgt = t;
       memcpy(&guesses[(size_t)i * 16], pairs[i].guess, 16 * sizeof(float));
       need.push_back(s), need.push_back(t);
       nmax_src = std::max(nmax_src, clouds[s].n);
@@ -495,6 +497,7 @@ class Engine {
     defer_errflag = false;
     APD_TRY(rc_cov);
     APD_TRY(upload_desc());
+    for (int64_t i = 0; i < n; i++) h_pairs[i].s = h_desc[h_pairs[i].src], h_pairs[i].t = h_desc[h_pairs[i].tgt];
     npairs = (int)n;
     if ((size_t)n * sizeof(PairState) > d_state.cap) APD_HIP(hipStreamSynchronize(stream));
     APD_TRY(d_state.ensure(n * sizeof(PairState)));

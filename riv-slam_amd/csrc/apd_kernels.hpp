@@ -41,6 +41,7 @@ struct CloudDesc {
 
 struct PairDesc {
   int src, tgt;
+  CloudDesc s, t;  // copies of clouds[src] / clouds[tgt]: one hop from the pair index to every pointer a kernel needs
 };
 
 struct Consts {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
   const int pair = w.pair0 + blockIdx.z;
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
-  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, M = tgt.n, tid = threadIdx.x;
   const int base = blockIdx.x * (NN_BLK * S);
   if (base >= N) return;
@@ -456,6 +457,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// wave-wide min / max through DPP (row_shr 1,2,4,8, row_bcast 15/31; lanes without a source keep their own value),
+// result read from lane 63 into an SGPR: uniform, no LDS traffic
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_uniform(float v) {
+  auto step = [](float x, float o) { return MAX ? fmaxf(x, o) : fminf(x, o); };
+#define APD_DPP_F(ctrl, rmask) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), ctrl, rmask, 0xf, false))
+  v = step(v, APD_DPP_F(0x111, 0xf));
+  v = step(v, APD_DPP_F(0x112, 0xf));
+  v = step(v, APD_DPP_F(0x114, 0xf));
+  v = step(v, APD_DPP_F(0x118, 0xf));
+  v = step(v, APD_DPP_F(0x142, 0xa));
+  v = step(v, APD_DPP_F(0x143, 0xc));
+#undef APD_DPP_F
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
 // one wave stages one 128-target group into its LDS tile: lane l loads targets 2l, 2l+1, and lanes
 // 0..47 the group's 8 chunk boxes (48 consecutive floats)
 template <bool WITH_PERM = false>
@@ -496,14 +513,27 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   __shared__ float cbl[6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
   const int pair = w.pair0 + blockIdx.y;
-  if (st[pair].status != ST_NEED_LIN) return;
+  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
-  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const Rigid T0 = st[pair].x0;
+  if (status != ST_NEED_LIN) return;
+  const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, M = tgt.n, lane = threadIdx.x;
   const int base = blockIdx.x * (64 * S);
   if (base >= N) return;
+  const bool tstat = w.stats && (blockIdx.x & 15) == 0;
+  long long tcy[4] = {0, 0, 0, 0}, tm = tstat ? clock64() : 0;
   float Tf[12];
-  load_Tf(st[pair].x0, Tf);
+  load_Tf(T0, Tf);
+  const int ngroups = (M + kGroupPts - 1) / kGroupPts;
+  const int nchunks = (M + kChunk - 1) / kChunk;
+  // boxes of the first 64 target groups: requested now, parked in registers, written to LDS after the warm start
+  float gpre[6];
+#pragma unroll
+  for (int u = 0; u < 6; u++) {
+    const int e = u * 64 + lane;
+    gpre[u] = e < 6 * min(64, ngroups) ? ((const float*)tgt.gbox)[e] : 0.f;
+  }
   const float inf = __builtin_inff();
 
   // Warm start: the neighbour found by the previous iteration is a real target point, so its
@@ -529,8 +559,19 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
     }
   }
   all_hinted = __all(all_hinted);
-  const int ngroups = (M + kGroupPts - 1) / kGroupPts;
-  const int nchunks = (M + kChunk - 1) / kChunk;
+  // bounding box of this wave's (transformed) points
+  Box wbox;
+  {
+    float lx = px[0], ly = py[0], lz = pz[0], hx = px[0], hy = py[0], hz = pz[0];
+#pragma unroll
+    for (int s = 1; s < S; s++) {
+      lx = fminf(lx, px[s]), ly = fminf(ly, py[s]), lz = fminf(lz, pz[s]);
+      hx = fmaxf(hx, px[s]), hy = fmaxf(hy, py[s]), hz = fmaxf(hz, pz[s]);
+    }
+    wbox = Box{wave_minmax_uniform<false>(lx), wave_minmax_uniform<false>(ly), wave_minmax_uniform<false>(lz),
+               wave_minmax_uniform<true>(hx), wave_minmax_uniform<true>(hy), wave_minmax_uniform<true>(hz)};
+  }
+  if (tstat) { const long long t = clock64(); tcy[0] += t - tm, tm = t; }
 
   unsigned n_groups = 0, n_ctest = 0, n_cscan = 0;
   // registers of the group in flight: loaded from L2 while the previous group is scanned out of LDS
@@ -598,7 +639,11 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
     const int nbb = min(GB_BATCH, ngroups - gb0);
     __syncthreads();
-    for (int e = lane; e < 6 * nbb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
+    if (gb0 == 0) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) gbl[u * 64 + lane] = gpre[u];
+    }
+    for (int e = (gb0 == 0 ? 6 * 64 : 0) + lane; e < 6 * nbb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
     __syncthreads();
     for (int sb = 0; sb < nbb; sb += 64) {  // 64 groups at a time: their need bits fit one mask
       const int nb = min(64, nbb - sb);
@@ -622,17 +667,32 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
           scan_tile(g0 + seed);
         }
       }
-      // candidate groups with the bounds known now (4 tests per trip keep the LDS reads in flight); a
-      // candidate is re-tested against the then-current `best` just before its scan
+      // candidate groups with the bounds known now; a candidate is re-tested against the then-current
+      // `best` just before its scan.  First one test per LANE: group `lane` against the box of all points of
+      // this wave with the wave's largest radius (a lower bound of every per-point bound, so it only removes
+      // groups no lane needs); the per-point tests then run on the few survivors, 4 per trip.
+      float rad = best[0];
+#pragma unroll
+      for (int s = 1; s < S; s++) rad = fmaxf(rad, best[s]);
+      rad = wave_minmax_uniform<true>(rad);
+      unsigned long long pre = nb < 64 ? (1ull << nb) - 1ull : ~0ull;
+      if (rad < inf) pre &= __ballot(lb_box_box(wbox, lds_box(boxes, min(lane, nb - 1))) <= rad);
       unsigned long long cand = 0;
-      for (int g = 0; g < nb; g += 4) {
+      while (pre) {
+        int gq[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int gg = min(g + u, nb - 1);
+          gq[u] = pre ? __builtin_ctzll(pre) : -1;
+          if (pre) pre &= pre - 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int gg = gq[u] >= 0 ? gq[u] : gq[0];
           if (__any(lane_needs(lds_box(boxes, gg)))) cand |= 1ull << gg;
         }
       }
       if (seed >= 0) cand &= ~(1ull << seed);
+      if (tstat) { const long long t = clock64(); tcy[1] += t - tm, tm = t; }
       // software pipeline: group k+1 travels L2 -> registers while group k is scanned out of LDS
       int cur = cand ? __builtin_ctzll(cand) : -1;
       if (cur >= 0) {
@@ -651,6 +711,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
       }
     }
   }
+  if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -660,6 +721,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   if (w.stats && lane == 0) {
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
     atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
+    if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);
   }
 }
 
@@ -1276,19 +1338,18 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     int jorig = 0x7fffffff;
     if (!tie) {
       float4 t[kChunk];
+      int po[kChunk];  // original indices, fetched with the points (no dependent load behind the distance test)
 #pragma unroll
       for (int jj = 0; jj < kChunk; jj++) {
         const int g = (int)chunk * kChunk + jj;
         t[jj] = tgt.pts[g < M ? g : M - 1];
+        po[jj] = tgt.perm[g < M ? g : M - 1];
       }
 #pragma unroll
       for (int jj = 0; jj < kChunk; jj++) {
         const int g = (int)chunk * kChunk + jj;
         const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
-        if (g < M && d == m) {
-          const int o = tgt.perm[g];
-          if (o < jorig) jorig = o, j = g;
-        }
+        if (g < M && d == m && po[jj] < jorig) jorig = po[jj], j = g;
       }
     } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
       for (int g = 0; g < M; g++) {
@@ -1392,7 +1453,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
 constexpr int LIN_BLK = 256;
 
 __device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
-                                              double* stage = nullptr);
+                                              double* stage = nullptr, int prestaged = 0);
 __device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
 
 // Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  Every block
@@ -1422,13 +1483,14 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
   const int pair = w.pair0 + blockIdx.y;
-  if (st[pair].status != ST_NEED_LIN) return;
+  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
-  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const Rigid T = st[pair].x0;
+  if (status != ST_NEED_LIN) return;
+  const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
   if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
-  const Rigid T = st[pair].x0;
 
   double acc[29];
 #pragma unroll
@@ -1479,7 +1541,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   const int pair = w.pair0 + blockIdx.y;
   if (st[pair].status != ST_NEED_ERR) return;
   const PairDesc pd = pairs[pair];
-  const CloudDesc src = clouds[pd.src], tgt = clouds[pd.tgt];
+  const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
   if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
@@ -1550,14 +1612,21 @@ __device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok
 // coalesced loads that are all in flight together, kGatherRows at a time, and summed out of LDS -- the
 // same order of additions without one memory round trip per row.
 constexpr int kGatherRows = 128;
-__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid, double* stage = nullptr) {
+__device__ __forceinline__ void stage_rows(double* stage, const double* p, int b0, int rows, int tid) {
+  for (int e = tid; e < rows * kRed; e += 64) stage[e] = p[(size_t)b0 * kRed + e];
+}
+// prestaged: rows [0, prestaged) are already in `stage` (the caller fetched them together with its other start-up loads)
+__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid, double* stage = nullptr,
+                                                 int prestaged = 0) {
   const double* p = w.blkpart + (size_t)pair * w.nblk_max * kRed;
   if (stage) {
     double v = 0.0;
     for (int b0 = 0; b0 < nblk; b0 += kGatherRows) {
-      const int rows = min(kGatherRows, nblk - b0), cnt = rows * kRed;
-      __syncthreads();
-      for (int e = tid; e < cnt; e += 64) stage[e] = p[(size_t)b0 * kRed + e];
+      const int rows = min(kGatherRows, nblk - b0);
+      if (b0 > 0 || prestaged < rows) {
+        __syncthreads();
+        stage_rows(stage, p, b0, rows, tid);
+      }
       __syncthreads();
       if (tid < 29)
         for (int b = 0; b < rows; b++) v += stage[b * kRed + tid];
@@ -1582,8 +1651,8 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 // after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
 // block (>= 64 threads, uniformly); lds: >= 32 doubles.
 __device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
-                                              double* stage) {
-  gather_linearize(s, w, pair, nblk, lds, tid, stage);
+                                              double* stage, int prestaged) {
+  gather_linearize(s, w, pair, nblk, lds, tid, stage, prestaged);
   if (tid != 0) return;
   s.n_lin += 1;
   if (c.optimizer == 1) {  // step_gn
@@ -1652,11 +1721,15 @@ __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const 
   __shared__ PairState ls;
   __shared__ double stage[kGatherRows * kRed];
   const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
-  if (st[pair].status != ST_NEED_LIN) return;
-  const int N = clouds[pairs[pair].src].n;
+  // every start-up load is issued before the first wait: status, N, the state and the first rows of partials
+  const int status = st[pair].status;
+  const int N = pairs[pair].s.n;
+  const int pre = min(kGatherRows, w.nblk_max);
   state_copy((double*)&ls, (const double*)&st[pair], tid);
+  stage_rows(stage, w.blkpart + (size_t)pair * w.nblk_max * kRed, 0, pre, tid);
+  if (status != ST_NEED_LIN) return;
   __syncthreads();
-  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid, stage);
+  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid, stage, pre);
   __syncthreads();
   state_copy((double*)&st[pair], (const double*)&ls, tid);
 }
@@ -1665,7 +1738,7 @@ __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const
   __shared__ PairState ls;
   const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
   if (st[pair].status != ST_NEED_ERR) return;
-  const int N = clouds[pairs[pair].src].n;
+  const int N = pairs[pair].s.n;
   state_copy((double*)&ls, (const double*)&st[pair], tid);
   __syncthreads();
   if (tid == 0) lm_decide_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c);
@@ -1726,7 +1799,7 @@ __global__ void k_set_probe(PairState* st, const double* T16, int status, int us
 __global__ __launch_bounds__(64) void k_probe_reduce(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, double* out, int which) {
   __shared__ double lds[32];
   const int tid = threadIdx.x;
-  const int N = clouds[pairs[0].src].n;
+  const int N = pairs[0].s.n;
   const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
   PairState& s = st[0];
   if (which == 0) {
@@ -1788,7 +1861,7 @@ __global__ void k_transform_points(const float4* pts /* original order */, int n
 __global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out) {
   __shared__ double red[(LIN_BLK / 64) * 2];
   const int pair = w.pair0 + blockIdx.y;
-  const int N = clouds[pairs[pair].src].n, tid = threadIdx.x;
+  const int N = pairs[pair].s.n, tid = threadIdx.x;
   if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
   double acc[2] = {0.0, 0.0};

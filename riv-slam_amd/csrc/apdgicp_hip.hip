@@ -5,6 +5,7 @@
 #include <new>
 
 #include "apd_engine.hpp"
+#include "apd_voxel.hpp"
 
 using namespace apd;
 
@@ -17,6 +18,22 @@ struct apdgicp_handle {
 
 struct apdgicp_batch {
   Engine eng;
+};
+
+struct apdgicp_submap {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevBuf stage, cat, keys, pos, bsum, out, scal;  // scal: box6[6], total, err
+  CachedTable jobs;
+  int* h_scal = nullptr;  // pinned mirror of {total, err}
+  int64_t n_last = 0;
+  bool last_is_cat = false;  // no downsampling: the result is the concatenation itself
+  ~apdgicp_submap() {
+    if (h_scal) (void)hipHostFree(h_scal);
+    for (DevBuf* b : {&stage, &cat, &keys, &pos, &bsum, &out, &scal, &jobs.dev}) b->release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
 };
 
 namespace {
@@ -560,7 +577,7 @@ int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n
   return guarded([&]() -> int {
     if (!b || !pairs || !scores) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
     Engine& e = b->eng;
-    const bool same = e.npairs == n_pairs && (int64_t)e.h_pairs.size() == n_pairs;
+    const bool same = e.npairs == n_pairs && (int64_t)e.h_pairs.size() == n_pairs && !e.desc_dirty;  // no cloud replaced since
     bool same_pairs = same;
     for (int64_t i = 0; same_pairs && i < n_pairs; i++)
       same_pairs = e.h_pairs[i].src == pairs[i].source_cloud && e.h_pairs[i].tgt == pairs[i].target_cloud;
@@ -642,6 +659,156 @@ int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_l
   if (nn_sources_per_lane) *nn_sources_per_lane = b->eng.nn_S;
   if (nn_target_splits) *nn_target_splits = b->eng.work.T;
   return 0;
+}
+
+
+// ------------------------------------------------------------------ scan-to-submap target assembly (apd_voxel.hpp)
+int apdgicp_submap_create(int device, void* stream, apdgicp_submap** out) {
+  return guarded([&]() -> int {
+    if (!out) return fail(APDGICP_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    int count = 0;
+    APD_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(APDGICP_ERR_INVALID_ARG, "device index out of range");
+    APD_HIP(hipSetDevice(device));
+    apdgicp_submap* s = new apdgicp_submap;
+    s->device = device;
+    if (stream) {
+      s->stream = (hipStream_t)stream;
+    } else {
+      const hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) {
+        delete s;
+        return fail(APDGICP_ERR_HIP, hipGetErrorString(e));
+      }
+      s->own_stream = true;
+    }
+    if (hipHostMalloc((void**)&s->h_scal, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess || s->scal.ensure(8 * sizeof(int)) < 0) {
+      delete s;
+      return fail(APDGICP_ERR_HIP, "allocation failed");
+    }
+    *out = s;
+    return 0;
+  });
+}
+
+int apdgicp_submap_destroy(apdgicp_submap* s) {
+  delete s;
+  return 0;
+}
+
+int apdgicp_submap_assemble(apdgicp_submap* s, int n_clouds, const void* const* xyz, const int64_t* n_points, int64_t stride_bytes,
+                            int64_t intensity_offset_bytes, int on_device, const double* rel_poses, const float* leaf, int64_t* n_out) {
+  return guarded([&]() -> int {
+    if (!s || !xyz || !n_points || !n_out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (n_clouds < 1 || n_clouds > 4096) return fail(APDGICP_ERR_INVALID_ARG, "n_clouds must be in [1, 4096]");
+    if (stride_bytes < 12 || stride_bytes % 4) return fail(APDGICP_ERR_INVALID_ARG, "stride must be a multiple of 4 bytes and >= 12");
+    if (intensity_offset_bytes >= 0 && (intensity_offset_bytes % 4 || intensity_offset_bytes + 4 > stride_bytes))
+      return fail(APDGICP_ERR_INVALID_ARG, "intensity offset outside the point");
+    APD_HIP(hipSetDevice(s->device));
+    *n_out = 0;
+    s->n_last = 0;
+    int64_t total = 0, nmax = 0;
+    for (int c = 0; c < n_clouds; c++) {
+      if (n_points[c] < 0 || (n_points[c] > 0 && !xyz[c])) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud");
+      total += n_points[c], nmax = std::max<int64_t>(nmax, n_points[c]);
+    }
+    if (total > (1ll << 27)) return fail(APDGICP_ERR_UNSUPPORTED, "more than 2^27 points");
+    if (total == 0) return 0;
+    // inputs: device pointers are read in place, host clouds go through one staging buffer
+    std::vector<SubmapJob> jobs(n_clouds);
+    const int stride_f = (int)(stride_bytes / 4);
+    if (!on_device) {
+      APD_HIP(hipStreamSynchronize(s->stream));  // the staging buffer may still be read by the previous call
+      APD_TRY(s->stage.ensure((size_t)total * stride_bytes));
+    }
+    int64_t off = 0;
+    for (int c = 0; c < n_clouds; c++) {
+      SubmapJob& j = jobs[c];
+      memset(&j, 0, sizeof(j));
+      j.n = n_points[c], j.stride = stride_f, j.out_off = (int)off;
+      j.intensity_off = intensity_offset_bytes >= 0 ? (int)(intensity_offset_bytes / 4) : -1;
+      if (on_device) {
+        j.xyz = (const float*)xyz[c];
+      } else {
+        float* dst = s->stage.as<float>() + off * stride_f;
+        // the last point may be shorter than the stride in the caller's buffer: copy up to its last used float only
+        const size_t used = std::max<int64_t>(12, intensity_offset_bytes >= 0 ? intensity_offset_bytes + 4 : 12);
+        if (j.n > 0) APD_HIP(hipMemcpyAsync(dst, xyz[c], (size_t)(j.n - 1) * stride_bytes + used, hipMemcpyHostToDevice, s->stream));
+        j.xyz = dst;
+      }
+      for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 4; q++) j.T[4 * r + q] = rel_poses ? rel_poses[(size_t)c * 16 + r + 4 * q] : (r == q ? 1.0 : 0.0);
+      off += j.n;
+    }
+    APD_TRY(s->jobs.upload(jobs.data(), jobs.size() * sizeof(SubmapJob), s->stream));
+    const int n = (int)total;
+    APD_TRY(s->cat.ensure((size_t)n * 16));
+    hipLaunchKernelGGL(k_submap_transform, dim3((unsigned)((nmax + 255) / 256), (unsigned)n_clouds), dim3(256), 0, s->stream,
+                       s->jobs.as<SubmapJob>(), s->cat.as<float4>());
+    APD_HIP(hipGetLastError());
+    if (!leaf || !(leaf[0] > 0.f)) {  // downsample_method NONE: downsample() returns the cloud itself (:413-415)
+      APD_HIP(hipStreamSynchronize(s->stream));
+      s->n_last = n, s->last_is_cat = true;
+      *n_out = n;
+      return 0;
+    }
+    if (!(leaf[1] > 0.f) || !(leaf[2] > 0.f)) return fail(APDGICP_ERR_INVALID_ARG, "leaf sizes must be positive");
+    const float il[3] = {1.f / leaf[0], 1.f / leaf[1], 1.f / leaf[2]};  // inverse_leaf_size_ = Array4f::Ones() / leaf_size_
+    int np2 = VOX_TILE;
+    while (np2 < n) np2 <<= 1;
+    const int nsb = (np2 + SCAN_BLK * SCAN_ITEMS - 1) / (SCAN_BLK * SCAN_ITEMS);
+    APD_TRY(s->keys.ensure((size_t)np2 * 8));
+    APD_TRY(s->pos.ensure((size_t)np2 * 4));
+    APD_TRY(s->bsum.ensure((size_t)nsb * 4));
+    APD_TRY(s->out.ensure((size_t)n * 16));
+    int* box6 = s->scal.as<int>();
+    int* d_total = box6 + 6;
+    int* d_err = box6 + 7;
+    const int init[8] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff, 0, 0};
+    APD_HIP(hipMemcpyAsync(box6, init, sizeof(init), hipMemcpyHostToDevice, s->stream));  // pageable source: staged before the call returns
+    hipLaunchKernelGGL(k_vox_bbox, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->cat.as<float4>(), n, box6);
+    unsigned long long* keys = s->keys.as<unsigned long long>();
+    hipLaunchKernelGGL(k_vox_keys, dim3((np2 + 255) / 256), dim3(256), 0, s->stream, s->cat.as<float4>(), n, np2, box6, il[0], il[1], il[2], keys, d_err);
+    hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, s->stream, keys);
+    for (int k = 2 * VOX_TILE; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j >= VOX_TILE; j >>= 1)
+        hipLaunchKernelGGL(k_bitonic_global, dim3((np2 / 2 + 255) / 256), dim3(256), 0, s->stream, keys, np2, k, j);
+      hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(np2 / VOX_TILE), dim3(1024), 0, s->stream, keys, k);
+    }
+    hipLaunchKernelGGL(k_vox_heads, dim3(nsb), dim3(SCAN_BLK), 0, s->stream, keys, np2, s->pos.as<int>(), s->bsum.as<int>());
+    hipLaunchKernelGGL(k_scan_bsum, dim3(1), dim3(SCAN_BLK), 0, s->stream, s->bsum.as<int>(), nsb, d_total);
+    hipLaunchKernelGGL(k_vox_centroids, dim3((np2 + 255) / 256), dim3(256), 0, s->stream, keys, s->cat.as<float4>(), s->pos.as<int>(),
+                       s->bsum.as<int>(), np2, s->out.as<float4>(), n);
+    APD_HIP(hipGetLastError());
+    APD_HIP(hipMemcpyAsync(s->h_scal, d_total, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    APD_HIP(hipStreamSynchronize(s->stream));
+    if (s->h_scal[1] == 5) return fail(APDGICP_ERR_UNSUPPORTED, "leaf size is too small for the extent of the submap (voxel index overflows int32)");
+    if (s->h_scal[1]) return fail(APDGICP_ERR_INTERNAL, "voxel filter failed");
+    s->n_last = s->h_scal[0], s->last_is_cat = false;
+    *n_out = s->n_last;
+    return 0;
+  });
+}
+
+int apdgicp_submap_points(apdgicp_submap* s, const float** device_xyzi, int64_t* n) {
+  if (!s || !device_xyzi || !n) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  *device_xyzi = s->n_last ? (s->last_is_cat ? s->cat.as<float>() : s->out.as<float>()) : nullptr;
+  *n = s->n_last;
+  return 0;
+}
+
+int apdgicp_submap_copy(apdgicp_submap* s, float* dst_xyzi, int64_t capacity_points, int dst_on_device) {
+  return guarded([&]() -> int {
+    if (!s || !dst_xyzi) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (capacity_points < s->n_last) return fail(APDGICP_ERR_INVALID_ARG, "destination holds fewer points than the assembled cloud");
+    if (!s->n_last) return 0;
+    APD_HIP(hipSetDevice(s->device));
+    const float* src = s->last_is_cat ? s->cat.as<float>() : s->out.as<float>();
+    APD_HIP(hipMemcpyAsync(dst_xyzi, src, (size_t)s->n_last * 16, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->stream));
+    APD_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+  });
 }
 
 }  // extern "C"

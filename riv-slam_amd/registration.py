@@ -90,6 +90,7 @@ SYMBOLS = [
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
     "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
+    "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
 
 _lib = None
@@ -154,6 +155,11 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_last_nn_profile.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.apdgicp_batch_debug_stats.argtypes = [vp, vp]
+    L.apdgicp_submap_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.apdgicp_submap_destroy.argtypes = [vp]
+    L.apdgicp_submap_assemble.argtypes = [vp, i32, vp, vp, i64, i64, i32, vp, vp, C.POINTER(i64)]
+    L.apdgicp_submap_points.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.apdgicp_submap_copy.argtypes = [vp, vp, i64, i32]
     if path is None:
         _lib = L
     return L
@@ -179,9 +185,19 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class DevicePoints:
+    """n points in device memory, `stride_bytes` apart, xyz first (e.g. the cloud a SubmapAssembler holds);
+    accepted wherever a cloud is: the pointer is passed straight through.  `owner` keeps the memory alive."""
+
+    def __init__(self, ptr: int, n: int, stride_bytes: int, owner=None):
+        self.ptr, self.n, self.stride_bytes, self.owner = int(ptr), int(n), int(stride_bytes), owner
+
+
 def _cloud_arg(cloud):
-    """-> (pointer, n, stride_bytes, on_device, keepalive).  Accepts numpy [n,>=3] float32 or a
-    torch CUDA/CPU float32 tensor of the same shape (device pointers are passed straight through)."""
+    """-> (pointer, n, stride_bytes, on_device, keepalive).  Accepts numpy [n,>=3] float32, a
+    torch CUDA/CPU float32 tensor of the same shape, or DevicePoints (device pointers are passed straight through)."""
+    if isinstance(cloud, DevicePoints):
+        return C.c_void_p(cloud.ptr), cloud.n, cloud.stride_bytes, 1, cloud
     if hasattr(cloud, "data_ptr"):  # torch tensor
         t = cloud
         if t.dim() != 2 or t.shape[1] < 3 or str(t.dtype) != "torch.float32" or t.stride(1) != 1:

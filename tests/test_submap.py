@@ -1,0 +1,183 @@
+"""Scan-to-submap target assembly: transform + concatenate + pcl::VoxelGrid.
+
+CPU part (-m "not gpu"): the C++ oracle against an independent numpy restatement of the same PCL algorithm.
+GPU part (-m gpu): the HIP path through the C ABI against the oracle.  Bars: number of voxels, their order
+(ascending voxel index) and their membership exact; the transformed points bit-exact; centroids 2 ulp-ish
+(PCL adds the points of a voxel in std::sort's order, the device in input order -- fp32 sums, so the last bit may differ).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import ref as R
+
+
+def keyframes(scene, n_frames, n_pts, seed):
+    """n_frames clouds [n, 4] {x, y, z, intensity} of one synthetic street seen from a moving sensor + their odometry"""
+    rng = np.random.default_rng(seed)
+    clouds, odoms = [], []
+    T = np.eye(4)
+    for f in range(n_frames):
+        src, _, Tt, _ = scene.make_pair(n_pts, 16, scene.pair_seed(seed, f), "odometry")
+        c = np.concatenate([src[:, :3], rng.uniform(0, 40, (n_pts, 1)).astype(np.float32)], axis=1)
+        clouds.append(np.ascontiguousarray(c, dtype=np.float32))
+        T = T @ Tt
+        odoms.append(T.copy())
+    return clouds, odoms
+
+
+def np_voxelgrid(cat, leaf):
+    """independent restatement of VoxelGrid::applyFilter on an [N, 4] float32 cloud: (voxel index, population, centroids)"""
+    inv = (np.float32(1) / np.broadcast_to(np.asarray(leaf, np.float32), (3,))).astype(np.float32)
+    ok = np.isfinite(cat[:, :3]).all(1)
+    p = cat[ok]
+    mn, mx = p[:, :3].min(0), p[:, :3].max(0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    div_b = np.floor(mx * inv).astype(np.int64) - min_b + 1
+    ijk = np.floor(p[:, :3] * inv).astype(np.int64) - min_b
+    vid = ijk[:, 0] + ijk[:, 1] * div_b[0] + ijk[:, 2] * div_b[0] * div_b[1]
+    order = np.argsort(vid, kind="stable")
+    u, start, cnt = np.unique(vid[order], return_index=True, return_counts=True)
+    cen = np.stack([np.add.reduceat(p[order, k].astype(np.float64), start) for k in range(4)], 1) / cnt[:, None]
+    return u, cnt, cen
+
+
+def test_oracle_matches_numpy_restatement(scene):
+    clouds, odoms = keyframes(scene, 4, 1500, 11)
+    sub = importlib.import_module("riv-slam_amd.submap")
+    poses = sub.relative_poses(odoms[:-1], odoms[-1])
+    cat, _, _ = R.submap_assemble(clouds[:-1], poses, None)
+    exp = np.concatenate([((T[:3, :3] @ c[:, :3].astype(np.float64).T).T + T[:3, 3]) for c, T in zip(clouds, poses)])
+    assert cat.shape == (4500, 4) and np.abs(cat[:, :3] - exp).max() < 1e-5
+    assert np.array_equal(cat[:, 3], np.concatenate([c[:, 3] for c in clouds[:-1]]))
+    for leaf in (0.1, 0.5, (0.2, 0.4, 1.0)):
+        out, idx, cnt = R.submap_assemble(clouds[:-1], poses, leaf)
+        u, c2, cen = np_voxelgrid(cat, leaf)
+        assert np.array_equal(idx, u) and np.array_equal(cnt, c2)
+        assert np.abs(out - cen).max() < 2e-5
+    with pytest.raises(RuntimeError):
+        R.submap_assemble(clouds[:-1], poses, 1e-5)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def mods():
+    import __graft_entry__ as g
+    g.build()
+    return importlib.import_module("riv-slam_amd.registration"), importlib.import_module("riv-slam_amd.submap")
+
+
+def centroids_close(a, b, cnt=None):
+    """fp32 sums of `cnt` values added in a different order: |error of the mean| <= (cnt - 1) eps |mean| to first order"""
+    k = 4.0 if cnt is None else np.maximum(cnt, 4)[:, None].astype(np.float64)
+    tol = k * np.finfo(np.float32).eps * np.maximum(np.abs(b), 1.0)
+    return bool((np.abs(a.astype(np.float64) - b) <= tol).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_frames,n_pts", ((2, 700), (5, 3000), (5, 8192)))
+def test_assemble_vs_oracle(mods, scene, n_frames, n_pts):
+    reg, sub = mods
+    clouds, odoms = keyframes(scene, n_frames + 1, n_pts, 3 + n_frames)
+    poses = sub.relative_poses(odoms[:-1], odoms[-1])
+    a = sub.SubmapAssembler()
+    # no filter: transform + concatenation, bit for bit
+    n = a.assemble(clouds[:-1], poses, None)
+    cat, _, _ = R.submap_assemble(clouds[:-1], poses, None)
+    assert n == n_frames * n_pts and np.array_equal(a.to_numpy(), cat)
+    for leaf in (0.1, 0.25, (0.2, 0.4, 1.0), 5.0):
+        exp, idx, cnt = R.submap_assemble(clouds[:-1], poses, leaf)
+        n = a.assemble(clouds[:-1], poses, leaf)
+        got = a.to_numpy()
+        assert n == exp.shape[0] == got.shape[0]
+        single = cnt == 1
+        assert np.array_equal(got[single], exp[single])  # one-point voxels: no summation at all
+        assert centroids_close(got, exp, cnt)
+        # membership: every centroid lies in the voxel the oracle says it belongs to
+        u, _, _ = np_voxelgrid(got, leaf)  # voxel ids of the centroids, in the grid of the centroids' own extent
+        assert len(np.unique(u)) <= n
+
+
+@pytest.mark.gpu
+def test_device_inputs_strides_and_intensity(mods, scene):
+    import torch
+    reg, sub = mods
+    clouds, odoms = keyframes(scene, 4, 2000, 21)
+    poses = sub.relative_poses(odoms[:-1], odoms[-1])
+    exp, _, _ = R.submap_assemble(clouds[:-1], poses, 0.2)
+    a = sub.SubmapAssembler()
+    # pcl::PointXYZI layout on the device: 32-byte points, intensity at byte 16
+    dev = []
+    for c in clouds[:-1]:
+        t = torch.zeros((c.shape[0], 8), dtype=torch.float32)
+        t[:, :3] = torch.from_numpy(c[:, :3])
+        t[:, 4] = torch.from_numpy(c[:, 3])
+        dev.append(t.cuda())
+    n = a.assemble(dev, poses, 0.2, intensity_column=4)
+    assert n == exp.shape[0] and centroids_close(a.to_numpy(), exp)
+    # xyz only: the intensity channel is 0
+    n = a.assemble([c[:, :3].copy() for c in clouds[:-1]], poses, 0.2, intensity_column=None)
+    got = a.to_numpy()
+    assert n == exp.shape[0] and centroids_close(got[:, :3], exp[:, :3]) and not got[:, 3].any()
+    # identity poses == no poses
+    n1 = a.assemble(clouds[:-1], None, 0.2)
+    g1 = a.to_numpy()
+    n2 = a.assemble(clouds[:-1], [np.eye(4)] * 3, 0.2)
+    assert n1 == n2 and np.array_equal(g1, a.to_numpy())
+
+
+@pytest.mark.gpu
+def test_edge_cases(mods, scene):
+    reg, sub = mods
+    a = sub.SubmapAssembler()
+    c = np.array([[0.01, 0.01, 0.01, 1], [0.02, 0.02, 0.02, 3], [np.nan, 0, 0, 9], [5, 5, 5, 7], [np.inf, 1, 1, 2]], dtype=np.float32)
+    exp, idx, cnt = R.submap_assemble([c], None, 0.1)
+    assert a.assemble([c], None, 0.1) == 2 == exp.shape[0]  # non-finite points are skipped
+    assert centroids_close(a.to_numpy(), exp)
+    assert a.assemble([c[:0], c[:1]], None, 0.1) == 1  # an empty keyframe cloud among the inputs
+    assert a.assemble([c[:0]], None, 0.1) == 0 and a.to_numpy().shape == (0, 4)
+    with pytest.raises(reg.ApdgicpError):  # PCL: "Leaf size is too small for the input dataset"
+        a.assemble([c[[0, 3]]], None, 1e-4)
+    # all points in one voxel; duplicates
+    d = np.tile(np.array([[1.5, 2.5, 3.5, 4.0]], dtype=np.float32), (1000, 1))
+    assert a.assemble([d], None, 0.5) == 1 and np.array_equal(a.to_numpy(), d[:1])
+
+
+@pytest.mark.gpu
+def test_large_submap_properties(mods, scene):
+    """C5-sized: 5 x 100k points (524288-key sort): population conserved, centroids inside their voxels, ascending order"""
+    reg, sub = mods
+    rng = np.random.default_rng(5)
+    clouds = [np.concatenate([rng.uniform(-60, 60, (100000, 2)), rng.uniform(-3, 8, (100000, 1)), rng.uniform(0, 1, (100000, 1))], 1).astype(np.float32)
+              for _ in range(5)]
+    a = sub.SubmapAssembler()
+    leaf = 0.5
+    n = a.assemble(clouds, None, leaf)
+    got = a.to_numpy()
+    exp, idx, cnt = R.submap_assemble(clouds, None, leaf)
+    assert n == exp.shape[0] and centroids_close(got, exp, cnt)
+    u, c2, _ = np_voxelgrid(np.concatenate(clouds), leaf)
+    assert len(u) == n and c2.sum() == 500000
+
+
+@pytest.mark.gpu
+def test_update_submap_target_feeds_the_registration(mods, scene):
+    """the :606-618 block end to end: the device-resident submap as target gives the same registration as its host copy"""
+    reg, sub = mods
+    clouds, odoms = keyframes(scene, 6, 4000, 31)
+    prm = reg.default_params(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+    a = sub.SubmapAssembler()
+    g = reg.FastAPDGICP(prm)
+    n = sub.update_submap_target(g, clouds, odoms, 5, 0.1, a)
+    assert n > 0 and g.n_tgt == n
+    exp, _, _ = R.submap_assemble(clouds[1:5], sub.relative_poses(odoms[1:5], odoms[-1]), 0.1)
+    assert n == exp.shape[0]
+    g.setInputSource(clouds[-1][:, :3])
+    T1 = g.align(None)
+    h = reg.FastAPDGICP(prm)
+    h.setInputTarget(a.to_numpy())
+    h.setInputSource(clouds[-1][:, :3])
+    T2 = h.align(None)
+    assert np.array_equal(T1, T2)
+    assert sub.update_submap_target(g, clouds[:1], odoms[:1], 5, 0.1, a) == 0  # a single keyframe: no submap yet
