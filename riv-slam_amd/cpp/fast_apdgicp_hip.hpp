@@ -122,6 +122,16 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
         apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
       report("setInputTarget");
   }
+  /// scan-to-map mode: the target already lives in device memory (apdgicp_submap_points, 16-byte stride), so the
+  /// setInputTarget(keyframe_cloud_s2m) of scan_matching_odometry_nodelet.cpp:615 needs no host cloud.  PCL's align()
+  /// insists on a non-null target_, which gets a one-point placeholder; nothing on this path reads it.
+  void setInputTargetDevice(const float* device_xyz, std::size_t n, std::size_t stride_bytes) {
+    typename PointCloudTarget::Ptr placeholder(new PointCloudTarget());
+    placeholder->resize(1);
+    Base::setInputTarget(placeholder);
+    if (handle_ && n && apdgicp_set_target(handle_, device_xyz, (int64_t)n, (int64_t)stride_bytes, 1, ++device_epoch_) != 0)
+      report("setInputTargetDevice");
+  }
   virtual void setSourceCovariances(const CovVector& covs) {
     if (handle_ && apdgicp_set_covariances(handle_, APDGICP_SOURCE, covs[0].data(), (int64_t)covs.size()) != 0) report("setSourceCovariances");
   }
@@ -189,6 +199,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   }
   void report(const char* what) const { std::fprintf(stderr, "[FastAPDGICPHip] %s failed: %s\n", what, apdgicp_last_error()); }
 
+  uint64_t device_epoch_ = 0x5375624d61700000ull;  // tokens of device targets (never equal to a host cloud's address)
   apdgicp_handle* handle_ = nullptr;
   apdgicp_params params_;
   apdgicp_result result_{};

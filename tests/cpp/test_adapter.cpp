@@ -66,6 +66,25 @@ int main(int argc, char** argv) {
   auto* hip = dynamic_cast<fast_gicp::FastAPDGICPHip<PointT, PointT>*>(registration.get());
   std::printf(" %d", hip->lastResult().iterations);
   for (int i = 0; i < 16; i++) std::printf(" %.9g", T.data()[i]);
-  std::printf(" %.9g %.9g %.9g %.9g\n", aligned->at(0).x, aligned->at(0).y, aligned->at(0).z, aligned->at(0).intensity);
+  std::printf(" %.9g %.9g %.9g %.9g", aligned->at(0).x, aligned->at(0).y, aligned->at(0).z, aligned->at(0).intensity);
+  // scan-to-map mode (scan_matching_odometry_nodelet.cpp:606-618): the target is assembled on the device (one keyframe,
+  // identity pose, no voxel filter == the target cloud itself) and never comes back; same registration expected
+  apdgicp_submap* sm = nullptr;
+  int same = 0;
+  if (apdgicp_submap_create(0, nullptr, &sm) == 0) {
+    const void* xyz[1] = {&target->at(0).x};
+    const int64_t cnt[1] = {(int64_t)target->size()};
+    int64_t m = 0;
+    const float* dev = nullptr;
+    if (apdgicp_submap_assemble(sm, 1, xyz, cnt, sizeof(PointT), 16, 0, nullptr, nullptr, &m) == 0 && apdgicp_submap_points(sm, &dev, &m) == 0) {
+      hip->setInputTargetDevice(dev, (std::size_t)m, 16);
+      registration->align(*aligned, g);
+      const auto T2 = registration->getFinalTransformation();
+      same = m == (int64_t)target->size();
+      for (int i = 0; i < 16; i++) same = same && T2.data()[i] == T.data()[i];
+    }
+    apdgicp_submap_destroy(sm);
+  }
+  std::printf(" %d\n", same);
   return 0;
 }

@@ -56,3 +56,4 @@ def test_adapter_matches_python_binding(golden, scene, tmp_path):
     assert list(golden["lm_launch_info"][:2]) == [conv, iters]
     want = Tp[:3, :3] @ src[0] + Tp[:3, 3]
     assert np.abs(p0[:3] - want).max() < 1e-4 and p0[3] == 42.0   # intensity carried over like pcl::transformPointCloud
+    assert int(vals[22]) == 1   # setInputTargetDevice (device-resident submap as target): the same registration
