@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -122,6 +123,8 @@ class Engine {
   Work work{};
   int nn_S = 2;
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
+  bool nn_gate_cap = true; // optimiser ticks stop the search at the correspondence gate (APDGICP_NN_GATE_CAP=0: unbounded)
+  float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
   bool fuse_lm = false;    // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=1): measured neutral (r01)
   DevBuf b_ticket;
@@ -174,6 +177,7 @@ class Engine {
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 0) != 0;
+    nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 2)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
@@ -525,6 +529,7 @@ class Engine {
     work.T = T;
     work.nstride = (nmax_src + 255) & ~255;
     work.nblk_max = (nmax_src + LIN_BLK - 1) / LIN_BLK;
+    work.cap = std::numeric_limits<float>::infinity();
     const size_t ns = work.nstride;
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
@@ -579,6 +584,7 @@ class Engine {
     const PairState* st = d_state.as<PairState>();
     Work w = work;
     w.pair0 = sp.p0;
+    w.cap = nn_cap;
     if (nn_pruned) {
       if (nn_S == 1) hipLaunchKernelGGL(k_nn_pruned<1>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
       else if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
@@ -613,7 +619,15 @@ class Engine {
     const Consts c = consts();
     Work w = work;
     w.pair0 = sp.p0;
-    APD_TRY(launch_nn(sp));
+    if (nn_gate_cap) {       // smallest float >= corr_dist_threshold^2 (A:156 compares the float distance with the double square)
+      const double thr2 = consts().thr2;
+      float capf = (float)thr2;
+      if ((double)capf < thr2) capf = std::nextafterf(capf, std::numeric_limits<float>::infinity());
+      nn_cap = capf;
+    }
+    const int rc_nn = launch_nn(sp);
+    nn_cap = std::numeric_limits<float>::infinity();
+    APD_TRY(rc_nn);
     APD_TRY(launch_linearize(sp, fuse_lm ? 2 : 1));
     if (!fuse_lm)
       hipLaunchKernelGGL(k_lm_solve, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w, c);

@@ -83,6 +83,9 @@ struct Work {
   double* blkpart;             // [pair][nblk_max][kRed]
   double* errpart;             // [pair][nblk_max]
   int nstride, nblk_max, T;
+  float cap;                   // pruned searches: squared search radius (+inf: unbounded).  The optimiser ticks pass the smallest float
+                               // >= corr_dist_threshold^2: a point without any target inside it has no correspondence whatever its
+                               // true neighbour is (A:156), so the search may stop there (sqd then holds the cap, nnidx -1)
   int pair0, npairs;           // this launch covers pairs [pair0, pair0 + gridDim pairs) of npairs (one stream per pair group)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   const int N = src.n, M = tgt.n, lane = threadIdx.x;
   const int base = blockIdx.x * (64 * S);
   if (base >= N) return;
-  const bool tstat = w.stats && (blockIdx.x & 15) == 0;
+  const bool tstat = w.stats && (blockIdx.x & 15) == 0;  // phase timing: sampled waves only
   long long tcy[4] = {0, 0, 0, 0}, tm = tstat ? clock64() : 0;
   float Tf[12];
   load_Tf(T0, Tf);
@@ -548,17 +551,19 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
     const int ii = i < N ? i : N - 1;
     const float4 p = src.pts[ii];
     px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
-    best[s] = inf, bestc[s] = kNoChunk;
+    best[s] = w.cap, bestc[s] = kNoChunk;
     const int hint = w.nnidx[(size_t)pair * w.nstride + ii];
     if (hint >= 0 && hint < M) {
       const float4 t = tgt.pts[hint];
       const float d = sqdist1(t.x, t.y, t.z, px[s], py[s], pz[s]);
-      if (d < inf) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
+      if (d < best[s]) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
     } else {
       all_hinted = false;
     }
   }
-  all_hinted = __all(all_hinted);
+  // seeded cold start only when (almost) nobody has a hint; a few lanes without one (no target inside the cap last
+  // time) start from the cap and need no seed
+  all_hinted = w.cap < inf ? __popcll(__ballot(all_hinted)) >= 32 : __all(all_hinted);
   // bounding box of this wave's (transformed) points
   Box wbox;
   {
@@ -726,6 +731,7 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
 }
 
 // ----------------------------------------------------------------------------------------------
+
 // wave-wide bitonic sort (ascending over lane id) of one 64-bit key per lane
 __device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long v, int lane) {
 #pragma unroll

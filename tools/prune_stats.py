@@ -16,7 +16,7 @@ for p in range(P):
 b.compute_covariances(); kst = b.debug_stats()
 r = b.align([(2*i,2*i+1) for i in range(P)], g)
 st = b.debug_stats()
-print("NN cycles/wave (sampled): start+hint %.0f  masks %.0f  groups %.0f" % (st[10]/st[14], st[11]/st[14], st[12]/st[14]))
+print("NN ticks/wave (sampled): start+hint %.0f  masks %.0f  groups %.0f" % (st[10]/st[14], st[11]/st[14], st[12]/st[14]))
 print("NN: groups/wave %.1f chunks tested/wave %.1f scanned/wave %.1f waves %d (%d launches)" % (st[0]/st[3], st[1]/st[3], st[2]/st[3], st[3], prm.max_iterations))
 st = kst
 print("KNN: groups loaded/wave %.1f  (query,group) pairs/wave %.1f  compactions/wave %.2f  waves %d" % (st[4]/st[7], st[9]/st[7], st[8]/st[7], st[7]))
