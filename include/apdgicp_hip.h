@@ -136,7 +136,10 @@ int apdgicp_linearize(apdgicp_handle* h, const double T[16], double H[36], doubl
 /* compute_error (A:275-298): frozen correspondences / Mahalanobis of the last linearize */
 int apdgicp_compute_error(apdgicp_handle* h, const double T[16], double* cost);
 /* correspondences_ / sq_distances_ (H:104-105) and mahalanobis_ (H:102; n x 16 doubles, zeros for
- * unmatched points) after the last linearize; any pointer may be NULL */
+ * unmatched points) after the last linearize; any pointer may be NULL.  After apdgicp_linearize every sq_dist is the
+ * exact nearest-neighbour distance.  Inside apdgicp_align the search stops at the correspondence gate: a point with
+ * corr == -1 then reports the smallest float >= max_correspondence_distance^2 (or the distance to its previous
+ * neighbour) instead of the distance to a neighbour the reference would reject anyway (A:156); correspondences are exact. */
 int apdgicp_get_correspondences(apdgicp_handle* h, int32_t* corr, float* sq_dist, int64_t n);
 int apdgicp_get_mahalanobis(apdgicp_handle* h, double* out_n16, int64_t n);
 
