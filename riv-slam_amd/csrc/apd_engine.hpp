@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <cstdio>
@@ -673,6 +674,8 @@ class Engine {
     const int chunk = std::max(1, env_int("APDGICP_POLL_TICKS", lm ? 4 : std::min(64, std::max(1, params.max_iterations))));
     long long ticks = 0;
     bool all_done = params.max_iterations <= 0;
+    const bool dbg_t = env_int("APDGICP_DEBUG_TIMING", 0) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     while (!all_done && ticks < tick_cap) {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
@@ -696,7 +699,11 @@ class Engine {
                          d_errflag.as<int>());
       APD_HIP(hipMemcpyAsync(h_status, d_status.p, (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
       APD_HIP(hipEventRecord(ev_poll, stream));
+      const auto t_enq = std::chrono::steady_clock::now();
       APD_HIP(hipEventSynchronize(ev_poll));
+      if (dbg_t)
+        fprintf(stderr, "[apdgicp] %d ticks: enqueue %.3f ms, wait %.3f ms\n", todo, std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
       all_done = true;
       for (int p = 0; p < npairs; p++) all_done &= (h_status[p] == ST_DONE);
       if (h_status[npairs]) {

@@ -1292,6 +1292,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
   Sym3 out;
   if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+  if (stats && lane == 0) atomicAdd(stats + 15, (unsigned long long)(clock64() - tm));  // rounds + regularisation
   double* cov = c.cov;
   cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
 }

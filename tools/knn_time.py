@@ -24,4 +24,4 @@ print("sort+knn ms (min of 8): %.3f   all: %s" % (min(ts), " ".join("%.3f" % t f
 if os.environ.get("APDGICP_STATS"):
     st = b.debug_stats()
     print("KNN: groups loaded/wave %.1f  (query,group) pairs/wave %.1f  compactions/wave %.2f  waves %d" % (st[4]/st[7], st[9]/st[7], st[8]/st[7], st[7]))
-    print("cycles/wave: A %.0f  gneed %.0f  B %.0f  C(rounds) %.0f" % (st[10]/st[7], st[11]/st[7], st[12]/st[7], st[13]/st[7]))
+    print("ticks/wave: A %.0f  gneed %.0f  B %.0f  C(rounds) %.0f  C incl. regularisation %.0f" % (st[10]/st[7], st[11]/st[7], st[12]/st[7], st[13]/st[7], st[15]/st[7]))

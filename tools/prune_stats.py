@@ -5,7 +5,7 @@ sys.path.insert(0,'.')
 import numpy as np, torch
 reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
 import bench
-P=8
+P=int(os.environ.get('P','8'))
 prm = bench.bench_params(reg)
 if len(sys.argv) > 1: prm.max_iterations = int(sys.argv[1])
 b = reg.BatchAPDGICP(prm)
