@@ -615,17 +615,20 @@ class Engine {
     return 0;
   }
 
+  float gate_cap() const {  // smallest float >= corr_dist_threshold^2 (A:156 compares the float distance with the double square)
+    if (!nn_gate_cap) return std::numeric_limits<float>::infinity();
+    const double thr2 = consts().thr2;
+    float capf = (float)thr2;
+    if ((double)capf < thr2) capf = std::nextafterf(capf, std::numeric_limits<float>::infinity());
+    return capf;
+  }
+
   // one tick of the state machines of the pairs in `sp`
   int launch_tick(Span sp) {
     const Consts c = consts();
     Work w = work;
     w.pair0 = sp.p0;
-    if (nn_gate_cap) {       // smallest float >= corr_dist_threshold^2 (A:156 compares the float distance with the double square)
-      const double thr2 = consts().thr2;
-      float capf = (float)thr2;
-      if ((double)capf < thr2) capf = std::nextafterf(capf, std::numeric_limits<float>::infinity());
-      nn_cap = capf;
-    }
+    nn_cap = gate_cap();
     const int rc_nn = launch_nn(sp);
     nn_cap = std::numeric_limits<float>::infinity();
     APD_TRY(rc_nn);

@@ -509,21 +509,13 @@ __device__ __forceinline__ Box lds_box(const float* cbl, int ch) {
 // wave's points is scanned first so that `best` is tight before the sweep.
 constexpr int GB_BATCH = 256;  // group boxes staged per LDS batch (6 KB)
 
+// The search of k_nn_pruned for the 64*S points [base, base + 64*S) of one pair.  LDS: txy[64] float4, tz[64] float2, cbl[48], gbl[6*GB_BATCH] floats.
+// Returns the transformed points, the minimum squared distance and (chunk | kTieBit) per point.
 template <int S>
-__global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
-  __shared__ float4 txy[kGroupPts / 2];
-  __shared__ float2 tz[kGroupPts / 2];
-  __shared__ float cbl[6 * kGroupChunks];
-  __shared__ float gbl[6 * GB_BATCH];
-  const int pair = w.pair0 + blockIdx.y;
-  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
-  const PairDesc pd = pairs[pair];
-  const Rigid T0 = st[pair].x0;
-  if (status != ST_NEED_LIN) return;
-  const CloudDesc src = pd.s, tgt = pd.t;
-  const int N = src.n, M = tgt.n, lane = threadIdx.x;
-  const int base = blockIdx.x * (64 * S);
-  if (base >= N) return;
+__device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T0, const Work& w, int pair, int base, int lane,
+                                          float4* txy, float2* tz, float* cbl, float* gbl, float (&px)[S], float (&py)[S], float (&pz)[S],
+                                          float (&best)[S], unsigned (&bestc)[S]) {
+  const int N = src.n, M = tgt.n;
   const bool tstat = w.stats && (blockIdx.x & 15) == 0;  // phase timing: sampled waves only
   long long tcy[4] = {0, 0, 0, 0}, tm = tstat ? clock64() : 0;
   float Tf[12];
@@ -542,8 +534,6 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
   // Warm start: the neighbour found by the previous iteration is a real target point, so its
   // distance at the new pose is a valid upper bound of the minimum and makes the pruning effective
   // from the first group on.  It only changes which chunks are visited, never the result.
-  float px[S], py[S], pz[S], best[S];
-  unsigned bestc[S];
   bool all_hinted = true;
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -717,16 +707,36 @@ __global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const
     }
   }
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
+  if (w.stats && lane == 0) {
+    atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
+    atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
+    if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  __shared__ float4 txy[kGroupPts / 2];
+  __shared__ float2 tz[kGroupPts / 2];
+  __shared__ float cbl[6 * kGroupChunks];
+  __shared__ float gbl[6 * GB_BATCH];
+  const int pair = w.pair0 + blockIdx.y;
+  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
+  const PairDesc pd = pairs[pair];
+  const Rigid T0 = st[pair].x0;
+  if (status != ST_NEED_LIN) return;
+  const CloudDesc src = pd.s, tgt = pd.t;
+  const int N = src.n, lane = threadIdx.x;
+  const int base = blockIdx.x * (64 * S);
+  if (base >= N) return;
+  float px[S], py[S], pz[S], best[S];
+  unsigned bestc[S];
+  nn_search<S>(src, tgt, T0, w, pair, base, lane, txy, tz, cbl, gbl, px, py, pz, best, bestc);
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
 #pragma unroll
   for (int s = 0; s < S; s++) {
     const int i = base + s * 64 + lane;
     if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
-  }
-  if (w.stats && lane == 0) {
-    atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
-    atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
-    if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);
   }
 }
 
@@ -1615,6 +1625,15 @@ __device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok
 }
 
 // sums the block partials of k_linearize in block order (deterministic) into s.H / s.b / s.y0
+// the 29 sums of a linearize -> H (both triangles), b, cost, number of matched points
+__device__ __forceinline__ void fill_from_sums(PairState& s, const double* v) {
+  int q = 0;
+  for (int r = 0; r < 6; r++)
+    for (int c2 = r; c2 < 6; c2++, q++) s.H[r + 6 * c2] = v[q], s.H[c2 + 6 * r] = v[q];
+  for (int r = 0; r < 6; r++) s.b[r] = v[21 + r];
+  s.y0 = v[27];
+  s.n_matched = (int)v[28];
+}
 // stage (optional, kGatherRows * kRed doubles of LDS, 64-thread callers only): the rows are fetched with
 // coalesced loads that are all in flight together, kGatherRows at a time, and summed out of LDS -- the
 // same order of additions without one memory round trip per row.
@@ -1645,22 +1664,20 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
     lds[tid] = v;
   }
   __syncthreads();
-  if (tid == 0) {
-    int q = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c2 = r; c2 < 6; c2++, q++) s.H[r + 6 * c2] = lds[q], s.H[c2 + 6 * r] = lds[q];
-    for (int r = 0; r < 6; r++) s.b[r] = lds[21 + r];
-    s.y0 = lds[27];
-    s.n_matched = (int)lds[28];
-  }
+  if (tid == 0) fill_from_sums(s, lds);
 }
 
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c);
 // after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
 // block (>= 64 threads, uniformly); lds: >= 32 doubles.
 __device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
                                               double* stage, int prestaged) {
   gather_linearize(s, w, pair, nblk, lds, tid, stage, prestaged);
   if (tid != 0) return;
+  lm_after_gather(s, c);
+}
+// one lane: the optimiser step once H, b and the cost are in the state
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
   s.n_lin += 1;
   if (c.optimizer == 1) {  // step_gn
     s.lambda = 0.0;
