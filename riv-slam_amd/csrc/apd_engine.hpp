@@ -120,9 +120,10 @@ class Engine {
   DevBuf d_state, d_results, d_status, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
   CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs;
-  DevBuf b_nnpart, b_corr, b_nnidx, b_sqd, b_maha, b_blkpart, b_errpart;
+  DevBuf b_nnpart, b_corr, b_nnpt, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
+  int nn_W = 2;  // waves per block of k_nn_pruned<1, W> sharing the same 64 points (APDGICP_NN_W = 1, 2, 4)
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
   bool nn_gate_cap = true; // optimiser ticks stop the search at the correspondence gate (APDGICP_NN_GATE_CAP=0: unbounded)
   float nn_cap = std::numeric_limits<float>::infinity();
@@ -179,6 +180,8 @@ class Engine {
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 0) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
+    nn_W = env_int("APDGICP_NN_W", 2);  // measured (r01): 2 beats 1 by 5 %, 4 loses (every wave repeats the bounds and candidate tests)
+    if (nn_W != 1 && nn_W != 2 && nn_W != 4) nn_W = 2;
     ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 2)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
@@ -199,7 +202,7 @@ class Engine {
     for (auto& c : clouds) c.release_all();
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs}) t->dev.release();
     for (DevBuf* b : {&d_state, &d_results, &d_status, &d_errflag, &d_probe, &d_stage, &d_T,
-                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnidx, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_status) e = hipHostFree(h_status);
     if (h_probe) e = hipHostFree(h_probe);
@@ -534,15 +537,15 @@ class Engine {
     const size_t ns = work.nstride;
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
-    APD_TRY(b_nnidx.ensure((size_t)npairs * ns * 4));
-    APD_HIP(hipMemsetAsync(b_nnidx.p, 0xFF, (size_t)npairs * ns * 4, stream));  // -1: no warm start yet
+    APD_TRY(b_nnpt.ensure((size_t)npairs * ns * 16));
+    APD_HIP(hipMemsetAsync(b_nnpt.p, 0xFF, (size_t)npairs * ns * 16, stream));  // index bits -1: no warm start yet
     APD_TRY(b_sqd.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_maha.ensure((size_t)npairs * 6 * ns * 8));
     APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
     APD_TRY(b_errpart.ensure((size_t)npairs * work.nblk_max * 8));
     work.nnpart = b_nnpart.as<unsigned long long>();
     work.corr = b_corr.as<int>();
-    work.nnidx = b_nnidx.as<int>();
+    work.nnpt = b_nnpt.as<float4>();
     work.sqd = b_sqd.as<float>();
     work.maha = b_maha.as<double>();
     work.blkpart = b_blkpart.as<double>();
@@ -587,9 +590,11 @@ class Engine {
     w.pair0 = sp.p0;
     w.cap = nn_cap;
     if (nn_pruned) {
-      if (nn_S == 1) hipLaunchKernelGGL(k_nn_pruned<1>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
-      else if (nn_S == 2) hipLaunchKernelGGL(k_nn_pruned<2>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
-      else hipLaunchKernelGGL(k_nn_pruned<4>, grid, dim3(64), 0, sp.st, cd, pd, st, w);
+      if (nn_S == 1 && nn_W == 4) hipLaunchKernelGGL((k_nn_pruned<1, 4>), grid, dim3(256), 0, sp.st, cd, pd, st, w);
+      else if (nn_S == 1 && nn_W == 2) hipLaunchKernelGGL((k_nn_pruned<1, 2>), grid, dim3(128), 0, sp.st, cd, pd, st, w);
+      else if (nn_S == 1) hipLaunchKernelGGL((k_nn_pruned<1, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
+      else if (nn_S == 2) hipLaunchKernelGGL((k_nn_pruned<2, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
+      else hipLaunchKernelGGL((k_nn_pruned<4, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
     } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
     else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
     else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
@@ -667,7 +672,7 @@ class Engine {
     profile_phase = (profile_phase + 1) % profile_stride;
     // every align starts cold (hints of an earlier run would still be valid bounds, but results must
     // not depend on call history in any observable way, timing included)
-    APD_HIP(hipMemsetAsync(b_nnidx.p, 0xFF, (size_t)npairs * work.nstride * 4, stream));
+    APD_HIP(hipMemsetAsync(b_nnpt.p, 0xFF, (size_t)npairs * work.nstride * 16, stream));
     hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
                        params.max_iterations);
     const bool lm = params.optimizer == APDGICP_OPT_LM;

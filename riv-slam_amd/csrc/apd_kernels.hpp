@@ -76,7 +76,8 @@ constexpr unsigned kTieBit = 0x80000000u;  // set in a chunk id when the minimum
 struct Work {
   unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
   int* corr;                   // [pair][nstride]   correspondences_ (A:156)
-  int* nnidx;                  // [pair][nstride]   nearest neighbour found by the previous linearize, ungated (-1: none):
+  float4* nnpt;                // [pair][nstride]   nearest neighbour found by the previous linearize, ungated: its coordinates and, in
+                               //                   .w, the bits of its sorted index (-1: none) -- one coalesced load instead of index + gather:
                                //                   a warm start for the pruned search, never an input of the result
   float* sqd;                  // [pair][nstride]   sq_distances_ (A:153)
   double* maha;                // [pair][6][nstride] mahalanobis_ upper triangle (A:191)
@@ -85,7 +86,7 @@ struct Work {
   int nstride, nblk_max, T;
   float cap;                   // pruned searches: squared search radius (+inf: unbounded).  The optimiser ticks pass the smallest float
                                // >= corr_dist_threshold^2: a point without any target inside it has no correspondence whatever its
-                               // true neighbour is (A:156), so the search may stop there (sqd then holds the cap, nnidx -1)
+                               // true neighbour is (A:156), so the search may stop there (sqd then holds the cap, the hint index -1)
   int pair0, npairs;           // this launch covers pairs [pair0, pair0 + gridDim pairs) of npairs (one stream per pair group)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
@@ -511,22 +512,31 @@ constexpr int GB_BATCH = 256;  // group boxes staged per LDS batch (6 KB)
 
 // The search of k_nn_pruned for the 64*S points [base, base + 64*S) of one pair.  LDS: txy[64] float4, tz[64] float2, cbl[48], gbl[6*GB_BATCH] floats.
 // Returns the transformed points, the minimum squared distance and (chunk | kTieBit) per point.
-template <int S>
+//
+// W waves per block share the SAME 64*S points: every wave computes the bounds and the candidate groups (cheap), then
+// scans only every W-th candidate group out of its own LDS tile, and the partial minima are merged through LDS at the end.
+// The per-block latency of the scan phase drops by about W at the price of W times the waves; with the GPU mostly idle
+// during an optimiser tick that is the better trade.  txy/tz/cbl: this wave's tile; gbl: shared by the block.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // same-wave LDS write -> read
+
+template <int S, int W>
 __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T0, const Work& w, int pair, int base, int lane,
-                                          float4* txy, float2* tz, float* cbl, float* gbl, float (&px)[S], float (&py)[S], float (&pz)[S],
-                                          float (&best)[S], unsigned (&bestc)[S]) {
+                                          int wid, float4* txy, float2* tz, float* cbl, float* gbl, unsigned long long* mrg /* [W][64*S] */,
+                                          float (&px)[S], float (&py)[S], float (&pz)[S], float (&best)[S], unsigned (&bestc)[S]) {
   const int N = src.n, M = tgt.n;
-  const bool tstat = w.stats && (blockIdx.x & 15) == 0;  // phase timing: sampled waves only
+  const int tid = wid * 64 + lane;
+  const bool tstat = w.stats && wid == 0 && (blockIdx.x & 15) == 0;  // phase timing: sampled waves only
   long long tcy[4] = {0, 0, 0, 0}, tm = tstat ? clock64() : 0;
   float Tf[12];
   load_Tf(T0, Tf);
   const int ngroups = (M + kGroupPts - 1) / kGroupPts;
   const int nchunks = (M + kChunk - 1) / kChunk;
   // boxes of the first 64 target groups: requested now, parked in registers, written to LDS after the warm start
-  float gpre[6];
+  constexpr int NPRE = (6 * 64 + 64 * W - 1) / (64 * W);
+  float gpre[NPRE];
 #pragma unroll
-  for (int u = 0; u < 6; u++) {
-    const int e = u * 64 + lane;
+  for (int u = 0; u < NPRE; u++) {
+    const int e = u * 64 * W + tid;
     gpre[u] = e < 6 * min(64, ngroups) ? ((const float*)tgt.gbox)[e] : 0.f;
   }
   const float inf = __builtin_inff();
@@ -542,9 +552,9 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     const float4 p = src.pts[ii];
     px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
     best[s] = w.cap, bestc[s] = kNoChunk;
-    const int hint = w.nnidx[(size_t)pair * w.nstride + ii];
+    const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
+    const int hint = __float_as_int(t.w);
     if (hint >= 0 && hint < M) {
-      const float4 t = tgt.pts[hint];
       const float d = sqdist1(t.x, t.y, t.z, px[s], py[s], pz[s]);
       if (d < best[s]) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
     } else {
@@ -582,11 +592,11 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     }
   };
   auto commit_group = [&]() {  // registers -> the wave's LDS tile ({x0,x1,y0,y1} + {z0,z1} pairs, 8 chunk boxes)
-    __syncthreads();           // single-wave block: the previous scan is done with the tile
+    wave_lds_fence();          // the tile belongs to this wave alone: its previous scan is done with it
     txy[lane] = make_float4(pa.x, pb.x, pa.y, pb.y);
     tz[lane] = make_float2(pa.z, pb.z);
     if (lane < 6 * kGroupChunks) cbl[lane] = pc;
-    __syncthreads();
+    wave_lds_fence();
   };
   auto lane_needs = [&](const Box& bx) {
     bool need = false;
@@ -633,12 +643,13 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
 
   for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
     const int nbb = min(GB_BATCH, ngroups - gb0);
-    __syncthreads();
+    __syncthreads();  // uniform over the block's waves (the batch loop is): nobody still reads the previous batch
     if (gb0 == 0) {
 #pragma unroll
-      for (int u = 0; u < 6; u++) gbl[u * 64 + lane] = gpre[u];
+      for (int u = 0; u < NPRE; u++)
+        if (u * 64 * W + tid < 6 * 64) gbl[u * 64 * W + tid] = gpre[u];
     }
-    for (int e = (gb0 == 0 ? 6 * 64 : 0) + lane; e < 6 * nbb; e += 64) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
+    for (int e = (gb0 == 0 ? 6 * 64 : 0) + tid; e < 6 * nbb; e += 64 * W) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
     __syncthreads();
     for (int sb = 0; sb < nbb; sb += 64) {  // 64 groups at a time: their need bits fit one mask
       const int nb = min(64, nbb - sb);
@@ -687,6 +698,10 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         }
       }
       if (seed >= 0) cand &= ~(1ull << seed);
+      // This wave scans the groups with index = wid (mod W).  The split must not depend on the candidate set: after the
+      // first 64 groups the waves hold different partial minima, hence different candidate sets (a group missing from
+      // one wave's set cannot beat that wave's minimum, so it cannot beat the merged minimum either).
+      if (W > 1) cand &= (W == 2 ? 0x5555555555555555ull : 0x1111111111111111ull) << wid;
       if (tstat) { const long long t = clock64(); tcy[1] += t - tm, tm = t; }
       // software pipeline: group k+1 travels L2 -> registers while group k is scanned out of LDS
       int cur = cand ? __builtin_ctzll(cand) : -1;
@@ -706,32 +721,57 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       }
     }
   }
+  if (W > 1) {  // merge the waves' partial minima: smallest distance; the same minimum in two different chunks is a tie
+#pragma unroll
+    for (int s = 0; s < S; s++) mrg[(wid * S + s) * 64 + lane] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      float bb = __uint_as_float((unsigned)(mrg[s * 64 + lane] >> 32));
+      unsigned cc = (unsigned)mrg[s * 64 + lane];
+#pragma unroll
+      for (int o = 1; o < W; o++) {
+        const unsigned long long v = mrg[(o * S + s) * 64 + lane];
+        const float bo = __uint_as_float((unsigned)(v >> 32));
+        const unsigned co = (unsigned)v;
+        if (bo < bb) {
+          bb = bo, cc = co;
+        } else if (bo == bb && bo < inf) {
+          if ((co & ~kTieBit) != (cc & ~kTieBit)) cc |= kTieBit;
+          cc |= co & kTieBit;
+        }
+      }
+      best[s] = bb, bestc[s] = cc;
+    }
+  }
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
-  if (w.stats && lane == 0) {
+  if (w.stats && tid == 0) {
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
     atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
     if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);
   }
 }
 
-template <int S>
-__global__ __launch_bounds__(64) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
-  __shared__ float4 txy[kGroupPts / 2];
-  __shared__ float2 tz[kGroupPts / 2];
-  __shared__ float cbl[6 * kGroupChunks];
+template <int S, int W>
+__global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  __shared__ float4 txy[W][kGroupPts / 2];
+  __shared__ float2 tz[W][kGroupPts / 2];
+  __shared__ float cbl[W][6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
+  __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
   const int pair = w.pair0 + blockIdx.y;
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
   const Rigid T0 = st[pair].x0;
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
-  const int N = src.n, lane = threadIdx.x;
+  const int N = src.n, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int base = blockIdx.x * (64 * S);
   if (base >= N) return;
   float px[S], py[S], pz[S], best[S];
   unsigned bestc[S];
-  nn_search<S>(src, tgt, T0, w, pair, base, lane, txy, tz, cbl, gbl, px, py, pz, best, bestc);
+  nn_search<S, W>(src, tgt, T0, w, pair, base, lane, wid, txy[wid], tz[wid], cbl[wid], gbl, mrg, px, py, pz, best, bestc);
+  if (wid != 0) return;
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -1350,6 +1390,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
                                                 unsigned chunk, bool tie, double* acc) {
   const int N = src.n, M = tgt.n;
   int j = -1;
+  float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);  // the neighbour itself
   if (chunk != kNoChunk) {
     // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
     int jorig = 0x7fffffff;
@@ -1366,20 +1407,20 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       for (int jj = 0; jj < kChunk; jj++) {
         const int g = (int)chunk * kChunk + jj;
         const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
-        if (g < M && d == m && po[jj] < jorig) jorig = po[jj], j = g;
+        if (g < M && d == m && po[jj] < jorig) jorig = po[jj], j = g, tq = t[jj];
       }
     } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
       for (int g = 0; g < M; g++) {
         const float4 t = tgt.pts[g];
         if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
           const int o = tgt.perm[g];
-          if (o < jorig) jorig = o, j = g;
+          if (o < jorig) jorig = o, j = g, tq = t;
         }
       }
     }
   }
   w.sqd[(size_t)pair * w.nstride + i] = m;
-  w.nnidx[(size_t)pair * w.nstride + i] = j;
+  w.nnpt[(size_t)pair * w.nstride + i] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
   const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
   w.corr[(size_t)pair * w.nstride + i] = corr;
   if (corr >= 0) {
@@ -1417,7 +1458,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
     mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
 
-    const float4 q = tgt.pts[corr];
+    const float4 q = tq;  // corr == j here
     const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
     const double vx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];   // transed_mean_A, A:236
     const double vy = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
