@@ -128,7 +128,7 @@ class Engine {
   bool nn_gate_cap = true; // optimiser ticks stop the search at the correspondence gate (APDGICP_NN_GATE_CAP=0: unbounded)
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
-  bool fuse_lm = false;    // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=1): measured neutral (r01)
+  bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
   DevBuf b_ticket;
   // pair groups: the tick kernels of each group run on their own stream so that one group's short serial
   // kernels (k_lm_solve) and launch gaps overlap with the other group's wide ones
@@ -178,11 +178,11 @@ class Engine {
     nn_pruned = !(m && std::string(m) == "brute");
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
-    fuse_lm = env_int("APDGICP_FUSE", 0) != 0;
+    fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_W = env_int("APDGICP_NN_W", 2);  // measured (r01): 2 beats 1 by 5 %, 4 loses (every wave repeats the bounds and candidate tests)
     if (nn_W != 1 && nn_W != 2 && nn_W != 4) nn_W = 2;
-    ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 2)));
+    ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 3)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
       hipStream_t st_;

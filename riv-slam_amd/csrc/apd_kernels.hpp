@@ -1513,23 +1513,44 @@ constexpr int LIN_BLK = 256;
 __device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
                                               double* stage = nullptr, int prestaged = 0);
 __device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c);
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c);
+__device__ __forceinline__ void fill_from_sums(PairState& s, const double* v);
 
-// Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  Every block
-// publishes its partials with an agent-scope release before taking the ticket, the last one acquires
-// before reading them (cdna_hip_programming.md G16: placement-independent, one fence pair per block).
+// Cross-block traffic inside one launch (the rows of partial sums, read by the last block of a pair) goes through
+// agent-scope atomic loads and stores: they are coherent at device level by themselves (sc1), so no release/acquire
+// fence is needed.  On this multi-XCD part an agent-scope fence writes back / invalidates a whole L2, which is what made
+// the first fused version (fence pair per block) slower than a separate k_lm_solve launch.
+__device__ __forceinline__ double ld_coh(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coh(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// p[0] + p[stride] + ... (n terms, in index order), the coherent loads issued 16 at a time
+__device__ __forceinline__ double sum_rows_coh(const double* p, int n, int stride) {
+  double v = 0.0;
+  for (int b0 = 0; b0 < n; b0 += 16) {
+    double t[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) t[u] = ld_coh(p + (size_t)min(b0 + u, n - 1) * stride);
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (b0 + u < n) v += t[u];
+  }
+  return v;
+}
+// Arrival ticket: returns true (block-uniformly) in the LAST block of this pair to get here.  The caller has written its
+// row with st_coh; every wave waits for its own stores, then one lane draws the ticket.
 __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int tid) {
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = t == nblk - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next tick
-    }
+    if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next tick
     s_last = last;
   }
   __syncthreads();
@@ -1583,11 +1604,24 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv * 29 + tid];
-    w.blkpart[((size_t)pair * w.nblk_max + blockIdx.x) * kRed + tid] = s;
+    double* row = w.blkpart + ((size_t)pair * w.nblk_max + blockIdx.x) * kRed + tid;
+    if (want_Hb == 2) st_coh(row, s);
+    else *row = s;
   }
-  if (want_Hb == 2) {
+  if (want_Hb == 2) {  // the last block of the pair to arrive takes the GN/LM step: no k_lm_solve launch
+    __shared__ PairState ls;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
-    if (last_block_of_pair(w.ticket + pair, nblk, tid)) lm_solve_body(st[pair], w, pair, nblk, cst, red, tid);
+    if (last_block_of_pair(w.ticket + pair, nblk, tid)) {
+      if (tid < 29) red[tid] = sum_rows_coh(w.blkpart + (size_t)pair * w.nblk_max * kRed + tid, nblk, kRed);
+      for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
+      __syncthreads();
+      if (tid == 0) {
+        fill_from_sums(ls, red);
+        lm_after_gather(ls, cst);
+      }
+      __syncthreads();
+      for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
+    }
   }
 }
 
@@ -1624,11 +1658,22 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv];
-    w.errpart[(size_t)pair * w.nblk_max + blockIdx.x] = s;
+    double* row = w.errpart + (size_t)pair * w.nblk_max + blockIdx.x;
+    if (fuse) st_coh(row, s);
+    else *row = s;
   }
-  if (fuse) {
+  if (fuse) {  // the last block of the pair to arrive decides (L:145-172): no k_lm_decide launch
+    __shared__ PairState ls;
+    __shared__ double s_yi;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
-    if (last_block_of_pair(w.ticket + w.npairs + pair, nblk, tid) && tid == 0) lm_decide_body(st[pair], w, pair, nblk, cst);
+    if (last_block_of_pair(w.ticket + w.npairs + pair, nblk, tid)) {
+      if (tid == 0) s_yi = sum_rows_coh(w.errpart + (size_t)pair * w.nblk_max, nblk, 1);
+      for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
+      __syncthreads();
+      if (tid == 0) lm_decide_after_sum(ls, s_yi, cst);
+      __syncthreads();
+      for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
+    }
   }
 }
 
@@ -1747,6 +1792,9 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
 __device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c) {
   double yi = 0.0;
   for (int b = 0; b < nblk; b++) yi += w.errpart[(size_t)pair * w.nblk_max + b];
+  lm_decide_after_sum(s, yi, c);
+}
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c) {
   s.yi = yi;
   s.n_err += 1;
   double den = 0.0;
