@@ -435,55 +435,70 @@ class Engine {
   bool defer_errflag = false;  // set by the align paths: the flag is then read together with the final status
   int compute_covariances(const std::vector<int>& ids_in, bool force = false) {
     std::vector<int> ids;
-    int nmax = 0;
+    APD_TRY(filter_cov_ids(ids_in, force, ids));
+    if (ids.empty()) return 0;
+    APD_HIP(hipSetDevice(device));
+    APD_TRY(upload_desc());
+    APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), stream));
+    APD_TRY(launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), stream));
+    if (!defer_errflag) APD_TRY(check_errflag("k_knn_cov"));
+    return 0;
+  }
+  // the listed clouds that still need covariances, validated, without duplicates
+  int filter_cov_ids(const std::vector<int>& ids_in, bool force, std::vector<int>& ids) {
     for (int id : ids_in) {
       if (id < 0 || id >= (int)clouds.size() || clouds[id].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "cloud not set");
       if (clouds[id].cov_valid && !force) continue;
       if (clouds[id].n < params.k_correspondences)
         return fail(APDGICP_ERR_TOO_FEW_POINTS, "cloud has fewer points than k_correspondences");
       if (std::find(ids.begin(), ids.end(), id) == ids.end()) ids.push_back(id);
-      nmax = std::max(nmax, clouds[id].n);
     }
-    if (ids.empty()) return 0;
-    APD_HIP(hipSetDevice(device));
-    APD_TRY(upload_desc());
-    APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), stream));
+    return 0;
+  }
+  // one covariance launch for the clouds ids[0..count) (device copy of the list: d_list) on stream `st`
+  int launch_knn(const int* ids, const int* d_list, int count, hipStream_t st) {
+    if (count <= 0) return 0;
+    int nmax = 0;
+    long long total = 0;
+    for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
     if (knn_pruned) {
       // queries per wave: 64 amortises the group loads best; fewer queries per wave shorten the per-wave
       // dependency chain and shrink its LDS lists, which wins whenever the GPU is not already full
-      long long total = 0;
-      for (int id : ids) total += clouds[id].n;
       int qpw = env_int("APDGICP_KNN_QPW", 0);
       if (qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : 8;  // measured: r01 sweep
-      const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)ids.size());
+      const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
       static const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
       if (coop && qpw == 16)
-        hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
-                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+        hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else if (coop && qpw == 8)
-        hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
-                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+        hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else
-        hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), stream, d_desc.as<CloudDesc>(), d_ids.as<int>(),
-                           params.k_correspondences, params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
+        hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {
       static bool attr_set = false;
       if (!attr_set) {
         APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
         attr_set = true;
       }
-      const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)ids.size());
-      hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, stream, d_desc.as<CloudDesc>(), d_ids.as<int>(), params.k_correspondences,
+      const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)count);
+      hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                          params.regularization, d_errflag.as<int>());
     }
     APD_HIP(hipGetLastError());
-    if (!defer_errflag) APD_TRY(check_errflag("k_knn_cov"));
-    for (int id : ids) clouds[id].cov_valid = true;
+    for (int i = 0; i < count; i++) clouds[ids[i]].cov_valid = true;
     return 0;
   }
 
   // ------------------------------------------------------------------ batch set-up
-  int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess) {
+  // pipeline_cov: the covariances of clouds used by ONE pair group only are not launched here but by run_align on that
+  // group's stream, so that they overlap with the (latency-bound) optimiser ticks of the other groups
+  std::vector<int> cov_list;        // [shared clouds | group 0 | group 1 | ...]
+  std::vector<int> cov_group_off;   // offsets into cov_list: group g owns [off[g + 1], off[g + 2]); the shared part is [0, off[1])
+  int group_count() const { return std::max(1, std::min<int>((int)gstreams.size() + 1, npairs / 2)); }
+  int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
     h_pairs.resize(n);
@@ -500,10 +515,37 @@ class Engine {
       need.push_back(s), need.push_back(t);
       nmax_src = std::max(nmax_src, clouds[s].n);
     }
-    defer_errflag = true;
-    const int rc_cov = compute_covariances(need);
-    defer_errflag = false;
-    APD_TRY(rc_cov);
+    cov_list.clear();
+    cov_group_off.clear();
+    npairs = (int)n;
+    const int ng = group_count();
+    if (pipeline_cov && ng > 1 && knn_pruned) {
+      std::vector<int> ids;
+      APD_TRY(filter_cov_ids(need, false, ids));
+      // owner group of every cloud: -2 unseen, -1 shared by several groups
+      std::vector<int> owner(clouds.size(), -2);
+      for (int g = 0; g < ng; g++) {
+        const int p0 = (int)((long long)npairs * g / ng), p1 = (int)((long long)npairs * (g + 1) / ng);
+        for (int q = p0; q < p1; q++)
+          for (int id : {pairs[q].source_cloud, pairs[q].target_cloud}) owner[id] = owner[id] == -2 || owner[id] == g ? g : -1;
+      }
+      cov_group_off.assign(ng + 2, 0);
+      for (int g = -1; g < ng; g++) {
+        for (int id : ids)
+          if (owner[id] == g) cov_list.push_back(id);
+        cov_group_off[g + 2] = (int)cov_list.size();
+      }
+      APD_TRY(upload_desc());
+      if (!cov_list.empty()) {
+        APD_TRY(d_ids.upload(cov_list.data(), cov_list.size() * sizeof(int), stream));
+        APD_TRY(launch_knn(cov_list.data(), d_ids.as<int>(), cov_group_off[1], stream));  // clouds shared between groups: now
+      }
+    } else {
+      defer_errflag = true;
+      const int rc_cov = compute_covariances(need);
+      defer_errflag = false;
+      APD_TRY(rc_cov);
+    }
     APD_TRY(upload_desc());
     for (int64_t i = 0; i < n; i++) h_pairs[i].s = h_desc[h_pairs[i].src], h_pairs[i].t = h_desc[h_pairs[i].tgt];
     npairs = (int)n;
@@ -688,10 +730,17 @@ class Engine {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
       // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
-      const int ng = std::max(1, std::min<int>((int)gstreams.size() + 1, npairs / 2));
+      const int ng = group_count();
       if (ng > 1) {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
+      }
+      if (ticks == 0 && (int)cov_group_off.size() == ng + 2) {  // this group's own clouds: behind the fork, in front of its ticks
+        for (int g = 0; g < ng; g++) {
+          const int o0 = cov_group_off[g + 1], o1 = cov_group_off[g + 2];
+          APD_TRY(launch_knn(cov_list.data() + o0, d_ids.as<int>() + o0, o1 - o0, g == 0 ? stream : gstreams[g - 1]));
+        }
+        cov_group_off.clear();
       }
       for (int t = 0; t < todo; t++, cur_tick++)
         for (int g = 0; g < ng; g++) {

@@ -554,7 +554,7 @@ int apdgicp_batch_compute_covariances(apdgicp_batch* b) {
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results) {
   return guarded([&]() -> int {
     if (!b || !pairs) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
-    APD_TRY(b->eng.setup_pairs(pairs, n_pairs, true));
+    APD_TRY(b->eng.setup_pairs(pairs, n_pairs, true, /*pipeline_cov=*/true));
     APD_TRY(b->eng.run_align());
     if (d_results) *d_results = b->eng.d_results.p;
     return 0;
