@@ -119,7 +119,8 @@ class Engine {
   std::vector<float> h_guesses;
   DevBuf d_state, d_results, d_status, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
-  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs;
+  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3];
+  bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
   DevBuf b_nnpart, b_corr, b_nnpt, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
@@ -180,6 +181,7 @@ class Engine {
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
+    sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
     nn_W = env_int("APDGICP_NN_W", 2);  // measured (r01): 2 beats 1 by 5 %, 4 loses (every wave repeats the bounds and candidate tests)
     if (nn_W != 1 && nn_W != 2 && nn_W != 4) nn_W = 2;
     ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 3)));
@@ -200,7 +202,7 @@ class Engine {
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
-    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs}) t->dev.release();
+    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2]}) t->dev.release();
     for (DevBuf* b : {&d_state, &d_results, &d_status, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
@@ -323,7 +325,7 @@ class Engine {
 
   // Z-curve sort + chunk/group boxes of every cloud that was (re)set since the last call
   int sort_clouds() {
-    std::vector<SortJob> small;
+    std::vector<SortJob> small, regjobs[3];
     std::vector<int> large;
     int np2max = 1;
     bool grew = false;
@@ -346,10 +348,14 @@ class Engine {
         SortJob j;
         j.pts = c.opts.as<float4>(), j.spts = c.pts.as<float4>(), j.perm = c.perm.as<int>();
         j.cbox = c.cbox.as<Box>(), j.gbox = c.gbox.as<Box>(), j.n = c.n, j.pad_ = 0;
-        small.push_back(j);
-        int np2 = 1;
-        while (np2 < c.n) np2 <<= 1;
-        np2max = std::max(np2max, np2);
+        if (c.n > 2048 && sort_in_registers) {  // k_sort_cloud_reg<E>: 1024*E/2 < n <= 1024*E
+          regjobs[c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2].push_back(j);
+        } else {
+          small.push_back(j);
+          int np2 = 1;
+          while (np2 < c.n) np2 <<= 1;
+          np2max = std::max(np2max, np2);
+        }
       } else {
         large.push_back((int)i);
       }
@@ -364,6 +370,23 @@ class Engine {
         attr_set = true;
       }
       hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_sortjobs.as<SortJob>());
+      APD_HIP(hipGetLastError());
+    }
+    for (int cls = 0; cls < 3; cls++) {
+      if (regjobs[cls].empty()) continue;
+      APD_TRY(d_sortjobs_reg[cls].upload(regjobs[cls].data(), regjobs[cls].size() * sizeof(SortJob), stream));
+      const void* fn = cls == 0 ? (const void*)k_sort_cloud_reg<4> : cls == 1 ? (const void*)k_sort_cloud_reg<8> : (const void*)k_sort_cloud_reg<16>;
+      const size_t lds = (size_t)(4 << cls) * SORT_BLK * 8;
+      static bool attr_set[3] = {false, false, false};
+      if (!attr_set[cls]) {
+        APD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[cls] = true;
+      }
+      const SortJob* dj = d_sortjobs_reg[cls].as<SortJob>();
+      const dim3 grid((unsigned)regjobs[cls].size());
+      if (cls == 0) hipLaunchKernelGGL(k_sort_cloud_reg<4>, grid, dim3(SORT_BLK), lds, stream, dj);
+      else if (cls == 1) hipLaunchKernelGGL(k_sort_cloud_reg<8>, grid, dim3(SORT_BLK), lds, stream, dj);
+      else hipLaunchKernelGGL(k_sort_cloud_reg<16>, grid, dim3(SORT_BLK), lds, stream, dj);
       APD_HIP(hipGetLastError());
     }
     for (int id : large) {  // generic path: keys in global memory, one launch per bitonic stage

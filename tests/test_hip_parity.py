@@ -440,6 +440,28 @@ def test_pruned_search_is_bitwise_the_brute_force_search(reg, scene):
         assert np.array_equal(Ta, Tb) and info_of(a) == info_of(b)
 
 
+def test_register_sort_equals_lds_sort(reg, scene):
+    """k_sort_cloud_reg<4|8|16> (keys in registers, shuffles, few barriers) must produce the permutation and the boxes of
+    k_sort_cloud_lds: everything downstream -- covariances, correspondences, fp32 distances -- is bitwise the same."""
+    import os
+    for n, m in ((2049, 4096), (4097, 8192), (8193, 12000), (16384, 9000)):
+        src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(8, n), "odometry")
+        out = []
+        for flag in ("1", "0"):
+            os.environ["APDGICP_SORT_REG"] = flag
+            try:
+                g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
+            finally:
+                os.environ.pop("APDGICP_SORT_REG", None)
+            g.setInputSource(src)
+            g.setInputTarget(tgt)
+            c, H, b = g.linearize(guess.astype(np.float64))
+            corr, sqd = g.correspondences()
+            out.append((g.getSourceCovariances(), g.getTargetCovariances(), corr, sqd, c, H, b))
+        for x, y in zip(*out):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_exact_ties_resolve_to_the_lowest_original_index(reg):
     """A source point exactly midway between two target points (equal fp32 distances, far apart on the
     Z-curve) and duplicated target points: the oracle's rule is (distance, index) lexicographic."""
