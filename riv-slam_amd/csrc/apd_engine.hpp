@@ -603,7 +603,6 @@ class Engine {
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_nnpt.ensure((size_t)npairs * ns * 16));
-    APD_HIP(hipMemsetAsync(b_nnpt.p, 0xFF, (size_t)npairs * ns * 16, stream));  // index bits -1: no warm start yet
     APD_TRY(b_sqd.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_maha.ensure((size_t)npairs * 6 * ns * 8));
     APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
@@ -735,23 +734,30 @@ class Engine {
     cur_tick = 0;
     profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 5));
     profile_phase = (profile_phase + 1) % profile_stride;
-    // every align starts cold (hints of an earlier run would still be valid bounds, but results must
-    // not depend on call history in any observable way, timing included)
-    APD_HIP(hipMemsetAsync(b_nnpt.p, 0xFF, (size_t)npairs * work.nstride * 16, stream));
+    // every align starts cold: k_init_state zeroes n_lin, and the search ignores the hint array until the first linearize of
+    // this align has rewritten it (hints of an earlier run would still be valid bounds, but nothing observable -- timing
+    // included -- may depend on call history)
     hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
                        params.max_iterations);
     const bool lm = params.optimizer == APDGICP_OPT_LM;
     const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
     // LM: the loop length is data dependent, poll every few ticks.  GN runs max_iterations ticks unless a
     // pair hits an exactly-zero step, so one poll at the end is enough.
-    const int chunk = std::max(1, env_int("APDGICP_POLL_TICKS", lm ? 4 : std::min(64, std::max(1, params.max_iterations))));
+    // LM polls after 1, then 2, then every 4 ticks: with the shipped parameters most registrations converge in 1-3
+    // iterations, and every tick enqueued past convergence is three empty launches
+    const int chunk_cfg = env_int("APDGICP_POLL_TICKS", 0);
+    auto chunk_at = [&](long long done) {
+      if (chunk_cfg > 0) return chunk_cfg;
+      if (!lm) return std::min(64, std::max(1, params.max_iterations));
+      return done == 0 ? 1 : done < 3 ? 2 : 4;
+    };
     long long ticks = 0;
     bool all_done = params.max_iterations <= 0;
     const bool dbg_t = env_int("APDGICP_DEBUG_TIMING", 0) != 0;
     const auto t_begin = std::chrono::steady_clock::now();
     while (!all_done && ticks < tick_cap) {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
-      const int todo = (int)std::min<long long>(chunk, tick_cap - ticks);
+      const int todo = (int)std::min<long long>(chunk_at(ticks), tick_cap - ticks);
       // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
       const int ng = group_count();
       if (ng > 1) {

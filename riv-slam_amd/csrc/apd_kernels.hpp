@@ -521,7 +521,7 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 
 template <int S, int W>
 __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T0, const Work& w, int pair, int base, int lane,
-                                          int wid, float4* txy, float2* tz, float* cbl, float* gbl, unsigned long long* mrg /* [W][64*S] */,
+                                          int wid, bool cold, float4* txy, float2* tz, float* cbl, float* gbl, unsigned long long* mrg /* [W][64*S] */,
                                           float (&px)[S], float (&py)[S], float (&pz)[S], float (&best)[S], unsigned (&bestc)[S]) {
   const int N = src.n, M = tgt.n;
   const int tid = wid * 64 + lane;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
     best[s] = w.cap, bestc[s] = kNoChunk;
     const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
-    const int hint = __float_as_int(t.w);
+    const int hint = cold ? -1 : __float_as_int(t.w);
     if (hint >= 0 && hint < M) {
       const float d = sqdist1(t.x, t.y, t.z, px[s], py[s], pz[s]);
       if (d < best[s]) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
@@ -761,6 +761,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
   const int pair = w.pair0 + blockIdx.y;
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
+  const bool cold = st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
   const PairDesc pd = pairs[pair];
   const Rigid T0 = st[pair].x0;
   if (status != ST_NEED_LIN) return;
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   if (base >= N) return;
   float px[S], py[S], pz[S], best[S];
   unsigned bestc[S];
-  nn_search<S, W>(src, tgt, T0, w, pair, base, lane, wid, txy[wid], tz[wid], cbl[wid], gbl, mrg, px, py, pz, best, bestc);
+  nn_search<S, W>(src, tgt, T0, w, pair, base, lane, wid, cold, txy[wid], tz[wid], cbl[wid], gbl, mrg, px, py, pz, best, bestc);
   if (wid != 0) return;
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
 #pragma unroll
@@ -1893,6 +1894,7 @@ __global__ void k_set_poses(PairState* st, const float* T16, int npairs) {
       for (int c2 = 0; c2 < 4; c2++) s.x0.m[4 * r + c2] = (double)g[r + 4 * c2];
   }
   s.status = ST_NEED_LIN;
+  s.n_lin = 0;  // cold search (see k_set_probe)
 }
 
 // probe support: put pair 0 into a given state at pose T (column-major double 4x4)
@@ -1905,6 +1907,7 @@ __global__ void k_set_probe(PairState* st, const double* T16, int status, int us
   if (use_xi) s.xi = r;
   else s.x0 = r;
   s.status = status;
+  s.n_lin = 0;  // probes always search cold: the hint array may describe another pair or pose
 }
 
 // probe support: reduce the linearize / error partials of pair 0 into out[0..43]:
