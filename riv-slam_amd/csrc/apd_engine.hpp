@@ -117,7 +117,7 @@ class Engine {
   std::vector<PairDesc> h_pairs;
   std::vector<CloudDesc> h_desc;  // host copy of the descriptor table (valid while !desc_dirty)
   std::vector<float> h_guesses;
-  DevBuf d_state, d_results, d_status, d_errflag, d_probe, d_stage, d_T;
+  DevBuf d_state, d_results, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
   CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3];
   bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
@@ -137,7 +137,11 @@ class Engine {
   std::vector<hipEvent_t> gevents;
   hipEvent_t ev_main = nullptr;
   int ngroups_cfg = 2;
-  int* h_status = nullptr;   // pinned
+  static constexpr int kHostResults = 256;  // batches up to this size get their records with the status poll
+  char* h_poll = nullptr;    // pinned: [records][status words + error flag] of the last poll
+  int* h_status = nullptr;   // inside h_poll (or, for check_errflag, at its start)
+  bool results_on_host = false;
+  const ResultRec* host_results() const { return results_on_host ? (const ResultRec*)h_poll : nullptr; }
   double* h_probe = nullptr; // pinned, 48 doubles
   hipEvent_t ev_poll = nullptr;
 
@@ -164,7 +168,8 @@ class Engine {
       APD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       own_stream = true;
     }
-    APD_HIP(hipHostMalloc((void**)&h_status, 65540 * sizeof(int), hipHostMallocDefault));
+    APD_HIP(hipHostMalloc((void**)&h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
+    h_status = (int*)h_poll;
     APD_HIP(hipHostMalloc((void**)&h_probe, 64 * sizeof(double), hipHostMallocDefault));
     APD_HIP(hipEventCreateWithFlags(&ev_poll, hipEventDisableTiming));
     APD_TRY(d_errflag.ensure(sizeof(int)));
@@ -203,10 +208,10 @@ class Engine {
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2]}) t->dev.release();
-    for (DevBuf* b : {&d_state, &d_results, &d_status, &d_errflag, &d_probe, &d_stage, &d_T,
+    for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
-    if (h_status) e = hipHostFree(h_status);
+    if (h_poll) e = hipHostFree(h_poll);
     if (h_probe) e = hipHostFree(h_probe);
     if (ev_poll) e = hipEventDestroy(ev_poll);
     if (ev_main) e = hipEventDestroy(ev_main);
@@ -439,9 +444,10 @@ class Engine {
 
   int check_errflag(const char* what) {
     int flag = 0;
-    APD_HIP(hipMemcpyAsync(h_status, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    int* h_flag = (int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65539;  // last pinned word: never part of a poll
+    APD_HIP(hipMemcpyAsync(h_flag, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     APD_HIP(hipStreamSynchronize(stream));
-    flag = h_status[0];
+    flag = h_flag[0];
     if (flag && env_int("APDGICP_IGNORE_ERRFLAG", 0)) {  // debugging aid only
       fprintf(stderr, "[apdgicp] %s: device error flag %d ignored\n", what, flag);
       APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
@@ -574,8 +580,7 @@ class Engine {
     npairs = (int)n;
     if ((size_t)n * sizeof(PairState) > d_state.cap) APD_HIP(hipStreamSynchronize(stream));
     APD_TRY(d_state.ensure(n * sizeof(PairState)));
-    APD_TRY(d_results.ensure(n * sizeof(ResultRec)));
-    APD_TRY(d_status.ensure((n + 1) * sizeof(int)));
+    APD_TRY(d_results.ensure(n * sizeof(ResultRec) + (n + 1) * sizeof(int)));  // records, then the status words of the poll
     APD_TRY(d_pairs.upload(h_pairs.data(), n * sizeof(PairDesc), stream));
     (void)with_guess;
     APD_TRY(d_guess.upload(guesses.data(), guesses.size() * sizeof(float), stream));
@@ -781,9 +786,19 @@ class Engine {
         APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
       }
       ticks += todo;
-      hipLaunchKernelGGL(k_copy_status, dim3((npairs + 255) / 256), dim3(256), 0, stream, d_state.as<PairState>(), d_status.as<int>(), npairs,
+      // poll = finalize: the result records and, right behind them in the same buffer, the status words and the error
+      // flag; small batches bring the records home in the same copy, so align() needs no second round trip
+      int* d_stat = (int*)(d_results.as<char>() + (size_t)npairs * sizeof(ResultRec));
+      hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), d_stat, npairs,
                          d_errflag.as<int>());
-      APD_HIP(hipMemcpyAsync(h_status, d_status.p, (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      results_on_host = npairs <= kHostResults;
+      if (results_on_host) {
+        APD_HIP(hipMemcpyAsync(h_poll, d_results.p, (size_t)npairs * sizeof(ResultRec) + (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        h_status = (int*)(h_poll + (size_t)npairs * sizeof(ResultRec));
+      } else {
+        h_status = (int*)h_poll;
+        APD_HIP(hipMemcpyAsync(h_status, d_stat, (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+      }
       APD_HIP(hipEventRecord(ev_poll, stream));
       const auto t_enq = std::chrono::steady_clock::now();
       APD_HIP(hipEventSynchronize(ev_poll));
@@ -798,10 +813,13 @@ class Engine {
         if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, "device error flag " + std::to_string(flag) + " (covariance k-NN)");
       }
     }
-    if (params.max_iterations <= 0) APD_TRY(check_errflag("k_knn_cov"));
     last_ticks = (int)ticks;
-    hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), (int*)nullptr,
-                       npairs);
+    if (ticks == 0) {  // max_iterations <= 0: no tick, no poll -- the records of the initial state
+      APD_TRY(check_errflag("k_knn_cov"));
+      results_on_host = false;
+      hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), (int*)nullptr,
+                         npairs, (const int*)nullptr);
+    }
     APD_HIP(hipGetLastError());
     if (profile_nn) {
       APD_HIP(hipStreamSynchronize(stream));

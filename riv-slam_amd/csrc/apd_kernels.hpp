@@ -1935,8 +1935,10 @@ __global__ __launch_bounds__(64) void k_probe_reduce(const CloudDesc* clouds, co
   }
 }
 
-__global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs) {
+// also the poll: status_out (optional) receives every pair's status and, behind them, the device error flag
+__global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs, const int* err_flag) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0 && status_out) status_out[npairs] = err_flag ? *err_flag : 0;
   if (p >= npairs) return;
   const PairState& s = st[p];
   ResultRec r;
@@ -1952,12 +1954,6 @@ __global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out,
   r.n_matched = s.n_matched;
   out[p] = r;
   if (status_out) status_out[p] = s.status;
-}
-
-__global__ void k_copy_status(const PairState* st, int* status_out, int npairs, const int* err_flag) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < npairs) status_out[p] = st[p].status;
-  if (p == 0) status_out[npairs] = *err_flag;  // the device error flag rides along with the poll
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}

@@ -298,8 +298,12 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
     else identity16(g);
     APD_TRY(e.d_guess.upload(g, sizeof(g), e.stream));
     APD_TRY(e.run_align());
-    APD_HIP(hipMemcpyAsync(out, e.d_results.p, sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
-    APD_HIP(hipStreamSynchronize(e.stream));
+    if (const ResultRec* r = e.host_results()) {  // came home with the last poll
+      memcpy(out, r, sizeof(apdgicp_result));
+    } else {
+      APD_HIP(hipMemcpyAsync(out, e.d_results.p, sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
+      APD_HIP(hipStreamSynchronize(e.stream));
+    }
     h->have_corr = out->n_linearize > 0;
     return 0;
   });
@@ -566,6 +570,10 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
     if (!results) return fail(APDGICP_ERR_INVALID_ARG, "results is null");
     APD_TRY(apdgicp_batch_align_async(b, pairs, n_pairs, nullptr));
     Engine& e = b->eng;
+    if (const ResultRec* r = e.host_results()) {
+      memcpy(results, r, n_pairs * sizeof(apdgicp_result));
+      return 0;
+    }
     APD_HIP(hipMemcpyAsync(results, e.d_results.p, n_pairs * sizeof(apdgicp_result), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
     return 0;
