@@ -494,11 +494,14 @@ class Engine {
       // queries per wave: 64 amortises the group loads best; fewer queries per wave shorten the per-wave
       // dependency chain and shrink its LDS lists, which wins whenever the GPU is not already full
       int qpw = env_int("APDGICP_KNN_QPW", 0);
-      if (qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : 8;  // measured: r01 sweep
+      if (qpw != 4 && qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;  // measured (r01): 2 clouds of 8k 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
       static const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
       if (coop && qpw == 16)
         hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+      else if (coop && qpw == 4)
+        hipLaunchKernelGGL(k_knn_cov_coop<16>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else if (coop && qpw == 8)
         hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,

@@ -1081,16 +1081,20 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
   const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
   return ((unsigned long long)hi << 32) | lo;
 }
-// butterflies over aligned groups of L lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then (L == 8)
-// row_half_mirror, which pairs every lane with one of the other quad once the quads are uniform
+// butterflies over aligned groups of L lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then (L >= 8) row_half_mirror and
+// (L == 16) row_mirror, which pair every lane with one of the other half once the halves are uniform
 template <int L>
 __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
   unsigned long long o = dpp_u64<0xB1>(v);
   v = o < v ? o : v;
   o = dpp_u64<0x4E>(v);
   v = o < v ? o : v;
-  if (L == 8) {
-    o = dpp_u64<0x141>(v);
+  if (L >= 8) {
+    o = dpp_u64<0x141>(v);  // row_half_mirror
+    v = o < v ? o : v;
+  }
+  if (L == 16) {
+    o = dpp_u64<0x140>(v);  // row_mirror: pairs the two (by now uniform) halves of the 16-lane row
     v = o < v ? o : v;
   }
   return v;
@@ -1099,7 +1103,8 @@ template <int L>
 __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v) {
   v |= dpp_u64<0xB1>(v);
   v |= dpp_u64<0x4E>(v);
-  if (L == 8) v |= dpp_u64<0x141>(v);
+  if (L >= 8) v |= dpp_u64<0x141>(v);
+  if (L == 16) v |= dpp_u64<0x140>(v);
   return v;
 }
 
@@ -1107,7 +1112,7 @@ template <int L>
 __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                      unsigned long long* stats) {
   constexpr int QPW = 64 / L, NCL = KNN_NC / L, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
-  static_assert(L == 4 || L == 8, "L lanes per query");
+  static_assert(L == 4 || L == 8 || L == 16, "L lanes per query");
   static_assert(KQ_CAP % L == 0 && KQ_WIN % KNN_NC == 0, "layout");
   extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
