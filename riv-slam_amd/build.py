@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libapdgicp_hip.so")
 SOURCES = ["apdgicp_hip.hip"]
-DEPS = ["apdgicp_hip.hip", "apd_engine.hpp", "apd_kernels.hpp", "apd_math.hpp", os.path.join("..", "..", "include", "apdgicp_hip.h")]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os.path.join("..", "..", "include", "apdgicp_hip.h")]  # every source the one translation unit includes
 FLAGS = [*os.environ.get("APD_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
