@@ -149,14 +149,33 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_lds(const SortJob* jobs
 // k_sort_cloud_reg<E>: the same job for 1024*E/2 < n <= 1024*E points (E = 4, 8, 16) with the keys in REGISTERS:
 // thread t owns the E keys of positions t*E .. t*E+E-1.  A bitonic stage with stride j
 //   j < E          is a compare-exchange between two registers of the same thread,
-//   E <= j < 64*E  exchanges with lane (lane ^ j/E) of the same wave through ds_bpermute -- no barrier,
+//   E <= j < 64*E  exchanges with lane (lane ^ j/E) of the same wave -- DPP for lane distances 1, 2, 4, 8 (pure VALU),
+//                  ds_bpermute for 16 and 32 -- no barrier,
 //   j >= 64*E      goes through LDS (slot e*1024 + t: conflict-free) with two barriers;
 // for 8192 keys that leaves 10 barrier stages out of 91 (k_sort_cloud_lds pays a barrier in every one of them).
+// Every stride is a compile-time constant (fully unrolled stage loops): key[] is only ever indexed statically and the
+// DPP controls are immediates.  118 us (LDS version) -> 58 us for 8192 keys, bound by the one CU a block runs on.
 // The sort is a total order of unique keys, so the permutation is the one k_sort_cloud_lds produces.
 // The sorted points are gathered once into registers and serve the copy, the chunk boxes (16/E neighbouring lanes)
 // and the group boxes (128/E lanes) through xor-shuffles.
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-  const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+// value of lane (lane ^ m): DPP (pure VALU) for m = 1, 2 (quad_perm), 4 (row_shl/row_shr 4, selected by lane bit 2) and
+// 8 (row_ror 8); ds_bpermute only for 16 and 32
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned v, int m, int lane) {
+  switch (m) {
+    case 1: return dpp_mov<0xB1>(v);
+    case 2: return dpp_mov<0x4E>(v);
+    case 4: {
+      const unsigned up = dpp_mov<0x104>(v), dn = dpp_mov<0x114>(v);  // row_shl:4 = lane + 4, row_shr:4 = lane - 4
+      return (lane & 4) ? dn : up;
+    }
+    case 8: return dpp_mov<0x128>(v);  // row_ror:8
+    default: return __shfl_xor(v, m, 64);
+  }
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m, int lane) {
+  const unsigned lo = lane_xor_u32((unsigned)v, m, lane), hi = lane_xor_u32((unsigned)(v >> 32), m, lane);
   return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -194,30 +213,39 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_reg(const SortJob* jobs
     const int i = tid * E + e;
     key[e] = i < n ? ((unsigned long long)morton30(p[e].x, p[e].y, p[e].z, lx, ly, lz, scale) << 32) | (unsigned)i : ~0ull;
   }
+#pragma unroll
   for (int k = 2; k <= NP; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64 * E) {  // partner in another wave: through LDS
-        const int pt = tid ^ (j / E);
-        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; e++) xch[e * SORT_BLK + tid] = key[e];
-        __syncthreads();
+    for (int j = k >> 1; j >= 64 * E; j >>= 1) {  // partner in another wave: through LDS
+      const int pt = tid ^ (j / E);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) xch[e * SORT_BLK + tid] = key[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int i = tid * E + e;
+        const unsigned long long o = xch[e * SORT_BLK + pt];
+        const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+        key[e] = ((o < key[e]) == take_min) ? o : key[e];
+      }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {  // partner lane (lane ^ m) of the same wave; compile-time m: DPP where it exists
+      const int j = m * E;
+      if (j < k) {
 #pragma unroll
         for (int e = 0; e < E; e++) {
           const int i = tid * E + e;
-          const unsigned long long o = xch[e * SORT_BLK + pt];
+          const unsigned long long o = shfl_xor_u64(key[e], m, tid & 63);
           const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-          key[e] = take_min ? (o < key[e] ? o : key[e]) : (o > key[e] ? o : key[e]);
+          key[e] = ((o < key[e]) == take_min) ? o : key[e];
         }
-      } else if (j >= E) {  // partner lane of the same wave
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-          const int i = tid * E + e;
-          const unsigned long long o = shfl_xor_u64(key[e], j / E);
-          const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-          key[e] = take_min ? (o < key[e] ? o : key[e]) : (o > key[e] ? o : key[e]);
-        }
-      } else {  // both keys in this thread
+    for (int j = E / 2; j > 0; j >>= 1) {  // strides below E: both keys in this thread, compile-time register indices
+      if (j < k) {
 #pragma unroll
         for (int e = 0; e < E; e++) {
           if ((e & j) == 0) {
