@@ -215,7 +215,6 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_reg(const SortJob* jobs
   }
 #pragma unroll
   for (int k = 2; k <= NP; k <<= 1) {
-#pragma unroll
     for (int j = k >> 1; j >= 64 * E; j >>= 1) {  // partner in another wave: through LDS
       const int pt = tid ^ (j / E);
       __syncthreads();
