@@ -397,7 +397,7 @@ class Engine {
     for (int id : large) {  // generic path: keys in global memory, one launch per bitonic stage
       Cloud& c = clouds[id];
       const int n = c.n;
-      int np2 = 1;
+      int np2 = VOX_TILE;
       while (np2 < n) np2 <<= 1;
       APD_HIP(hipStreamSynchronize(stream));
       APD_TRY(d_keys.ensure((size_t)np2 * 8));
@@ -408,9 +408,12 @@ class Engine {
       hipLaunchKernelGGL(k_bbox_atomic, dim3((n + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, d_box6.as<int>());
       hipLaunchKernelGGL(k_morton_keys, dim3((np2 + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, np2, d_box6.as<int>(),
                          d_keys.as<unsigned long long>());
-      for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1)
+      hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>());
+      for (int k = 2 * VOX_TILE; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j >= VOX_TILE; j >>= 1)
           hipLaunchKernelGGL(k_bitonic_global, dim3((np2 / 2 + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), np2, k, j);
+        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>(), k);
+      }
       hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), c.opts.as<float4>(), n,
                          c.pts.as<float4>(), c.perm.as<int>());
       const int nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;

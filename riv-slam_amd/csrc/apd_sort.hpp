@@ -339,6 +339,39 @@ __global__ void k_bitonic_global(unsigned long long* keys, int np2, int k, int j
   if ((a > b) == up) keys[i] = b, keys[l] = a;
 }
 
+// ---- the same sort with LDS tiles of VOX_TILE keys: k_bitonic_global only for strides >= VOX_TILE, one tile kernel for the
+// rest of every merge stage (35 launches for 2^19 keys instead of 190); also used by the voxel filter (apd_voxel.hpp)
+constexpr int VOX_TILE = 4096;
+__device__ __forceinline__ void tile_steps(unsigned long long* t, int base, int k, int jmax, int tid) {
+  for (int j = jmax; j > 0; j >>= 1) {
+    for (int q = tid; q < VOX_TILE / 2; q += 1024) {
+      const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+      const bool up = ((base + i) & k) == 0;
+      const unsigned long long a = t[i], b = t[l];
+      if ((a > b) == up) t[i] = b, t[l] = a;
+    }
+    __syncthreads();
+  }
+}
+// full sort of every tile (the directions alternate as the later merges expect)
+__global__ __launch_bounds__(1024) void k_bitonic_tile_sort(unsigned long long* keys) {
+  __shared__ unsigned long long t[VOX_TILE];
+  const int base = blockIdx.x * VOX_TILE, tid = threadIdx.x;
+  for (int q = tid; q < VOX_TILE; q += 1024) t[q] = keys[base + q];
+  __syncthreads();
+  for (int k = 2; k <= VOX_TILE; k <<= 1) tile_steps(t, base, k, k >> 1, tid);
+  for (int q = tid; q < VOX_TILE; q += 1024) keys[base + q] = t[q];
+}
+// the strides < VOX_TILE of merge stage k
+__global__ __launch_bounds__(1024) void k_bitonic_tile_merge(unsigned long long* keys, int k) {
+  __shared__ unsigned long long t[VOX_TILE];
+  const int base = blockIdx.x * VOX_TILE, tid = threadIdx.x;
+  for (int q = tid; q < VOX_TILE; q += 1024) t[q] = keys[base + q];
+  __syncthreads();
+  tile_steps(t, base, k, VOX_TILE >> 1, tid);
+  for (int q = tid; q < VOX_TILE; q += 1024) keys[base + q] = t[q];
+}
+
 __global__ void k_gather_sorted(const unsigned long long* keys, const float4* pts, int n, float4* spts, int* perm) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;

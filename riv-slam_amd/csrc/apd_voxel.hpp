@@ -117,37 +117,7 @@ __global__ void k_vox_keys(const float4* pts, int n, int np2, const int* box6, f
   keys[i] = key;
 }
 
-// ---- bitonic sort of u64 keys, LDS tiles of VOX_TILE keys + global steps for the long strides
-constexpr int VOX_TILE = 4096;
-__device__ __forceinline__ void tile_steps(unsigned long long* t, int base, int k, int jmax, int tid) {
-  for (int j = jmax; j > 0; j >>= 1) {
-    for (int q = tid; q < VOX_TILE / 2; q += 1024) {
-      const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
-      const bool up = ((base + i) & k) == 0;
-      const unsigned long long a = t[i], b = t[l];
-      if ((a > b) == up) t[i] = b, t[l] = a;
-    }
-    __syncthreads();
-  }
-}
-// full sort of every tile (the directions alternate as the later merges expect)
-__global__ __launch_bounds__(1024) void k_bitonic_tile_sort(unsigned long long* keys) {
-  __shared__ unsigned long long t[VOX_TILE];
-  const int base = blockIdx.x * VOX_TILE, tid = threadIdx.x;
-  for (int q = tid; q < VOX_TILE; q += 1024) t[q] = keys[base + q];
-  __syncthreads();
-  for (int k = 2; k <= VOX_TILE; k <<= 1) tile_steps(t, base, k, k >> 1, tid);
-  for (int q = tid; q < VOX_TILE; q += 1024) keys[base + q] = t[q];
-}
-// the strides < VOX_TILE of merge stage k
-__global__ __launch_bounds__(1024) void k_bitonic_tile_merge(unsigned long long* keys, int k) {
-  __shared__ unsigned long long t[VOX_TILE];
-  const int base = blockIdx.x * VOX_TILE, tid = threadIdx.x;
-  for (int q = tid; q < VOX_TILE; q += 1024) t[q] = keys[base + q];
-  __syncthreads();
-  tile_steps(t, base, k, VOX_TILE >> 1, tid);
-  for (int q = tid; q < VOX_TILE; q += 1024) keys[base + q] = t[q];
-}
+// (the u64 bitonic sort -- k_bitonic_tile_sort / k_bitonic_global / k_bitonic_tile_merge -- lives in apd_sort.hpp)
 
 // ---- voxel heads and their output slots: exclusive scan of the head flags (4096 per block, then the block sums)
 constexpr int SCAN_ITEMS = 4;
