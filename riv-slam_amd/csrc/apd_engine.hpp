@@ -74,18 +74,42 @@ inline int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-// A small host->device table that is re-uploaded only when its contents change.  The host copy lives
-// in the object, so the asynchronous copy never reads a dead local; a changed table is uploaded after
-// a stream synchronisation (kernels still queued may be reading the old one).
+// A small host->device table that is re-uploaded only when its contents change.  A changed table goes through one of two
+// pinned staging buffers and an asynchronous copy on the caller's stream -- stream order already keeps it behind the
+// kernels that still read the old contents -- and the host never waits for the GPU: a staging buffer is only rewritten
+// after the event recorded behind ITS last copy has fired (normally long ago).
 struct CachedTable {
   DevBuf dev;
-  std::vector<char> host;
+  std::vector<char> host;  // last uploaded contents (for the comparison)
+  char* pin[2] = {nullptr, nullptr};
+  size_t pin_cap[2] = {0, 0};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int cur = 0;
+  ~CachedTable() {
+    for (int i = 0; i < 2; i++) {
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+  }
   int upload(const void* data, size_t bytes, hipStream_t stream) {
     if (dev.p && host.size() == bytes && (bytes == 0 || memcmp(host.data(), data, bytes) == 0)) return 0;
-    APD_HIP(hipStreamSynchronize(stream));
     host.assign((const char*)data, (const char*)data + bytes);
+    if (std::max<size_t>(bytes, 16) > dev.cap) APD_HIP(hipStreamSynchronize(stream));  // the old device buffer is about to be freed
     APD_TRY(dev.ensure(std::max<size_t>(bytes, 16)));
-    if (bytes) APD_HIP(hipMemcpyAsync(dev.p, host.data(), bytes, hipMemcpyHostToDevice, stream));
+    if (!bytes) return 0;
+    cur ^= 1;
+    if (!ev[cur]) APD_HIP(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
+    else APD_HIP(hipEventSynchronize(ev[cur]));
+    if (bytes > pin_cap[cur]) {
+      if (pin[cur]) APD_HIP(hipHostFree(pin[cur]));
+      pin[cur] = nullptr, pin_cap[cur] = 0;
+      const size_t cap = std::max<size_t>(bytes * 2, 256);
+      APD_HIP(hipHostMalloc((void**)&pin[cur], cap, hipHostMallocDefault));
+      pin_cap[cur] = cap;
+    }
+    memcpy(pin[cur], data, bytes);
+    APD_HIP(hipMemcpyAsync(dev.p, pin[cur], bytes, hipMemcpyHostToDevice, stream));
+    APD_HIP(hipEventRecord(ev[cur], stream));
     return 0;
   }
   template <typename T>

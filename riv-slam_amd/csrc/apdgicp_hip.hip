@@ -40,7 +40,14 @@ namespace {
 
 constexpr int kSrc = 0, kTgt = 1;
 
-int ensure_pair(apdgicp_handle* h) {
+void identity16(float* g) {
+  memset(g, 0, 16 * sizeof(float));
+  g[0] = g[5] = g[10] = g[15] = 1.f;
+}
+
+// guess16: the initial guess the caller is about to align with (column-major; null: identity).  It goes into the pair
+// table so that the guess buffer is uploaded once per call, not once with a placeholder and once with the real one.
+int ensure_pair(apdgicp_handle* h, const float* guess16 = nullptr) {
   Engine& e = h->eng;
   if (e.clouds.size() < 2 || e.clouds[kSrc].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "source cloud is not set");
   if (e.clouds[kTgt].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "target cloud is not set");
@@ -48,18 +55,14 @@ int ensure_pair(apdgicp_handle* h) {
   apdgicp_pair p;
   p.source_cloud = kSrc;
   p.target_cloud = kTgt;
-  memset(p.guess, 0, sizeof(p.guess));
-  p.guess[0] = p.guess[5] = p.guess[10] = p.guess[15] = 1.f;
+  if (guess16) memcpy(p.guess, guess16, sizeof(p.guess));
+  else identity16(p.guess);
   APD_TRY(e.setup_pairs(&p, 1, true));
   h->pair_ready = true;
   h->have_corr = false;
   return 0;
 }
 
-void identity16(float* g) {
-  memset(g, 0, 16 * sizeof(float));
-  g[0] = g[5] = g[10] = g[15] = 1.f;
-}
 
 void rigid_to_colmajor(const Rigid& r, double* T) {
   for (int i = 0; i < 3; i++)
@@ -291,12 +294,12 @@ int apdgicp_get_mahalanobis(apdgicp_handle* h, double* out, int64_t n) {
 int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out) {
   return guarded([&]() -> int {
     if (!h || !out) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
-    APD_TRY(ensure_pair(h));
-    Engine& e = h->eng;
     float g[16];
     if (guess) memcpy(g, guess, sizeof(g));
     else identity16(g);
-    APD_TRY(e.d_guess.upload(g, sizeof(g), e.stream));
+    APD_TRY(ensure_pair(h, g));
+    Engine& e = h->eng;
+    APD_TRY(e.d_guess.upload(g, sizeof(g), e.stream));  // no-op when ensure_pair has just uploaded it
     APD_TRY(e.run_align());
     if (const ResultRec* r = e.host_results()) {  // came home with the last poll
       memcpy(out, r, sizeof(apdgicp_result));
