@@ -393,6 +393,30 @@ def test_batch_matches_single(reg, golden, scene):
     assert res2["n_linearize"].min() >= 1
 
 
+def test_large_batch_300_pairs(reg, scene):
+    """More pairs than ride home with the status poll (256): the records come from the device buffer instead; the three
+    pair groups, their separate covariance launches and a cloud shared by every pair are all in play."""
+    n_pairs = 300
+    tgt_shared = scene.make_pair(700, 900, scene.pair_seed(9, 0), "odometry")[1]
+    clouds, pairs, guesses = [tgt_shared], [], []
+    for i in range(n_pairs):
+        s, t, _, gs = scene.make_pair(600 + (i % 7) * 31, 640, scene.pair_seed(9, 1 + i % 12), "odometry")
+        clouds += [s, t]
+        pairs.append((1 + 2 * i, 2 + 2 * i) if i % 10 else (1 + 2 * i, 0))
+        guesses.append(gs)
+    kw = dict(optimizer=1, max_iterations=4, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0)
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    for c in clouds:
+        b.add_cloud(c)
+    res = b.align(pairs, guesses)
+    assert len(res) == n_pairs and int(res["n_linearize"].min()) == 4
+    for i in (0, 1, 10, 137, 299):
+        g = reg.FastAPDGICP(reg.default_params(**kw))
+        g.setInputSource(clouds[pairs[i][0]])
+        g.setInputTarget(clouds[pairs[i][1]])
+        assert np.array_equal(reg.result_matrix(res[i]), g.align(guesses[i])), i
+
+
 def test_batch_is_deterministic(reg, scene):
     s, t, _, gs = scene.make_pair(2048, 2048, scene.pair_seed(4, 77), "odometry")
     b = reg.BatchAPDGICP(reg.default_params(**LAUNCH))
