@@ -143,7 +143,8 @@ class Engine {
   std::vector<float> h_guesses;
   DevBuf d_state, d_results, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
-  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3];
+  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_active;
+  std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
   bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
   DevBuf b_nnpart, b_corr, b_nnpt, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
@@ -231,7 +232,7 @@ class Engine {
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
-    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2]}) t->dev.release();
+    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_active}) t->dev.release();
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
@@ -634,6 +635,7 @@ class Engine {
     work.nstride = (nmax_src + 255) & ~255;
     work.nblk_max = (nmax_src + LIN_BLK - 1) / LIN_BLK;
     work.cap = std::numeric_limits<float>::infinity();
+    work.active = nullptr;
     const size_t ns = work.nstride;
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
@@ -788,13 +790,15 @@ class Engine {
     };
     long long ticks = 0;
     bool all_done = params.max_iterations <= 0;
+    work.active = nullptr;
+    int n_active = npairs;
     const bool dbg_t = env_int("APDGICP_DEBUG_TIMING", 0) != 0;
     const auto t_begin = std::chrono::steady_clock::now();
     while (!all_done && ticks < tick_cap) {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk_at(ticks), tick_cap - ticks);
       // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
-      const int ng = group_count();
+      const int ng = ticks == 0 ? group_count() : std::max(1, std::min<int>((int)gstreams.size() + 1, n_active / 2));
       if (ng > 1) {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
@@ -808,7 +812,7 @@ class Engine {
       }
       for (int t = 0; t < todo; t++, cur_tick++)
         for (int g = 0; g < ng; g++) {
-          const int p0 = (int)((long long)npairs * g / ng), p1 = (int)((long long)npairs * (g + 1) / ng);
+          const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
           APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
         }
       for (int g = 1; g < ng; g++) {
@@ -835,14 +839,23 @@ class Engine {
       if (dbg_t)
         fprintf(stderr, "[apdgicp] %d ticks: enqueue %.3f ms, wait %.3f ms\n", todo, std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
-      all_done = true;
-      for (int p = 0; p < npairs; p++) all_done &= (h_status[p] == ST_DONE);
+      h_active.clear();
+      for (int p = 0; p < npairs; p++)
+        if (h_status[p] != ST_DONE) h_active.push_back(p);
+      all_done = h_active.empty();
+      if (!all_done && (int)h_active.size() < n_active) {  // from now on launch over the pairs that still run
+        APD_TRY(d_active.upload(h_active.data(), h_active.size() * sizeof(int), stream));
+        work.active = d_active.as<int>();
+        n_active = (int)h_active.size();
+      }
       if (h_status[npairs]) {
         const int flag = h_status[npairs];
         APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+        work.active = nullptr;
         if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, "device error flag " + std::to_string(flag) + " (covariance k-NN)");
       }
     }
+    work.active = nullptr;
     last_ticks = (int)ticks;
     if (ticks == 0) {  // max_iterations <= 0: no tick, no poll -- the records of the initial state
       APD_TRY(check_errflag("k_knn_cov"));

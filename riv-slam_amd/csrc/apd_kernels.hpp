@@ -88,9 +88,13 @@ struct Work {
                                // >= corr_dist_threshold^2: a point without any target inside it has no correspondence whatever its
                                // true neighbour is (A:156), so the search may stop there (sqd then holds the cap, the hint index -1)
   int pair0, npairs;           // this launch covers pairs [pair0, pair0 + gridDim pairs) of npairs (one stream per pair group)
+  const int* active;           // optional: the launch covers active[pair0 ...] instead -- the pairs that are not DONE yet (LM batches whose
+                               // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
 };
+
+__device__ __forceinline__ int pair_of(const Work& w, unsigned block) { return w.active ? w.active[w.pair0 + block] : w.pair0 + (int)block; }
 
 // ----------------------------------------------------------------------------------------------
 // fp32 helpers: the exact operation order of the reference (see oracle/apdgicp_ref.cpp)
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
   // used and each coordinate pair sits in one 64-bit register pair for the v_pk op_sel splats.
   __shared__ float4 txy[NN_TILE / 2];
   __shared__ float2 tz[NN_TILE / 2];
-  const int pair = w.pair0 + blockIdx.z;
+  const int pair = pair_of(w, blockIdx.z);
   if (st[pair].status != ST_NEED_LIN) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = pd.s, tgt = pd.t;
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   __shared__ float cbl[W][6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
   __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
-  const int pair = w.pair0 + blockIdx.y;
+  const int pair = pair_of(w, blockIdx.y);
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const bool cold = st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
   const PairDesc pd = pairs[pair];
@@ -1567,7 +1571,7 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
-  const int pair = w.pair0 + blockIdx.y;
+  const int pair = pair_of(w, blockIdx.y);
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
   const Rigid T = st[pair].x0;
@@ -1636,7 +1640,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
 // Mahalanobis matrices of the last linearize.
 __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst, int fuse) {
   __shared__ double red[LIN_BLK / 64];
-  const int pair = w.pair0 + blockIdx.y;
+  const int pair = pair_of(w, blockIdx.y);
   if (st[pair].status != ST_NEED_ERR) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = pd.s, tgt = pd.t;
@@ -1839,7 +1843,7 @@ __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const 
   __shared__ double lds[32];
   __shared__ PairState ls;
   __shared__ double stage[kGatherRows * kRed];
-  const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
+  const int pair = pair_of(w, blockIdx.x), tid = threadIdx.x;
   // every start-up load is issued before the first wait: status, N, the state and the first rows of partials
   const int status = st[pair].status;
   const int N = pairs[pair].s.n;
@@ -1855,7 +1859,7 @@ __global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const 
 
 __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
   __shared__ PairState ls;
-  const int pair = w.pair0 + blockIdx.x, tid = threadIdx.x;
+  const int pair = pair_of(w, blockIdx.x), tid = threadIdx.x;
   if (st[pair].status != ST_NEED_ERR) return;
   const int N = pairs[pair].s.n;
   state_copy((double*)&ls, (const double*)&st[pair], tid);
@@ -1977,7 +1981,7 @@ __global__ void k_transform_points(const float4* pts /* original order */, int n
 // out[2*pair] += d2 (double), out[2*pair+1] += 1
 __global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out) {
   __shared__ double red[(LIN_BLK / 64) * 2];
-  const int pair = w.pair0 + blockIdx.y;
+  const int pair = pair_of(w, blockIdx.y);
   const int N = pairs[pair].s.n, tid = threadIdx.x;
   if ((int)(blockIdx.x * LIN_BLK) >= N) return;
   const int i = blockIdx.x * LIN_BLK + tid;
