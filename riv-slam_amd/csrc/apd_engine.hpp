@@ -526,13 +526,13 @@ class Engine {
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
       static const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
       if (coop && qpw == 16)
-        hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+        hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else if (coop && qpw == 4)
-        hipLaunchKernelGGL(k_knn_cov_coop<16>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+        hipLaunchKernelGGL(k_knn_cov_coop<16>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else if (coop && qpw == 8)
-        hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+        hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
       else
         hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,

@@ -879,6 +879,7 @@ constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 
 // qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
 // smaller lists (more waves per CU); lanes >= qpw only help in the lane = candidate phase.
 __host__ __device__ constexpr int knn_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4; }
+__host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16; }  // k_knn_cov_coop keeps the group boxes in registers
 
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                        unsigned long long* stats, int qpw) {
@@ -1122,7 +1123,6 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
   float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
   float4* wtile = (float4*)(lst + QPW * KQ_STRIDE);              // sorted neighbourhood
-  float* gbl = (float*)(wtile + KQ_WIN);                         // 64 group boxes
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
   const int base = blockIdx.x * QPW;
@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     if (j < n) t = c.pts[j];
     wtile[e] = t;
   }
-  for (int e = lane; e < 6 * min(64, ngroups); e += 64) gbl[e] = ((const float*)c.gbox)[e];  // boxes of the first 64 groups
+  const Box nobox{inf, inf, inf, inf, inf, inf};
+  Box mybox = lane < ngroups ? c.gbox[lane] : nobox;  // lane g keeps the box of group gb0 + g in registers: no LDS copy
   int cnt = 0;  // entries in this query's list (same value in its L lanes)
   int idx_bits = 1;
   while ((1 << idx_bits) < n) idx_bits++;
@@ -1197,27 +1198,19 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   // ---- B
   for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {
     const int nb = min(64, ngroups - gb0);
-    if (gb0 > 0) {
-      __syncthreads();
-      for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
-      __syncthreads();
-    }
-    unsigned long long gneed = 0;
-    {
-      const float td = __uint_as_float(tau_hi);
+    if (gb0 > 0) mybox = gb0 + lane < ngroups ? c.gbox[gb0 + lane] : nobox;
+    // group masks, one query per trip: lane g tests ITS box against the query broadcast through SGPRs, the ballot IS the
+    // query's mask (a finished or padding query has tau = -1 and gets none); gany = groups some query of this wave needs
+    unsigned long long gneed = 0, gany = 0;
 #pragma unroll
-      for (int t = 0; t < 64 / L; t++) {
-        const int g = sub + L * t;
-        if (g < nb && lb_point_box(lds_box(gbl, g), q.x, q.y, q.z) <= td) gneed |= 1ull << g;
-      }
-      gneed = group_or_u64<L>(gneed);
-      if (!valid) gneed = 0;
+    for (int qi = 0; qi < QPW; qi++) {
+      const float qx = readlane_f(q.x, qi * L), qy = readlane_f(q.y, qi * L), qz = readlane_f(q.z, qi * L);
+      const float td = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tau_hi, qi * L));
+      const unsigned long long mq = __ballot(lane < nb && lb_point_box(mybox, qx, qy, qz) <= td);
+      gany |= mq;
+      if (slot == qi) gneed = mq;
     }
     if (stats) { const long long t = clock64(); tG += t - tm, tm = t; }
-    // groups some query of this wave needs (uniform), walked with the next group's loads in flight
-    unsigned long long gany = 0;
-    for (int g = 0; g < nb; g++)
-      if (__ballot(((gneed >> g) & 1ull) != 0)) gany |= 1ull << g;
     float4 c0, c1, d0, d1;
     unsigned o0, o1, p0, p1;
     auto fetch = [&](int g, float4& a0, float4& a1, unsigned& b0, unsigned& b1) {
