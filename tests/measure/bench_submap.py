@@ -1,5 +1,5 @@
 """Times scan-to-submap target assembly (f3): K keyframe clouds of N points -> transform, concatenate, VoxelGrid.
-usage: python tools/bench_submap.py [K] [N] [leaf];  prints device ms (inputs resident in HBM) and the CPU oracle's ms"""
+usage: python tests/measure/bench_submap.py [K] [N] [leaf];  prints device ms (inputs resident in HBM) and the CPU oracle's ms"""
 import importlib, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
 import numpy as np, torch

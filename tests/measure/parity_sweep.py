@@ -2,9 +2,9 @@
 """Parity sweep: the HIP path (C ABI) against the CPU oracle on many seeded pairs the golden file does not hold.
 For every pair: final pose error (bar 1e-3 m / 1e-4 rad), convergence flag, iteration counts, and -- at the first pose --
 correspondences (exact), fp32 squared distances (bit-exact) and H / b / cost (5e-6 relative).
-usage: python tools/parity_sweep.py [n_pairs_per_config]   -> one JSON object (commit it under profiles/)"""
+usage: python tests/measure/parity_sweep.py [n_pairs_per_config]   -> one JSON object (commit it under profiles/)"""
 import importlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch  # noqa
 reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
