@@ -687,6 +687,11 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       rad = wave_minmax_uniform<true>(rad);
       unsigned long long pre = nb < 64 ? (1ull << nb) - 1ull : ~0ull;
       if (rad < inf) pre &= __ballot(lb_box_box(wbox, lds_box(boxes, min(lane, nb - 1))) <= rad);
+      // This wave scans the groups with index = wid (mod W), so those are the only ones it has to test.  The split must not
+      // depend on the candidate set: after the first 64 groups the waves hold different partial minima, hence different
+      // candidate sets (a group missing from one wave's set cannot beat that wave's minimum, so it cannot beat the merged
+      // minimum either).
+      if (W > 1) pre &= (W == 2 ? 0x5555555555555555ull : 0x1111111111111111ull) << wid;
       unsigned long long cand = 0;
       while (pre) {
         int gq[4];
@@ -702,10 +707,6 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         }
       }
       if (seed >= 0) cand &= ~(1ull << seed);
-      // This wave scans the groups with index = wid (mod W).  The split must not depend on the candidate set: after the
-      // first 64 groups the waves hold different partial minima, hence different candidate sets (a group missing from
-      // one wave's set cannot beat that wave's minimum, so it cannot beat the merged minimum either).
-      if (W > 1) cand &= (W == 2 ? 0x5555555555555555ull : 0x1111111111111111ull) << wid;
       if (tstat) { const long long t = clock64(); tcy[1] += t - tm, tm = t; }
       // software pipeline: group k+1 travels L2 -> registers while group k is scanned out of LDS
       int cur = cand ? __builtin_ctzll(cand) : -1;
