@@ -4,6 +4,7 @@
 // is unavailable every entry point fails with APDGICP_ERR_HIP.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -682,7 +683,6 @@ class Engine {
       }
       e0 = nn_events[nn_events_used].first, e1 = nn_events[nn_events_used].second;
       nn_events_used++;
-      APD_HIP(hipEventRecord(e0, sp.st));
     }
     const CloudDesc* cd = d_desc.as<CloudDesc>();
     const PairDesc* pd = d_pairs.as<PairDesc>();
@@ -690,16 +690,19 @@ class Engine {
     Work w = work;
     w.pair0 = sp.p0;
     w.cap = nn_cap;
+    // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
+    // a profiler reports them, not the stream's idle gaps around it
+#define APD_NN_LAUNCH(KERNEL, BLOCK) hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w)
     if (nn_pruned) {
-      if (nn_S == 1 && nn_W == 4) hipLaunchKernelGGL((k_nn_pruned<1, 4>), grid, dim3(256), 0, sp.st, cd, pd, st, w);
-      else if (nn_S == 1 && nn_W == 2) hipLaunchKernelGGL((k_nn_pruned<1, 2>), grid, dim3(128), 0, sp.st, cd, pd, st, w);
-      else if (nn_S == 1) hipLaunchKernelGGL((k_nn_pruned<1, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
-      else if (nn_S == 2) hipLaunchKernelGGL((k_nn_pruned<2, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
-      else hipLaunchKernelGGL((k_nn_pruned<4, 1>), grid, dim3(64), 0, sp.st, cd, pd, st, w);
-    } else if (nn_S == 2) hipLaunchKernelGGL(k_nn_partial<2>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
-    else if (nn_S == 4) hipLaunchKernelGGL(k_nn_partial<4>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
-    else hipLaunchKernelGGL(k_nn_partial<8>, grid, dim3(NN_BLK), 0, sp.st, cd, pd, st, w);
-    if (timed) APD_HIP(hipEventRecord(e1, sp.st));
+      if (nn_S == 1 && nn_W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
+      else if (nn_S == 1 && nn_W == 2) APD_NN_LAUNCH((k_nn_pruned<1, 2>), 128);
+      else if (nn_S == 1) APD_NN_LAUNCH((k_nn_pruned<1, 1>), 64);
+      else if (nn_S == 2) APD_NN_LAUNCH((k_nn_pruned<2, 1>), 64);
+      else APD_NN_LAUNCH((k_nn_pruned<4, 1>), 64);
+    } else if (nn_S == 2) APD_NN_LAUNCH(k_nn_partial<2>, NN_BLK);
+    else if (nn_S == 4) APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
+    else APD_NN_LAUNCH(k_nn_partial<8>, NN_BLK);
+#undef APD_NN_LAUNCH
     return 0;
   }
 

@@ -6,12 +6,13 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 title = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
+# one row per (kernel, grid): the batch launches of the timed region and the single-pair launches of the other legs differ
 rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
-                  "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(grid_y), max(grid_z), max(workgroup_x) "
-                  "from kernels group by name order by 3 desc").fetchall()
+                  "max(vgpr_count), max(sgpr_count), max(lds_size), grid_x, grid_y, grid_z, max(workgroup_x) "
+                  "from kernels group by name, grid_x, grid_y, grid_z order by 3 desc").fetchall()
 total = sum(r[2] for r in rows)
 print(f"# {title}\n")
-print("rocprofv3 --kernel-trace --stats; durations in microseconds; grid = max grid size in work-items\n")
+print("rocprofv3 --kernel-trace --stats; durations in microseconds; one row per kernel and grid size (work-items)\n")
 print("| kernel | calls | total us | avg us | min us | max us | % | vgpr | sgpr | lds B | grid (x,y,z) | wg |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
