@@ -96,6 +96,16 @@ struct Work {
 
 __device__ __forceinline__ int pair_of(const Work& w, unsigned block) { return w.active ? w.active[w.pair0 + block] : w.pair0 + (int)block; }
 
+// XCD-aware block -> work mapping for 2-D grids (x: blocks of one pair / cloud, y: pairs / clouds).  Workgroups are
+// dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8, observed; a speed assumption only), each with its
+// own L2: the linear work index is permuted so that every XCD gets one contiguous eighth of the work, i.e. the blocks
+// that read the same target cloud share an L2 instead of pulling it into all eight.
+__device__ __forceinline__ void xcd_remap(unsigned& bx, unsigned& by) {
+  const unsigned nx = gridDim.x, U = nx * gridDim.y, lid = blockIdx.y * nx + blockIdx.x;
+  const unsigned u = (U & 7u) == 0 ? (lid & 7u) * (U >> 3) + (lid >> 3) : lid;
+  bx = u % nx, by = u / nx;
+}
+
 // ----------------------------------------------------------------------------------------------
 // fp32 helpers: the exact operation order of the reference (see oracle/apdgicp_ref.cpp)
 __device__ __forceinline__ void load_Tf(const Rigid& T, float Tf[12]) {
@@ -764,7 +774,9 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   __shared__ float cbl[W][6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
   __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
-  const int pair = pair_of(w, blockIdx.y);
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const int pair = pair_of(w, by);
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const bool cold = st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
   const PairDesc pd = pairs[pair];
@@ -772,7 +784,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int base = blockIdx.x * (64 * S);
+  const int base = (int)bx * (64 * S);
   if (base >= N) return;
   float px[S], py[S], pz[S], best[S];
   unsigned bestc[S];
@@ -1124,9 +1136,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
   float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
   float4* wtile = (float4*)(lst + QPW * KQ_STRIDE);              // sorted neighbourhood
-  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const CloudDesc c = clouds[cloud_ids[by]];
   const int n = c.n, lane = threadIdx.x;
-  const int base = blockIdx.x * QPW;
+  const int base = (int)bx * QPW;
   if (base >= n) return;
   const float inf = __builtin_inff();
   const int slot = lane / L, sub = lane % L, owner = lane - sub;
@@ -1135,7 +1149,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   const float4 q = c.pts[valid ? i : n - 1];
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
   unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
-  if ((blockIdx.x & 63) != 0) stats = nullptr;  // diagnostics sample every 64th wave (the atomics would dominate otherwise)
+  if ((bx & 63) != 0) stats = nullptr;  // diagnostics sample every 64th wave (the atomics would dominate otherwise)
 
   long long tA = 0, tG = 0, tB = 0, tC = 0, tm = stats ? clock64() : 0;
   // ---- A: bound from the sorted neighbourhood
@@ -1565,15 +1579,17 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
-  const int pair = pair_of(w, blockIdx.y);
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const int pair = pair_of(w, by);
   const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
   const Rigid T = st[pair].x0;
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
-  if ((int)(blockIdx.x * LIN_BLK) >= N) return;
-  const int i = blockIdx.x * LIN_BLK + tid;
+  if ((int)(bx * LIN_BLK) >= N) return;
+  const int i = (int)bx * LIN_BLK + tid;
 
   double acc[29];
 #pragma unroll
@@ -1608,7 +1624,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv * 29 + tid];
-    double* row = w.blkpart + ((size_t)pair * w.nblk_max + blockIdx.x) * kRed + tid;
+    double* row = w.blkpart + ((size_t)pair * w.nblk_max + bx) * kRed + tid;
     if (want_Hb == 2) st_coh(row, s);
     else *row = s;
   }
@@ -1634,13 +1650,15 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
 // Mahalanobis matrices of the last linearize.
 __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst, int fuse) {
   __shared__ double red[LIN_BLK / 64];
-  const int pair = pair_of(w, blockIdx.y);
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const int pair = pair_of(w, by);
   if (st[pair].status != ST_NEED_ERR) return;
   const PairDesc pd = pairs[pair];
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
-  if ((int)(blockIdx.x * LIN_BLK) >= N) return;
-  const int i = blockIdx.x * LIN_BLK + tid;
+  if ((int)(bx * LIN_BLK) >= N) return;
+  const int i = (int)bx * LIN_BLK + tid;
   const Rigid T = st[pair].xi;
   double acc[1] = {0.0};
   if (i < N) {
@@ -1662,7 +1680,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv];
-    double* row = w.errpart + (size_t)pair * w.nblk_max + blockIdx.x;
+    double* row = w.errpart + (size_t)pair * w.nblk_max + bx;
     if (fuse) st_coh(row, s);
     else *row = s;
   }
