@@ -38,7 +38,7 @@ class ShardedBatchAligner:
 
     def align(self, n_pairs: int):
         """Registers this rank's block and all-gathers the records.  Returns a uint8 tensor
-        [n_pairs, 96] in global pair order on every rank."""
+        [n_pairs, 96] in global pair order on every rank (valid until the next call: the buffer is reused)."""
         import torch
         parts = block_partition(n_pairs, self.world)
         b, e = parts[self.rank]
@@ -46,14 +46,20 @@ class ShardedBatchAligner:
         local = self.engine.align_block(list(range(b, e)))
         if self.world == 1 and not self.dist.is_initialized():
             return local
-        # fixed-size contribution per rank (pad the short tail block) -> one all_gather_into_tensor
-        pad = torch.zeros((per, RESULT_BYTES), dtype=torch.uint8, device=local.device)
+        # fixed-size contribution per rank -> one all_gather_into_tensor; the buffers are allocated once per batch shape
+        key = (per, self.world, str(local.device))
+        if getattr(self, "_key", None) != key:
+            self._key = key
+            self._out = torch.empty((self.world * per, RESULT_BYTES), dtype=torch.uint8, device=local.device)
+            self._pad = torch.zeros((per, RESULT_BYTES), dtype=torch.uint8, device=local.device)
+        even = all(pe - pb == per for pb, pe in parts)
+        if even and local.is_contiguous():  # every rank holds a full block: no staging copy, no trimming
+            self.dist.all_gather_into_tensor(self._out, local, group=self.group)
+            return self._out
         if e > b:
-            pad[: e - b] = local
-        out = torch.empty((self.world * per, RESULT_BYTES), dtype=torch.uint8, device=local.device)
-        self.dist.all_gather_into_tensor(out, pad, group=self.group)
-        keep = torch.cat([out[r * per: r * per + (pe - pb)] for r, (pb, pe) in enumerate(parts)], dim=0)
-        return keep
+            self._pad[: e - b] = local
+        self.dist.all_gather_into_tensor(self._out, self._pad, group=self.group)
+        return torch.cat([self._out[r * per: r * per + (pe - pb)] for r, (pb, pe) in enumerate(parts)], dim=0)
 
 
 def records_from_bytes(t) -> np.ndarray:
