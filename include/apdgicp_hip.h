@@ -204,10 +204,10 @@ int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n
 /* copies the n_pairs result records of the last align into caller memory (device pointer when
  * dst_on_device != 0, e.g. a tensor that RCCL will all-gather) and waits for the copy */
 int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int dst_on_device);
-/* Measurement hooks (bench.py's roofline leg).  With profiling enabled every launch of the dominant
- * kernel (brute-force nearest neighbour) is bracketed by HIP events on the batch's stream;
- * last_nn_time returns their summed milliseconds and the launch count for the last align;
- * last_ticks returns the number of state-machine ticks and the NN launch shape that was used. */
+/* Measurement hooks (bench.py's roofline leg).  With profiling enabled, launches of the dominant kernel (the
+ * nearest-neighbour search) carry their own start/stop events (hipExtLaunchKernelGGL: the kernel's begin and end
+ * timestamps on the stream it runs on); last_nn_time returns their summed milliseconds and the launch count for
+ * the last align; last_ticks returns the number of state-machine ticks and the launch shape that was used. */
 int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable);
 int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches);
 /* same, plus the number of pairs the timed launches covered (a launch covers one pair group; only every 5th tick is
@@ -216,7 +216,8 @@ int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* l
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
 /* pruning diagnostics, collected only when the environment has APDGICP_STATS=1 (else zeros); reading
  * resets them.  [0..3] nearest neighbour: groups scanned, chunks tested, chunks scanned, waves;
- * [4..9] covariance k-NN: groups, chunks tested, chunks scanned, waves, sweep rounds, candidates kept */
+ * [4..9] covariance k-NN: groups loaded, -, -, waves sampled, list tightenings, (query, group) steps;
+ * [10..15] sampled phase timers (s_memtime ticks) of whichever of the two kernels ran last (tools/prune_stats.py, tools/knn_time.py) */
 int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]);
 
 /* ------------------------------------------------------------------ scan-to-submap target assembly
