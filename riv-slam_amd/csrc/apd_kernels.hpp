@@ -522,7 +522,7 @@ __device__ __forceinline__ Box lds_box(const float* cbl, int ch) {
 // and scans a group only if some lane can still improve, and inside a group the 16-point chunks are
 // tested the same way before their distances are evaluated.  The group that contains most of the
 // wave's points is scanned first so that `best` is tight before the sweep.
-constexpr int GB_BATCH = 256;  // group boxes staged per LDS batch (6 KB)
+constexpr int GB_BATCH = 64;   // group boxes staged per LDS batch (1.5 KB): small on purpose, three pair groups of search blocks share the CUs
 
 // The search of k_nn_pruned for the 64*S points [base, base + 64*S) of one pair.  LDS: txy[64] float4, tz[64] float2, cbl[48], gbl[6*GB_BATCH] floats.
 // Returns the transformed points, the minimum squared distance and (chunk | kTieBit) per point.
