@@ -892,7 +892,7 @@ constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 
 // qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
 // smaller lists (more waves per CU); lanes >= qpw only help in the lane = candidate phase.
 __host__ __device__ constexpr int knn_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4; }
-__host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16; }  // k_knn_cov_coop keeps the group boxes in registers
+__host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8; }  // k_knn_cov_coop: lists only (boxes in registers, window from L1)
 
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                        unsigned long long* stats, int qpw) {
@@ -1135,7 +1135,6 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
   float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
-  float4* wtile = (float4*)(lst + QPW * KQ_STRIDE);              // sorted neighbourhood
   unsigned bx, by;
   xcd_remap(bx, by);
   const CloudDesc c = clouds[cloud_ids[by]];
@@ -1154,12 +1153,6 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   long long tA = 0, tG = 0, tB = 0, tC = 0, tm = stats ? clock64() : 0;
   // ---- A: bound from the sorted neighbourhood
   const int w0 = min(max(base - (KQ_WIN - QPW) / 2, 0), max(n - KQ_WIN, 0));
-  for (int e = lane; e < KQ_WIN; e += 64) {
-    const int j = w0 + e;
-    float4 t = make_float4(inf, inf, inf, 0.f);
-    if (j < n) t = c.pts[j];
-    wtile[e] = t;
-  }
   const Box nobox{inf, inf, inf, inf, inf, inf};
   Box mybox = lane < ngroups ? c.gbox[lane] : nobox;  // lane g keeps the box of group gb0 + g in registers: no LDS copy
   int cnt = 0;  // entries in this query's list (same value in its L lanes)
@@ -1173,8 +1166,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
 #pragma unroll
       for (int m = 0; m < NCL; m++) {
-        const float4 t = wtile[sub + L * (t0 + m)];
-        cmp[m] = fminf(cmp[m], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
+        // straight from global memory: the L lanes of a query read L consecutive points, the queries of a wave the same
+        // window, so the lines stay in L1; no LDS copy of the window (3 KB per wave more for resident waves)
+        const int j = w0 + sub + L * (t0 + m);
+        const float4 t = c.pts[min(j, n - 1)];
+        cmp[m] = fminf(cmp[m], j < n ? sqdist1(t.x, t.y, t.z, q.x, q.y, q.z) : inf);
       }
     }
 #pragma unroll
