@@ -8,7 +8,7 @@ are resident in HBM before the timed region; a step packs them, computes BOTH cl
 (nothing cached), runs 20 Gauss-Newton iterations per pair on the device and, for N > 1, all-gathers
 the 96-byte result records with RCCL.  Synthetic data, seeded (riv-slam_amd/scene.py).
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus 1 --steps 20 --warmup 10     (the defaults; a step takes 2 ms, the clocks need a few steps to settle)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.
@@ -42,8 +42,8 @@ def bench_params(reg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--points", type=int, default=N_PTS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
