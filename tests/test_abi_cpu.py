@@ -63,3 +63,27 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle/apdgicp_ref.cpp)", ""), f"{f} mentions the oracle"
+
+
+def _build_c_smoke():
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    out = os.path.join(ROOT, "tests", "c", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "abi_smoke")
+    lib_dir = os.path.join(ROOT, "riv-slam_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", lib_dir, "-lapdgicp_hip", f"-Wl,-rpath,{lib_dir}",
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_the_library_links_from_c():
+    """include/apdgicp_hip.h compiled by gcc -std=c99 -pedantic -Werror; without a GPU the C program gets a status + message"""
+    import subprocess
+    exe = _build_c_smoke()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert "abi" in out.stdout
+

@@ -600,3 +600,14 @@ def test_batch_fitness_and_candidate_verifier(reg, scene, pkg):
     _, sq = O.nn1(cands[0], tgt)
     sel = sq.astype(np.float64) <= 4.0
     assert abs(s2[0] - sq[sel].astype(np.float64).mean()) < 1e-9 * s2[0]
+
+
+def test_c99_program_registers_through_the_abi():
+    """tests/c/abi_smoke.c (plain C, gcc -std=c99) runs a registration through the single-handle ABI on the GPU"""
+    import subprocess
+    from test_abi_cpu import _build_c_smoke
+    exe = _build_c_smoke()
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "converged 1" in out.stdout
+
