@@ -1628,8 +1628,10 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     __shared__ PairState ls;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
     if (last_block_of_pair(w.ticket + pair, nblk, tid)) {
+      static_assert(sizeof(PairState) / 8 <= LIN_BLK, "one state word per thread");
+      const double word = tid < (int)(sizeof(PairState) / 8) ? ((const double*)&st[pair])[tid] : 0.0;  // in flight with the rows
       if (tid < 29) red[tid] = sum_rows_coh(w.blkpart + (size_t)pair * w.nblk_max * kRed + tid, nblk, kRed);
-      for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
+      if (tid < (int)(sizeof(PairState) / 8)) ((double*)&ls)[tid] = word;
       __syncthreads();
       if (tid == 0) {
         fill_from_sums(ls, red);
