@@ -213,10 +213,10 @@ class Engine {
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
-    // waves per search block: 0 = by load -- 4 while the batch is small enough to leave the GPU mostly empty (a single
-    // registration: 35 -> 29 us per iteration), 2 otherwise (4 loses there: every wave repeats the bounds and candidate tests)
+    // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
+    // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
     nn_W = env_int("APDGICP_NN_W", 0);
-    if (nn_W != 1 && nn_W != 2 && nn_W != 4) nn_W = 0;
+    if (nn_W != 1 && nn_W != 2 && nn_W != 4 && nn_W != 8) nn_W = 0;
     ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 3)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
@@ -695,9 +695,11 @@ class Engine {
     // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w)
-    const int W = nn_W ? nn_W : ((long long)npairs * src_blocks <= 1024 ? 4 : 2);  // npairs: the whole batch, all groups tick together
+    const long long tick_blocks = (long long)npairs * src_blocks;  // the whole batch: all groups tick together
+    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : tick_blocks <= 1024 ? 4 : 2;
     if (nn_pruned) {
-      if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
+      if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
+      else if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
       else if (nn_S == 1 && W == 2) APD_NN_LAUNCH((k_nn_pruned<1, 2>), 128);
       else if (nn_S == 1) APD_NN_LAUNCH((k_nn_pruned<1, 1>), 64);
       else if (nn_S == 2) APD_NN_LAUNCH((k_nn_pruned<2, 1>), 64);

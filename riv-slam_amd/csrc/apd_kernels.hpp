@@ -701,7 +701,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       // depend on the candidate set: after the first 64 groups the waves hold different partial minima, hence different
       // candidate sets (a group missing from one wave's set cannot beat that wave's minimum, so it cannot beat the merged
       // minimum either).
-      if (W > 1) pre &= (W == 2 ? 0x5555555555555555ull : 0x1111111111111111ull) << wid;
+      if (W > 1) pre &= (W == 2 ? 0x5555555555555555ull : W == 4 ? 0x1111111111111111ull : 0x0101010101010101ull) << wid;
       unsigned long long cand = 0;
       while (pre) {
         int gq[4];
