@@ -611,3 +611,35 @@ def test_c99_program_registers_through_the_abi():
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "converged 1" in out.stdout
 
+
+def test_measurement_hooks(reg, scene):
+    """the hooks bench.py's roofline leg relies on: sampled kernel-timestamp timing of the search launches, tick count,
+    pruning counters (APDGICP_STATS); profiling must not change the results"""
+    import os
+    clouds, pairs, guesses = [], [], []
+    for i in range(8):
+        s, t, _, gs = scene.make_pair(2048, 2048, scene.pair_seed(12, i), "odometry")
+        clouds += [s, t]
+        pairs.append((2 * i, 2 * i + 1))
+        guesses.append(gs)
+    kw = dict(optimizer=1, max_iterations=10, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0)
+    os.environ["APDGICP_STATS"] = "1"
+    try:
+        b = reg.BatchAPDGICP(reg.default_params(**kw))
+    finally:
+        os.environ.pop("APDGICP_STATS", None)
+    for c in clouds:
+        b.add_cloud(c)
+    ref = b.align(pairs, guesses)
+    b.set_profiling(True)
+    res = b.align(pairs, guesses)
+    assert np.array_equal(np.asarray(res["T"]), np.asarray(ref["T"]))
+    ms, launches, pair_iters = b.last_nn_profile()
+    ticks, s_per_lane, splits = b.last_ticks()
+    assert ticks == 10 and s_per_lane == 1 and splits == 1
+    assert launches >= 1 and 0.0 < ms / launches < 5.0          # a search launch takes tens of microseconds
+    assert 1 <= pair_iters <= 8 * 10
+    st = b.debug_stats()
+    assert st[3] > 0 and st[2] > 0 and st[2] <= st[1]           # waves, chunks scanned <= chunks tested
+    assert b.debug_stats()[3] == 0                              # reading resets
+
