@@ -643,3 +643,36 @@ def test_measurement_hooks(reg, scene):
     assert st[3] > 0 and st[2] > 0 and st[2] <= st[1]           # waves, chunks scanned <= chunks tested
     assert b.debug_stats()[3] == 0                              # reading resets
 
+
+@pytest.mark.parametrize("n", (8192, 100_000))
+def test_self_registration_properties_at_full_size(reg, scene, n):
+    """Size-independent properties at BASELINE's sizes (no oracle needed): a cloud registered against itself keeps every
+    point's own index at distance exactly 0, costs exactly 0 and returns exactly the identity; against a rigidly moved
+    copy of itself the true motion comes back and every correspondence is the point itself."""
+    cloud, _, _, _ = scene.make_pair(n, 16, scene.pair_seed(13, n), "odometry")
+    kw = dict(max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    g.setInputSource(cloud)
+    g.setInputTarget(cloud.copy())
+    cost, H, b = g.linearize(np.eye(4))
+    corr, sqd = g.correspondences()
+    uniq = np.unique(cloud, axis=0).shape[0] == n
+    assert not sqd.any() and cost == 0.0 and not b.any()
+    if uniq:
+        assert np.array_equal(corr, np.arange(n))
+    T = g.align(None)
+    assert np.array_equal(T, np.eye(4, dtype=np.float32)) and g.hasConverged() and g.result.final_cost == 0.0
+    # rigidly moved copy: target = R * cloud + t  ->  align(source = cloud) returns (R, t)
+    M = scene.make_transform(np.array([0.3, -0.1, 0.02]), np.deg2rad(1.0), np.deg2rad(0.2), np.deg2rad(-0.1))
+    moved = ((M[:3, :3] @ cloud[:, :3].astype(np.float64).T).T + M[:3, 3]).astype(np.float32)
+    h = reg.FastAPDGICP(reg.default_params(**kw))
+    h.setInputSource(cloud)
+    h.setInputTarget(moved)
+    T2 = h.align(None)
+    te, re_ = scene.pose_error(M, T2)
+    # against the TRUE motion the bar is the optimiser's own stopping tolerance (rotation_epsilon 2e-3, translation 5e-4)
+    # plus the fp32 rounding of the moved copy, not the parity bar
+    assert te <= 1e-3 and re_ <= 5e-4 and h.hasConverged(), (te, re_)
+    corr2, _ = h.correspondences()
+    assert (corr2 == np.arange(n)).mean() > 0.999
+
