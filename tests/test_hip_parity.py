@@ -676,3 +676,20 @@ def test_self_registration_properties_at_full_size(reg, scene, n):
     corr2, _ = h.correspondences()
     assert (corr2 == np.arange(n)).mean() > 0.999
 
+
+def test_covariances_are_equivariant_at_8k(reg, scene):
+    """a6 at BASELINE's size without the oracle: cov(R p + t) = R cov(p) R^T for the unregularised neighbourhood covariance
+    (the moved cloud is rounded to fp32, which can swap near-tied k-th neighbours: asserted for 99 % of the points)"""
+    cloud, _, _, _ = scene.make_pair(8192, 16, scene.pair_seed(14, 0), "odometry")
+    M = scene.make_transform(np.array([1.0, -2.0, 0.3]), np.deg2rad(25.0), np.deg2rad(3.0), np.deg2rad(-2.0))
+    R3 = M[:3, :3]
+    moved = ((R3 @ cloud[:, :3].astype(np.float64).T).T + M[:3, 3]).astype(np.float32)
+    covs = []
+    for c in (cloud, moved):
+        g = reg.FastAPDGICP(reg.default_params(regularization=0))
+        g.setInputSource(c)
+        covs.append(g.getSourceCovariances()[:, :3, :3])
+    want = np.einsum("ij,njk,lk->nil", R3, covs[0], R3)
+    err = np.abs(covs[1] - want).reshape(len(cloud), -1).max(1) / np.maximum(np.abs(want).reshape(len(cloud), -1).max(1), 1e-12)
+    assert (err < 1e-3).mean() > 0.99, float((err < 1e-3).mean())
+
