@@ -886,7 +886,7 @@ __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { retu
 //                         (distance, index) order), gather of the k points, moments in fp64 relative
 //                         to the query (exact differences), cov = S2/k - m m^T (A:323-324), 3x3 Jacobi
 //                         eigen-decomposition and the regularisation (A:326-357).
-constexpr int KQ_CAP = 48, KQ_STRIDE = 49, KQ_WIN = 192;
+constexpr int KQ_CAP = 48, KQ_STRIDE = 49, KQ_WIN = 128;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.683 / 0.674 / 0.675 / 0.695 / 0.735 ms (64 clouds)
 constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 * 4;
 
 // qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
