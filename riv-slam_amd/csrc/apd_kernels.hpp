@@ -1082,12 +1082,13 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_knn_cov_coop<L>: the same algorithm with L = 4 or 8 lanes per query (64/L queries per wave) in the
+// k_knn_cov_coop<L>: the same algorithm with L = 4, 8 or 16 lanes per query (64/L queries per wave) in the
 // lane = query phases, so those phases cost 1/L of the instructions and stop being one long serial
 // chain per lane:
-//   A  the L lanes of a query split the 32 distance classes of the staged neighbourhood (32/L class
-//      minima per lane, exchanged through LDS; every lane then runs the same 32-key sorting network)
-//      and the 64 group-box tests (64/L per lane, masks merged with DPP butterflies);
+//   A  the L lanes of a query split the 32 distance classes of the KQ_WIN sorted neighbours around the wave, read
+//      straight from L1 (32/L class minima per lane, exchanged through LDS; every lane then runs the same 32-key
+//      sorting network).  Group masks: lane g keeps the box of group g in registers and tests it against one query
+//      per trip, broadcast through SGPRs -- the ballot is that query's mask;
 //   B  unchanged (lane = candidate); the query state (tau, count) is kept identical in the L lanes;
 //   C  each lane keeps KQ_CAP/L list entries in REGISTERS; a round is a register-only local minimum
 //      plus a DPP butterfly over the L lanes -- no LDS reads inside the k rounds.  All L lanes
