@@ -210,8 +210,8 @@ int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int
  * the last align; last_ticks returns the number of state-machine ticks and the launch shape that was used. */
 int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable);
 int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches);
-/* same, plus the number of pairs the timed launches covered (a launch covers one pair group; only every 5th tick is
- * timed, with a phase rotating from align to align, because bracketing every launch costs ~5 % of a step) */
+/* same, plus the number of pairs the timed launches covered (a launch covers one pair group; only every 10th tick is
+ * timed, with a phase rotating from align to align, because timing every launch costs ~5 % of a step) */
 int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered);
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
 /* pruning diagnostics, collected only when the environment has APDGICP_STATS=1 (else zeros); reading

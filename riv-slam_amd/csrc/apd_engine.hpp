@@ -179,7 +179,7 @@ class Engine {
   long long last_nn_launches = 0, last_nn_pairs = 0, nn_pairs_acc = 0;
   // events cost ~5 % of a batched step when every launch is bracketed, so only the launches of every
   // `profile_stride`-th tick are timed, with a phase that rotates from align to align (unbiased over ticks)
-  int profile_stride = 5, profile_phase = 0, cur_tick = 0;
+  int profile_stride = 10, profile_phase = 0, cur_tick = 0;
   int last_ticks = 0;
 
   int init(const apdgicp_params* p, int dev, void* strm) {
@@ -777,7 +777,7 @@ class Engine {
     nn_events_used = 0;
     nn_pairs_acc = 0;
     cur_tick = 0;
-    profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 5));
+    profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 10));
     profile_phase = (profile_phase + 1) % profile_stride;
     // every align starts cold: k_init_state zeroes n_lin, and the search ignores the hint array until the first linearize of
     // this align has rewritten it (hints of an earlier run would still be valid bounds, but nothing observable -- timing
