@@ -459,16 +459,25 @@ class BatchAPDGICP:
         self.n_clouds = max(self.n_clouds, idx + 1)
         return idx
 
-    def set_clouds(self, first_index: int, clouds):
-        """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride"""
+    @staticmethod
+    def pack_clouds(clouds):
+        """The C-side argument block of set_clouds (pointer array, sizes, stride, memory space) built once: a caller whose
+        clouds live in persistent buffers -- like a C caller holding a pointer array -- passes it to set_clouds on every
+        call instead of paying the per-tensor Python bookkeeping again.  Keeps the tensors alive."""
         args = [_cloud_arg(c) for c in clouds]
         stride, dev = args[0][2], args[0][3]
         if any(a[2] != stride or a[3] != dev for a in args):
             raise ValueError("set_clouds needs one stride and one memory space")
-        ptrs = (C.c_void_p * len(args))(*[a[0] if isinstance(a[0], C.c_void_p) else a[0] for a in args])
+        ptrs = (C.c_void_p * len(args))(*[a[0] for a in args])
         ns = (C.c_int64 * len(args))(*[a[1] for a in args])
-        _check(self.L.apdgicp_batch_set_clouds(self.b, first_index, len(args), ptrs, ns, stride, dev))
-        self.n_clouds = max(self.n_clouds, first_index + len(args))
+        return ("packed_clouds", ptrs, ns, stride, dev, len(args), [a[4] for a in args])
+
+    def set_clouds(self, first_index: int, clouds):
+        """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride -- or pack_clouds(list)"""
+        packed = clouds if isinstance(clouds, tuple) and clouds and clouds[0] == "packed_clouds" else self.pack_clouds(clouds)
+        _, ptrs, ns, stride, dev, n, _keep = packed
+        _check(self.L.apdgicp_batch_set_clouds(self.b, first_index, n, ptrs, ns, stride, dev))
+        self.n_clouds = max(self.n_clouds, first_index + n)
 
     def compute_covariances(self):
         _check(self.L.apdgicp_batch_compute_covariances(self.b))
