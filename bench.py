@@ -93,14 +93,11 @@ def main():
     batch.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
     pairs_arr = batch.make_pairs(pair_idx, guesses)
     clouds_arg = batch.pack_clouds(d_clouds)   # the pointer array a C caller would hold; the clouds themselves are re-registered every step
-    d_res = torch.zeros((P, sharded.RESULT_BYTES), dtype=torch.uint8, device="cuda")
 
     class Engine:  # this rank's block through the C ABI
         def align_block(self, _indices):
             batch.set_clouds(0, clouds_arg)       # fresh clouds every step: packed, sorted, covariances recomputed
-            batch.align_async(pairs_arr)
-            batch.copy_results_to(d_res, P)
-            return d_res
+            return batch.align_device(pairs_arr)  # zero-copy view of the engine's result records (final: align polls to the end)
 
     aligner = sharded.ShardedBatchAligner(Engine())
 
