@@ -138,7 +138,7 @@ class Engine {
   bool desc_dirty = true;
 
   // batch state
-  int npairs = 0, nmax_src = 0;
+  int npairs = 0, nmax_src = 0, nmax_tgt = 0;
   std::vector<PairDesc> h_pairs;
   std::vector<CloudDesc> h_desc;  // host copy of the descriptor table (valid while !desc_dirty)
   std::vector<float> h_guesses;
@@ -365,18 +365,18 @@ class Engine {
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
       if (c.n <= 0 || c.sorted) continue;
-      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
-      grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || ngr * sizeof(Box) > c.gbox.cap;
+      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts, nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
+      grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || (ngr + nsup) * sizeof(Box) > c.gbox.cap;
     }
     if (grew) APD_HIP(hipStreamSynchronize(stream));  // old buffers may still be read by queued kernels
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
       if (c.n <= 0 || c.sorted) continue;
-      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
+      const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts, nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
       APD_TRY(c.pts.ensure(n * 16));
       APD_TRY(c.perm.ensure(n * 4));
       APD_TRY(c.cbox.ensure(nch * sizeof(Box)));
-      APD_TRY(c.gbox.ensure(ngr * sizeof(Box)));
+      APD_TRY(c.gbox.ensure((ngr + nsup) * sizeof(Box)));  // group boxes, then (large clouds) the super boxes
       if (c.n <= SORT_LDS_MAX_N) {
         SortJob j;
         j.pts = c.opts.as<float4>(), j.spts = c.pts.as<float4>(), j.perm = c.perm.as<int>();
@@ -433,9 +433,12 @@ class Engine {
       const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff};  // +inf x3, -inf x3 (ordered-int)
       APD_HIP(hipMemcpyAsync(d_box6.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
       APD_HIP(hipStreamSynchronize(stream));
-      hipLaunchKernelGGL(k_bbox_atomic, dim3((n + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, d_box6.as<int>());
+      hipLaunchKernelGGL(k_bbox_atomic, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, stream, c.opts.as<float4>(), n, d_box6.as<int>());
+      int idx_bits = 1;
+      while ((1 << idx_bits) < np2) idx_bits++;
+      const int mbits = std::min(21, (64 - idx_bits) / 3);
       hipLaunchKernelGGL(k_morton_keys, dim3((np2 + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, np2, d_box6.as<int>(),
-                         d_keys.as<unsigned long long>());
+                         d_keys.as<unsigned long long>(), mbits, idx_bits);
       hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>());
       for (int k = 2 * VOX_TILE; k <= np2; k <<= 1) {
         for (int j = k >> 1; j >= VOX_TILE; j >>= 1)
@@ -443,10 +446,12 @@ class Engine {
         hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>(), k);
       }
       hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), c.opts.as<float4>(), n,
-                         c.pts.as<float4>(), c.perm.as<int>());
+                         c.pts.as<float4>(), c.perm.as<int>(), idx_bits);
       const int nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
       hipLaunchKernelGGL(k_boxes, dim3((nch + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, 16, c.cbox.as<Box>(), nch);
       hipLaunchKernelGGL(k_boxes, dim3((ngr + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, kGroupPts, c.gbox.as<Box>(), ngr);
+      const int nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
+      hipLaunchKernelGGL(k_super_boxes, dim3((nsup + 63) / 64), dim3(64), 0, stream, c.gbox.as<Box>(), ngr, nsup);
       APD_HIP(hipGetLastError());
     }
     return 0;
@@ -568,7 +573,7 @@ class Engine {
     std::vector<float>& guesses = h_guesses;
     guesses.resize((size_t)n * 16);
     std::vector<int> need;
-    nmax_src = 0;
+    nmax_src = 0, nmax_tgt = 0;
     for (int64_t i = 0; i < n; i++) {
       const int s = pairs[i].source_cloud, t = pairs[i].target_cloud;
       if (s < 0 || t < 0 || s >= (int)clouds.size() || t >= (int)clouds.size() || clouds[s].n <= 0 || clouds[t].n <= 0)
@@ -577,6 +582,7 @@ class Engine {
       memcpy(&guesses[(size_t)i * 16], pairs[i].guess, 16 * sizeof(float));
       need.push_back(s), need.push_back(t);
       nmax_src = std::max(nmax_src, clouds[s].n);
+      nmax_tgt = std::max(nmax_tgt, clouds[t].n);
     }
     cov_list.clear();
     cov_group_off.clear();
@@ -696,7 +702,10 @@ class Engine {
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w)
     const long long tick_blocks = (long long)npairs * src_blocks;  // the whole batch: all groups tick together
-    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : tick_blocks <= 1024 ? 4 : 2;
+    // large (dense) targets: a wave's 64 points touch many more groups (10.8 instead of 1.7 per wave for 100k x 500k), so
+    // splitting the scans over 4 waves still pays with a few thousand blocks (r01: 0.170 -> 0.143 ms per iteration)
+    const bool big_target = nmax_tgt > SORT_LDS_MAX_N;
+    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : 2;
     if (nn_pruned) {
       if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
       else if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);

@@ -592,7 +592,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   }
   if (tstat) { const long long t = clock64(); tcy[0] += t - tm, tm = t; }
 
-  unsigned n_groups = 0, n_ctest = 0, n_cscan = 0;
+  unsigned n_groups = 0, n_ctest = 0, n_cscan = 0, n_batches = 0;
   // registers of the group in flight: loaded from L2 while the previous group is scanned out of LDS
   float4 pa = make_float4(inf, inf, inf, 0.f), pb = pa;
   float pc = inf;
@@ -655,8 +655,27 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     }
   };
 
-  for (int gb0 = 0; gb0 < ngroups; gb0 += GB_BATCH) {
+  // Large targets carry one more level (apd_sort.hpp: a box per 64 groups, behind the group boxes): lane s tests super box
+  // s against the box of this wave's points with the radius known NOW -- before any scan, so the W waves of the block, which
+  // hold the same points and hints, agree on the batches they visit (the barriers below need that); later radii are smaller.
+  static_assert(GB_BATCH == kSuperGroups, "one batch of group boxes per super box");
+  const bool use_super = M > SORT_LDS_MAX_N;
+  const int nsuper = (ngroups + GB_BATCH - 1) / GB_BATCH;
+  float rad0 = best[0];
+#pragma unroll
+  for (int s = 1; s < S; s++) rad0 = fmaxf(rad0, best[s]);
+  rad0 = wave_minmax_uniform<true>(rad0);
+  for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
+  unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
+  if (use_super && rad0 < inf) {
+    const Box sbx = tgt.gbox[ngroups + min(sb0 + lane, nsuper - 1)];
+    smask &= __ballot(lb_box_box(wbox, sbx) <= rad0);
+  }
+  while (smask) {
+    const int gb0 = (sb0 + __builtin_ctzll(smask)) * GB_BATCH;
+    smask &= smask - 1;
     const int nbb = min(GB_BATCH, ngroups - gb0);
+    n_batches++;
     __syncthreads();  // uniform over the block's waves (the batch loop is): nobody still reads the previous batch
     if (gb0 == 0) {
 #pragma unroll
@@ -736,6 +755,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       }
     }
   }
+  }
   if (W > 1) {  // merge the waves' partial minima: smallest distance; the same minimum in two different chunks is a tie
 #pragma unroll
     for (int s = 0; s < S; s++) mrg[(wid * S + s) * 64 + lane] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
@@ -762,7 +782,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
   if (w.stats && tid == 0) {
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
-    atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull);
+    atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull), atomicAdd(w.stats + 5, (unsigned long long)n_batches);
     if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);
   }
 }
@@ -1208,7 +1228,25 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
 
   if (stats) { const long long t = clock64(); tA += t - tm, tm = t; }
   // ---- B
-  for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {
+  // large clouds: super boxes first (apd_sort.hpp), with the bounds of phase A -- tau only decreases afterwards
+  const bool use_super = n > SORT_LDS_MAX_N;
+  const int nsuper = (ngroups + kSuperGroups - 1) / kSuperGroups;
+  for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
+  unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
+  if (use_super) {
+    const Box sbx = sb0 + lane < nsuper ? c.gbox[ngroups + sb0 + lane] : nobox;
+    unsigned long long sany = 0;
+#pragma unroll
+    for (int qi = 0; qi < QPW; qi++) {
+      const float qx = readlane_f(q.x, qi * L), qy = readlane_f(q.y, qi * L), qz = readlane_f(q.z, qi * L);
+      const float td = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tau_hi, qi * L));
+      sany |= __ballot(lb_point_box(sbx, qx, qy, qz) <= td);
+    }
+    smask &= sany;
+  }
+  while (smask) {
+    const int gb0 = (sb0 + __builtin_ctzll(smask)) * kSuperGroups;
+    smask &= smask - 1;
     const int nb = min(64, ngroups - gb0);
     if (gb0 > 0) mybox = gb0 + lane < ngroups ? c.gbox[gb0 + lane] : nobox;
     // group masks, one query per trip: lane g tests ITS box against the query broadcast through SGPRs, the ballot IS the
@@ -1284,6 +1322,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
         }
       }
     }
+  }
   }
   __syncthreads();
   if (stats) { const long long t = clock64(); tB += t - tm, tm = t; }

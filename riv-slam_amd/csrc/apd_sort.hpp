@@ -298,9 +298,10 @@ __global__ void k_bbox_atomic(const float4* pts, int n, int* box6 /* ordered-int
   const int i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
   const float inf = __builtin_inff();
   float v[6] = {inf, inf, inf, -inf, -inf, -inf};
-  if (i < n) {
-    const float4 p = pts[i];
-    v[0] = v[3] = p.x, v[1] = v[4] = p.y, v[2] = v[5] = p.z;
+  for (int e = i; e < n; e += gridDim.x * blockDim.x) {  // few blocks, many points each: the six atomics per block are serialised
+    const float4 p = pts[e];
+    v[0] = fminf(v[0], p.x), v[1] = fminf(v[1], p.y), v[2] = fminf(v[2], p.z);
+    v[3] = fmaxf(v[3], p.x), v[4] = fmaxf(v[4], p.y), v[5] = fmaxf(v[5], p.z);
   }
   for (int q = 0; q < 6; q++) {
     const float r = block_reduce_minmax(v[q], q >= 3, red, tid, 256);
@@ -315,7 +316,18 @@ __global__ void k_bbox_atomic(const float4* pts, int n, int* box6 /* ordered-int
 }
 __device__ __forceinline__ float ordered_int_to_float(int b) { return __int_as_float(b >= 0 ? b : b ^ 0x7fffffff); }
 
-__global__ void k_morton_keys(const float4* pts, int n, int np2, const int* box6, unsigned long long* keys) {
+// Large clouds are dense: with 10 bits per axis many points share a Morton cell and the 128-point groups stop being
+// compact.  The key is [Morton code, `bits` per axis][index, idx_bits], bits = min(21, (64 - idx_bits) / 3).
+__device__ __forceinline__ unsigned long long expand21(unsigned long long x) {
+  x &= 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__global__ void k_morton_keys(const float4* pts, int n, int np2, const int* box6, unsigned long long* keys, int bits, int idx_bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np2) return;
   if (i >= n) {
@@ -325,8 +337,13 @@ __global__ void k_morton_keys(const float4* pts, int n, int np2, const int* box6
   const float lx = ordered_int_to_float(box6[0]), ly = ordered_int_to_float(box6[1]), lz = ordered_int_to_float(box6[2]);
   const float hx = ordered_int_to_float(box6[3]), hy = ordered_int_to_float(box6[4]), hz = ordered_int_to_float(box6[5]);
   const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  const float top = (float)((1u << bits) - 1u), scale = top / ext;
   const float4 p = pts[i];
-  keys[i] = ((unsigned long long)morton30(p.x, p.y, p.z, lx, ly, lz, 1023.f / ext) << 32) | (unsigned)i;
+  const unsigned long long cx = (unsigned long long)fminf(fmaxf((p.x - lx) * scale, 0.f), top);
+  const unsigned long long cy = (unsigned long long)fminf(fmaxf((p.y - ly) * scale, 0.f), top);
+  const unsigned long long cz = (unsigned long long)fminf(fmaxf((p.z - lz) * scale, 0.f), top);
+  const unsigned long long m = (expand21(cx) << 2) | (expand21(cy) << 1) | expand21(cz);
+  keys[i] = (m << idx_bits) | (unsigned long long)(unsigned)i;
 }
 
 __global__ void k_bitonic_global(unsigned long long* keys, int np2, int k, int j) {
@@ -372,10 +389,10 @@ __global__ __launch_bounds__(1024) void k_bitonic_tile_merge(unsigned long long*
   for (int q = tid; q < VOX_TILE; q += 1024) keys[base + q] = t[q];
 }
 
-__global__ void k_gather_sorted(const unsigned long long* keys, const float4* pts, int n, float4* spts, int* perm) {
+__global__ void k_gather_sorted(const unsigned long long* keys, const float4* pts, int n, float4* spts, int* perm, int idx_bits) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const int o = (int)(unsigned)keys[s];
+  const int o = (int)(keys[s] & ((1ull << idx_bits) - 1ull));
   perm[s] = o;
   spts[s] = pts[o];
 }
@@ -394,6 +411,23 @@ __global__ void k_boxes(const float4* spts, int n, int pts_per_box, Box* out, in
     }
   }
   out[c] = b;
+}
+
+// Third level for large clouds (n > SORT_LDS_MAX_N): one box per kSuperGroups consecutive group boxes (8192 sorted points),
+// stored behind the group boxes in the same buffer (gbox[ngroups + s]).  The searches test these first, so a wave looks
+// at 64 group boxes only where its neighbourhood can be.
+constexpr int kSuperGroups = 64;
+__global__ void k_super_boxes(Box* gbox, int ngroups, int nsuper) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsuper) return;
+  const float inf = __builtin_inff();
+  Box b{inf, inf, inf, -inf, -inf, -inf};
+  for (int g = s * kSuperGroups; g < min((s + 1) * kSuperGroups, ngroups); g++) {
+    const Box a = gbox[g];
+    b.lx = fminf(b.lx, a.lx), b.ly = fminf(b.ly, a.ly), b.lz = fminf(b.lz, a.lz);
+    b.hx = fmaxf(b.hx, a.hx), b.hy = fmaxf(b.hy, a.hy), b.hz = fmaxf(b.hz, a.hz);
+  }
+  gbox[ngroups + s] = b;
 }
 
 // un-permute helpers for the getters: out[perm[s]] = in[s]

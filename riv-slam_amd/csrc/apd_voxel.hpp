@@ -57,9 +57,12 @@ __global__ void k_vox_bbox(const float4* pts, int n, int* box6) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
   const float inf = __builtin_inff();
   float v[6] = {inf, inf, inf, -inf, -inf, -inf};
-  if (i < n) {
-    const float4 p = pts[i];
-    if (finite3(p)) v[0] = v[3] = p.x, v[1] = v[4] = p.y, v[2] = v[5] = p.z;
+  for (int e = i; e < n; e += gridDim.x * blockDim.x) {  // few blocks: the six atomics per block are serialised
+    const float4 p = pts[e];
+    if (finite3(p)) {
+      v[0] = fminf(v[0], p.x), v[1] = fminf(v[1], p.y), v[2] = fminf(v[2], p.z);
+      v[3] = fmaxf(v[3], p.x), v[4] = fmaxf(v[4], p.y), v[5] = fmaxf(v[5], p.z);
+    }
   }
   for (int q = 0; q < 6; q++) {
     const float r = block_reduce_minmax(v[q], q >= 3, red, tid, 256);

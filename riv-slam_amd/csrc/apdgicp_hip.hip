@@ -778,7 +778,7 @@ int apdgicp_submap_assemble(apdgicp_submap* s, int n_clouds, const void* const* 
     int* d_err = box6 + 7;
     const int init[8] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff, 0, 0};
     APD_HIP(hipMemcpyAsync(box6, init, sizeof(init), hipMemcpyHostToDevice, s->stream));  // pageable source: staged before the call returns
-    hipLaunchKernelGGL(k_vox_bbox, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->cat.as<float4>(), n, box6);
+    hipLaunchKernelGGL(k_vox_bbox, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, s->stream, s->cat.as<float4>(), n, box6);
     unsigned long long* keys = s->keys.as<unsigned long long>();
     hipLaunchKernelGGL(k_vox_keys, dim3((np2 + 255) / 256), dim3(256), 0, s->stream, s->cat.as<float4>(), n, np2, box6, il[0], il[1], il[2], keys, d_err);
     hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, s->stream, keys);
