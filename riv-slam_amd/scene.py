@@ -156,6 +156,31 @@ def make_pair(n_src: int, n_tgt: int, seed: int, kind: str = "odometry"):
     return source, target, T_true, guess.astype(np.float32)
 
 
+def make_keyframe_set(n_src: int, n_tgt: int, n_keyframes: int, seed: int):
+    """One scan against the last `n_keyframes` keyframes of the SAME street (BASELINE configs[2], the candidates of
+    scan_matching_odometry_nodelet.cpp:606-618 before they are merged into a submap): the sensor advances by an odometry
+    step per keyframe, the scan is taken one step past the newest keyframe.
+    Returns (source[N,3] f32, [target_k[M,3] f32], [T_true_k 4x4 f64 source->keyframe k], [guess_k 4x4 f32])."""
+    rng = np.random.default_rng(seed)
+    scene = Scene(rng)
+    poses, T = [], np.eye(4)
+    for _ in range(n_keyframes + 1):
+        poses.append(T.copy())
+        step = make_transform(np.array([rng.uniform(0.2, 1.0), rng.uniform(-0.1, 0.1), rng.uniform(-0.03, 0.03)]),
+                              np.deg2rad(rng.uniform(-2, 2)), *np.deg2rad(rng.uniform(-0.3, 0.3, size=2)))
+        T = T @ step
+    targets = [_observe(rng, scene, P, n_tgt) for P in poses[:-1]]
+    source = _observe(rng, scene, poses[-1], n_src)
+    truths, guesses = [], []
+    for P in poses[:-1]:
+        Tk = np.linalg.inv(P) @ poses[-1]
+        dt = rng.normal(size=3)
+        dt = 0.05 * dt / np.linalg.norm(dt)
+        truths.append(Tk)
+        guesses.append((make_transform(dt, np.deg2rad(0.5) * rng.choice([-1.0, 1.0]), 0.0, 0.0) @ Tk).astype(np.float32))
+    return source, targets, truths, guesses
+
+
 def pose_error(T_ref: np.ndarray, T_est: np.ndarray):
     """(t_err [m], r_err [rad]) of delta = T_ref^-1 * T_est; metric of
     fast_apdgicp/src/test/gicp_test.cpp:73-78."""

@@ -393,6 +393,33 @@ def test_batch_matches_single(reg, golden, scene):
     assert res2["n_linearize"].min() >= 1
 
 
+@pytest.mark.parametrize("mode", ("lm_launch", "gn6"))
+def test_one_scan_against_eight_keyframes(reg, scene, mode):
+    """BASELINE configs[2]: the newest scan registered against the last 8 keyframes of the same street in one batch; the
+    scan is one cloud shared by all 8 pairs.  Every pair against the CPU oracle; batch == single-handle results."""
+    src, tgts, _, guesses = scene.make_keyframe_set(1800, 1700, 8, 77)
+    kw = (dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0) if mode == "lm_launch" else
+          dict(optimizer=1, max_iterations=6, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0))
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    si = b.add_cloud(src)
+    ti = [b.add_cloud(t) for t in tgts]
+    res = b.align([(si, t) for t in ti], guesses)
+    assert len(res) == 8
+    for k in range(8):
+        o = R.RefAPDGICP(R.default_params(**kw))
+        o.setInputSource(src)
+        o.setInputTarget(tgts[k])
+        To = o.align(guesses[k])
+        te, re_ = scene.pose_error(To, reg.result_matrix(res[k]))
+        assert te <= T_TOL and re_ <= R_TOL, (k, te, re_)
+        assert [res[k]["converged"], res[k]["iterations"], res[k]["n_linearize"]] == [int(o.converged), o.nr_iterations, o.n_linearize], k
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    g.setInputSource(src)
+    for k in (0, 7):
+        g.setInputTarget(tgts[k])
+        assert np.array_equal(reg.result_matrix(res[k]), g.align(guesses[k])), k
+
+
 def test_large_batch_300_pairs(reg, scene):
     """More pairs than ride home with the status poll (256): the records come from the device buffer instead; the three
     pair groups, their separate covariance launches and a cloud shared by every pair are all in play."""
