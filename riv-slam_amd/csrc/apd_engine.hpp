@@ -565,7 +565,9 @@ class Engine {
   // group's stream, so that they overlap with the (latency-bound) optimiser ticks of the other groups
   std::vector<int> cov_list;        // [shared clouds | group 0 | group 1 | ...]
   std::vector<int> cov_group_off;   // offsets into cov_list: group g owns [off[g + 1], off[g + 2]); the shared part is [0, off[1])
-  int group_count() const { return std::max(1, std::min<int>((int)gstreams.size() + 1, npairs / 2)); }
+  // pair groups in flight: about 8 pairs per group up to the number of streams (r01, one scan against K keyframes, GN-20:
+  // K = 8: 0.90 / 0.92 / 0.92 ms with 1 / 2 / 3 groups, K = 12: 1.12 / 0.98 / 1.02, K = 24: 1.41 / 1.23 / 1.17)
+  int group_count() const { return std::max(1, std::min<int>((int)gstreams.size() + 1, (npairs + 4) / 8)); }
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
