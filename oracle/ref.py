@@ -42,10 +42,20 @@ def default_params(**kw) -> RefParams:
 
 
 def build(force: bool = False) -> str:
+    import fcntl
     src = os.path.join(_HERE, "apdgicp_ref.cpp")
-    if force or not os.path.exists(_LIB_PATH) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+    def stale():
+        return force or not os.path.exists(_LIB_PATH) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH))
+    if stale():
+        os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+        with open(_LIB_PATH + ".lock", "w") as lock:  # one builder at a time (bench.py: every rank of a node gets here)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

@@ -21,13 +21,28 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
+    """One process compiles at a time (several ranks of one node may call this together): an exclusive lock around the
+    freshness check, output into a temporary file that is renamed over the library only when complete."""
+    import fcntl
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *(extra or []), "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():  # (another process may have built it while this one waited)
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                tmp = f"{LIB}.{os.getpid()}.tmp"
+                cmd = [hipcc, *FLAGS, *(extra or []), "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                try:
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, LIB)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
