@@ -478,6 +478,12 @@ class Engine {
     return 0;
   }
 
+  static std::string errflag_text(int flag) {
+    static const char* const meaning[] = {"", "", "fewer than k neighbours at a finite distance (non-finite input points?)",
+                                          "covariance regularisation failed (non-finite covariance)", "k-NN candidate list overflow",
+                                          "voxel grid: leaf size too small for the cloud"};
+    return "device error flag " + std::to_string(flag) + (flag >= 2 && flag <= 5 ? std::string(": ") + meaning[flag] : std::string());
+  }
   int check_errflag(const char* what) {
     int flag = 0;
     int* h_flag = (int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65539;  // last pinned word: never part of a poll
@@ -491,7 +497,7 @@ class Engine {
     }
     if (flag) {
       APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
-      return fail(APDGICP_ERR_INTERNAL, std::string(what) + ": device error flag " + std::to_string(flag));
+      return fail(APDGICP_ERR_INTERNAL, std::string(what) + ": " + errflag_text(flag));
     }
     return 0;
   }
@@ -871,7 +877,7 @@ class Engine {
         const int flag = h_status[npairs];
         APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
         work.active = nullptr;
-        if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, "device error flag " + std::to_string(flag) + " (covariance k-NN)");
+        if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
       }
     }
     work.active = nullptr;

@@ -72,6 +72,28 @@ def test_cov_k_values(reg, golden):
         assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10, k
 
 
+def test_non_finite_points_fail_loudly(reg, scene):
+    """The preprocessing nodelet removes NaNs before registration (preprocessing_nodelet.cpp); a cloud that still carries
+    non-finite coordinates is reported as an error -- no hang, no silent garbage -- and the handle stays usable."""
+    src, tgt, _, guess = scene.make_pair(2000, 2000, 5, "odometry")
+    bad_s, bad_t = src.copy(), tgt.copy()
+    bad_s[[3, 500, 1999]] = np.nan
+    bad_t[[7, 900]] = np.inf
+    bad_t[1000, 1] = -np.inf
+    g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
+    g.setInputSource(bad_s)
+    g.setInputTarget(bad_t)
+    with pytest.raises(Exception, match="non-finite"):
+        g.align(guess)
+    g.setInputSource(src)
+    g.setInputTarget(tgt)
+    T = g.align(guess)
+    fresh = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
+    fresh.setInputSource(src)
+    fresh.setInputTarget(tgt)
+    assert np.array_equal(T, fresh.align(guess))
+
+
 def test_cov_duplicate_points(reg):
     """Many identical points: ties are resolved by index, the selection must still be exact."""
     rng = np.random.default_rng(5)
