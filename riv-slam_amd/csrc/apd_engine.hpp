@@ -670,7 +670,6 @@ class Engine {
     work.errpart = b_errpart.as<double>();
     work.stats = d_stats.as<unsigned long long>();
     APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
-    APD_HIP(hipMemsetAsync(b_ticket.p, 0, (size_t)2 * npairs * sizeof(int), stream));
     work.ticket = b_ticket.as<int>();
     work.pair0 = 0;
     work.npairs = npairs;
@@ -800,7 +799,7 @@ class Engine {
     // this align has rewritten it (hints of an earlier run would still be valid bounds, but nothing observable -- timing
     // included -- may depend on call history)
     hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
-                       params.max_iterations);
+                       params.max_iterations, b_ticket.as<int>());
     const bool lm = params.optimizer == APDGICP_OPT_LM;
     const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
     // LM: the loop length is data dependent, poll every few ticks.  GN runs max_iterations ticks unless a

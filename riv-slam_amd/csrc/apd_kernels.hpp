@@ -1952,9 +1952,11 @@ __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false
-__global__ void k_init_state(PairState* st, const float* guesses /* n x 16 column-major, or null */, int npairs, int max_iterations) {
+__global__ void k_init_state(PairState* st, const float* guesses /* n x 16 column-major, or null */, int npairs, int max_iterations,
+                             int* ticket /* [2][npairs] arrival counters of the fused optimiser step */) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
+  ticket[p] = 0, ticket[npairs + p] = 0;  // (a run that ended in an error may have left them mid-count)
   PairState& s = st[p];
   if (guesses) {
     const float* g = guesses + 16 * p;
