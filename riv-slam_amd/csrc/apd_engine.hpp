@@ -165,6 +165,7 @@ class Engine {
   int ngroups_cfg = 2;
   static constexpr int kHostResults = 256;  // batches up to this size get their records with the status poll
   char* h_poll = nullptr;    // pinned: [records][status words + error flag] of the last poll
+  char* h_poll_dev = nullptr;  // the same memory as the device addresses it
   int* h_status = nullptr;   // inside h_poll (or, for check_errflag, at its start)
   bool results_on_host = false;
   const ResultRec* host_results() const { return results_on_host ? (const ResultRec*)h_poll : nullptr; }
@@ -196,6 +197,7 @@ class Engine {
     }
     APD_HIP(hipHostMalloc((void**)&h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
     h_status = (int*)h_poll;
+    APD_HIP(hipHostGetDevicePointer((void**)&h_poll_dev, h_poll, 0));
     APD_HIP(hipHostMalloc((void**)&h_probe, 64 * sizeof(double), hipHostMallocDefault));
     APD_HIP(hipEventCreateWithFlags(&ev_poll, hipEventDisableTiming));
     APD_TRY(d_errflag.ensure(sizeof(int)));
@@ -847,16 +849,12 @@ class Engine {
       // poll = finalize: the result records and, right behind them in the same buffer, the status words and the error
       // flag; small batches bring the records home in the same copy, so align() needs no second round trip
       int* d_stat = (int*)(d_results.as<char>() + (size_t)npairs * sizeof(ResultRec));
-      hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), d_stat, npairs,
-                         d_errflag.as<int>());
+      // k_finalize writes the host's copy itself (pinned, device-visible memory): no copy kernel behind it
       results_on_host = npairs <= kHostResults;
-      if (results_on_host) {
-        APD_HIP(hipMemcpyAsync(h_poll, d_results.p, (size_t)npairs * sizeof(ResultRec) + (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-        h_status = (int*)(h_poll + (size_t)npairs * sizeof(ResultRec));
-      } else {
-        h_status = (int*)h_poll;
-        APD_HIP(hipMemcpyAsync(h_status, d_stat, (npairs + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-      }
+      h_status = results_on_host ? (int*)(h_poll + (size_t)npairs * sizeof(ResultRec)) : (int*)h_poll;
+      hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), d_stat, npairs,
+                         d_errflag.as<int>(), results_on_host ? (ResultRec*)h_poll_dev : (ResultRec*)nullptr,
+                         (int*)(h_poll_dev + ((char*)h_status - h_poll)));
       APD_HIP(hipEventRecord(ev_poll, stream));
       const auto t_enq = std::chrono::steady_clock::now();
       APD_HIP(hipEventSynchronize(ev_poll));
@@ -885,7 +883,7 @@ class Engine {
       APD_TRY(check_errflag("k_knn_cov"));
       results_on_host = false;
       hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), (int*)nullptr,
-                         npairs, (const int*)nullptr);
+                         npairs, (const int*)nullptr, (ResultRec*)nullptr, (int*)nullptr);
     }
     APD_HIP(hipGetLastError());
     if (profile_nn) {

@@ -2029,9 +2029,16 @@ __global__ __launch_bounds__(64) void k_probe_reduce(const CloudDesc* clouds, co
 }
 
 // also the poll: status_out (optional) receives every pair's status and, behind them, the device error flag
-__global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs, const int* err_flag) {
+// host_out / host_status (optional): the same records / status words + error flag written straight into pinned host memory,
+// so the poll needs no copy behind this kernel
+__global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs, const int* err_flag, ResultRec* host_out,
+                           int* host_status) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p == 0 && status_out) status_out[npairs] = err_flag ? *err_flag : 0;
+  if (p == 0) {
+    const int flag = err_flag ? *err_flag : 0;
+    if (status_out) status_out[npairs] = flag;
+    if (host_status) host_status[npairs] = flag;
+  }
   if (p >= npairs) return;
   const PairState& s = st[p];
   ResultRec r;
@@ -2046,7 +2053,9 @@ __global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out,
   r.lm_failed = s.failed;
   r.n_matched = s.n_matched;
   out[p] = r;
+  if (host_out) host_out[p] = r;
   if (status_out) status_out[p] = s.status;
+  if (host_status) host_status[p] = s.status;
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}
