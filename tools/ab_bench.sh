@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of library builds on ONE box (boxes differ by ~1.5 %): alternates riv-slam_amd/_<name>.bin copies of libapdgicp_hip.so
+# and prints ms_per_step of the default bench for each.   usage (inside gpurun): bash tools/ab_bench.sh old new [rounds]
+# build a variant here with:  hipcc <flags> -o riv-slam_amd/_<name>.bin riv-slam_amd/csrc/apdgicp_hip.hip
+a=$1; b=$2; rounds=${3:-3}
+cp riv-slam_amd/libapdgicp_hip.so riv-slam_amd/_keep.bin
+for i in $(seq $rounds); do
+  for v in $a $b; do
+    cp riv-slam_amd/_$v.bin riv-slam_amd/libapdgicp_hip.so
+    echo -n "$v "; timeout 300 python bench.py --no-cpu-baseline --no-diagnostics | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"
+  done
+done
+cp riv-slam_amd/_keep.bin riv-slam_amd/libapdgicp_hip.so; rm -f riv-slam_amd/_keep.bin
