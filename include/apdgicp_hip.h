@@ -194,6 +194,16 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
  * gather results with RCCL.  apdgicp_batch_synchronize() waits for the stream. */
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results);
 int apdgicp_batch_synchronize(apdgicp_batch* b);
+/* A stream of batches (one per keyframe, loop_detector.cpp:222-236) with two of them in flight: enqueue launches everything
+ * batch s needs -- packing and sorting of clouds set since the last call, covariances, every optimiser tick, the final
+ * poll -- and returns without waiting when the run length is known up front (Gauss-Newton; a Levenberg-Marquardt run polls
+ * as it goes and is complete on return).  The caller may then set the clouds of batch s+1 (stream-ordered behind batch s,
+ * the same cloud slots can be reused) and enqueue it before collecting batch s, so the GPU never waits for the host.
+ * collect(ticket) waits for that batch, reports its error if it had one, and hands out its records: *d_results (device,
+ * n_pairs x sizeof(apdgicp_result)) and/or host_results (may be NULL).  A ticket stays collectable until the SECOND enqueue
+ * after its own; collecting is optional (an uncollected batch is waited for when its slot is reused). */
+int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, uint64_t* ticket);
+int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_results, apdgicp_result* host_results);
 /* pcl getFitnessScore(max_range) of every pair at the given poses (T: n_pairs x 16 floats, column-major;
  * NULL = the poses found by the last align of the same pair list): mean squared nearest-neighbour distance of the
  * transformed source over the points with squared distance <= max_range, DBL_MAX when none qualifies.  One NN launch

@@ -171,6 +171,25 @@ class Engine {
   const ResultRec* host_results() const { return results_on_host ? (const ResultRec*)h_poll : nullptr; }
   double* h_probe = nullptr; // pinned, 48 doubles
   hipEvent_t ev_poll = nullptr;
+  // Two aligns in flight (apdgicp_batch_align_enqueue / _collect): everything an align leaves behind for its caller -- the
+  // record buffers on both sides, the poll event, the timed-launch events -- exists twice; swap_slots() makes the other set
+  // current.  All other state is reused in stream order.
+  struct AltSlot {
+    DevBuf d_results;
+    char* h_poll = nullptr;
+    char* h_poll_dev = nullptr;
+    int* h_status = nullptr;
+    bool results_on_host = false;
+    hipEvent_t ev_poll = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_events;
+    size_t nn_events_used = 0;
+    long long nn_pairs_acc = 0;
+    bool pending = false;
+    int pending_npairs = 0, pending_ticks = 0;
+  } alt;
+  bool pending = false;          // the current slot's final poll has been enqueued but not waited for
+  int pending_npairs = 0, pending_ticks = 0;
+  unsigned long long align_seq = 0;  // ticket of the current slot's align (the other slot holds align_seq - 1)
 
   // profiling of the dominant kernel (k_nn_partial)
   bool profile_nn = false;
@@ -242,6 +261,10 @@ class Engine {
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_poll) e = hipHostFree(h_poll);
+    if (alt.h_poll) e = hipHostFree(alt.h_poll);
+    if (alt.ev_poll) e = hipEventDestroy(alt.ev_poll);
+    alt.d_results.release();
+    for (auto& pr : alt.nn_events) e = hipEventDestroy(pr.first), e = hipEventDestroy(pr.second);
     if (h_probe) e = hipHostFree(h_probe);
     if (ev_poll) e = hipEventDestroy(ev_poll);
     if (ev_main) e = hipEventDestroy(ev_main);
@@ -775,6 +798,37 @@ class Engine {
     return 0;
   }
 
+  int ensure_alt_slot() {
+    if (alt.h_poll) return 0;
+    APD_HIP(hipHostMalloc((void**)&alt.h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
+    APD_HIP(hipHostGetDevicePointer((void**)&alt.h_poll_dev, alt.h_poll, 0));
+    alt.h_status = (int*)alt.h_poll;
+    APD_HIP(hipEventCreateWithFlags(&alt.ev_poll, hipEventDisableTiming));
+    return 0;
+  }
+  void swap_slots() {
+    std::swap(d_results, alt.d_results);
+    std::swap(h_poll, alt.h_poll), std::swap(h_poll_dev, alt.h_poll_dev), std::swap(h_status, alt.h_status);
+    std::swap(results_on_host, alt.results_on_host);
+    std::swap(ev_poll, alt.ev_poll);
+    nn_events.swap(alt.nn_events);
+    std::swap(nn_events_used, alt.nn_events_used), std::swap(nn_pairs_acc, alt.nn_pairs_acc);
+    std::swap(pending, alt.pending), std::swap(pending_npairs, alt.pending_npairs), std::swap(pending_ticks, alt.pending_ticks);
+  }
+  // waits for the deferred final poll of the CURRENT slot's align and reports its device error flag
+  int finish_align() {
+    if (!pending) return 0;
+    pending = false;
+    APD_HIP(hipEventSynchronize(ev_poll));
+    last_ticks = pending_ticks;
+    if (profile_nn) APD_TRY(collect_nn_profile());
+    if (h_status[pending_npairs]) {
+      const int flag = h_status[pending_npairs];
+      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+      if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
+    }
+    return 0;
+  }
   int collect_nn_profile() {
     last_nn_ms = 0;
     last_nn_launches = 0;
@@ -790,8 +844,11 @@ class Engine {
 
   // L:55-80 for every pair; leaves ResultRec[npairs] in d_results.  Blocks until all pairs are done
   // (the loop length is data dependent), polling the device every few ticks.
-  int run_align() {
+  // defer_poll: when the whole run is ONE chunk of ticks (Gauss-Newton), return right after enqueueing the final poll;
+  // finish_align() waits for it.  Levenberg-Marquardt runs poll as they go and are complete on return either way.
+  int run_align(bool defer_poll = false) {
     APD_HIP(hipSetDevice(device));
+    APD_TRY(finish_align());  // (an uncollected deferred align of this slot)
     nn_events_used = 0;
     nn_pairs_acc = 0;
     cur_tick = 0;
@@ -856,6 +913,12 @@ class Engine {
                          d_errflag.as<int>(), results_on_host ? (ResultRec*)h_poll_dev : (ResultRec*)nullptr,
                          (int*)(h_poll_dev + ((char*)h_status - h_poll)));
       APD_HIP(hipEventRecord(ev_poll, stream));
+      if (defer_poll && ticks == tick_cap && ticks == todo) {  // the only chunk: nothing on the host depends on its outcome
+        pending = true, pending_npairs = npairs, pending_ticks = (int)ticks;
+        work.active = nullptr;
+        APD_HIP(hipGetLastError());
+        return 0;
+      }
       const auto t_enq = std::chrono::steady_clock::now();
       APD_HIP(hipEventSynchronize(ev_poll));
       if (dbg_t)

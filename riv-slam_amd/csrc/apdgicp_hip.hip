@@ -18,6 +18,7 @@ struct apdgicp_handle {
 
 struct apdgicp_batch {
   Engine eng;
+  int64_t slot_pairs[2] = {0, 0};  // pairs of the last two enqueued batches (by ticket parity)
 };
 
 struct apdgicp_submap {
@@ -565,6 +566,46 @@ int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64
     APD_TRY(b->eng.run_align());
     if (d_results) *d_results = b->eng.d_results.p;
     return 0;
+  });
+}
+
+int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, uint64_t* ticket) {
+  return guarded([&]() -> int {
+    if (!b || !pairs || !ticket) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    Engine& e = b->eng;
+    APD_TRY(e.ensure_alt_slot());
+    e.swap_slots();  // the slot of the batch before the last one becomes current (run_align waits for it if nobody collected it)
+    e.align_seq++;
+    b->slot_pairs[e.align_seq & 1] = n_pairs;
+    APD_TRY(e.setup_pairs(pairs, n_pairs, true, /*pipeline_cov=*/true));
+    APD_TRY(e.run_align(/*defer_poll=*/true));
+    *ticket = e.align_seq;
+    return 0;
+  });
+}
+
+int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_results, apdgicp_result* host_results) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    Engine& e = b->eng;
+    const bool previous = ticket + 1 == e.align_seq;
+    if (ticket == 0 || (ticket != e.align_seq && !previous)) return fail(APDGICP_ERR_INVALID_ARG, "ticket is not one of the last two enqueued batches");
+    if (previous) e.swap_slots();
+    int rc = e.finish_align();
+    const int64_t n = b->slot_pairs[ticket & 1];
+    if (rc == 0) {
+      if (d_results) *d_results = e.d_results.p;
+      if (host_results) {
+        if (const ResultRec* r = e.host_results()) {
+          memcpy(host_results, r, n * sizeof(apdgicp_result));
+        } else {
+          const hipError_t he = hipMemcpy(host_results, e.d_results.p, n * sizeof(apdgicp_result), hipMemcpyDeviceToHost);
+          if (he != hipSuccess) rc = fail(APDGICP_ERR_HIP, hipGetErrorString(he));
+        }
+      }
+    }
+    if (previous) e.swap_slots();
+    return rc;
   });
 }
 

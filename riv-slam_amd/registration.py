@@ -89,7 +89,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
+    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
     "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
 
@@ -148,6 +148,8 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_set_clouds.argtypes = [vp, i32, i32, vp, vp, i64, i32]
     L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
     L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
+    L.apdgicp_batch_align_enqueue.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
+    L.apdgicp_batch_align_collect.argtypes = [vp, C.c_uint64, C.POINTER(vp), vp]
     L.apdgicp_batch_fitness.argtypes = [vp, vp, i64, vp, dbl, vp, vp]
     L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
     L.apdgicp_batch_set_profiling.argtypes = [vp, i32]
@@ -505,6 +507,42 @@ class BatchAPDGICP:
         dptr = C.c_void_p()
         _check(self.L.apdgicp_batch_align_async(self.b, arr, len(arr), C.byref(dptr)))
         return dptr.value, len(arr) * RESULT_DTYPE.itemsize
+
+    def align_enqueue(self, pairs, guesses=None) -> int:
+        """Launches the whole batch and returns its ticket without waiting (Gauss-Newton; an LM batch is complete on return).
+        The clouds of the NEXT batch may be set and enqueued before this one is collected (two batches in flight)."""
+        arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
+        ticket = C.c_uint64()
+        _check(self.L.apdgicp_batch_align_enqueue(self.b, arr, len(arr), C.byref(ticket)))
+        self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 1 >= ticket.value}, ticket.value: len(arr)}
+        return ticket.value
+
+    def align_collect(self, ticket: int, device: bool = False):
+        """Waits for the batch of `ticket` (one of the last two enqueued).  Returns its records as a structured numpy array, or
+        with device=True as a zero-copy torch uint8 CUDA tensor [n, 96] (valid until the second enqueue after its own)."""
+        n = getattr(self, "_ticket_pairs", {}).get(ticket)
+        if n is None:
+            raise ValueError(f"ticket {ticket} is not one of the last two enqueued batches")
+        if device:
+            dptr = C.c_void_p()
+            _check(self.L.apdgicp_batch_align_collect(self.b, ticket, C.byref(dptr), None))
+            return self._device_view(dptr.value, n * RESULT_DTYPE.itemsize)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        _check(self.L.apdgicp_batch_align_collect(self.b, ticket, None, _ptr(out)))
+        return out
+
+    def _device_view(self, ptr, nbytes):
+        import torch
+        views = self.__dict__.setdefault("_views", {})
+        if (ptr, nbytes) not in views:
+            class _View:  # __cuda_array_interface__ is honoured by torch.as_tensor on ROCm builds as well
+                pass
+            v = _View()
+            v.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+            if len(views) > 8:
+                views.clear()
+            views[(ptr, nbytes)] = torch.as_tensor(v, device="cuda").view(-1, RESULT_DTYPE.itemsize)
+        return views[(ptr, nbytes)]
 
     def align_device(self, pairs, guesses=None):
         """Runs the batch and returns the result records as a zero-copy torch uint8 CUDA tensor [n, 96] over the engine's own

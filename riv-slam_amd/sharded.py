@@ -39,11 +39,17 @@ class ShardedBatchAligner:
     def align(self, n_pairs: int):
         """Registers this rank's block and all-gathers the records.  Returns a uint8 tensor
         [n_pairs, 96] in global pair order on every rank (valid until the next call: the buffer is reused)."""
+        b, e = block_partition(n_pairs, self.world)[self.rank]
+        return self.gather(self.engine.align_block(list(range(b, e))), n_pairs)
+
+    def gather(self, local, n_pairs: int):
+        """The exchange step alone: `local` = this rank's records of a batch of n_pairs ([len(my_block), 96] uint8, on the
+        device the group communicates from).  For callers that keep two batches in flight (BatchAPDGICP.align_enqueue /
+        align_collect) and gather batch s while batch s+1 runs."""
         import torch
         parts = block_partition(n_pairs, self.world)
         b, e = parts[self.rank]
         per = parts[0][1] - parts[0][0]
-        local = self.engine.align_block(list(range(b, e)))
         if self.world == 1 and not self.dist.is_initialized():
             return local
         # fixed-size contribution per rank -> one all_gather_into_tensor; the buffers are allocated once per batch shape

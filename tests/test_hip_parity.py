@@ -442,6 +442,62 @@ def test_one_scan_against_eight_keyframes(reg, scene, mode):
         assert np.array_equal(reg.result_matrix(res[k]), g.align(guesses[k])), k
 
 
+@pytest.mark.parametrize("optimizer", ("gn", "lm"))
+def test_two_batches_in_flight(reg, scene, optimizer):
+    """apdgicp_batch_align_enqueue / _collect: batch s+1 (different clouds in the SAME slots) is set and enqueued before batch s is
+    collected; every batch must equal its synchronous align bit for bit, in host and device form, and an error of one batch
+    surfaces at its own collect."""
+    import torch
+    kw = (dict(optimizer=1, max_iterations=5, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0) if optimizer == "gn"
+          else dict(max_correspondence_distance=2.0, transformation_epsilon=0.01))
+    n_batches, n_pairs = 5, 6
+    data = []
+    for s in range(n_batches):
+        clouds, guesses = [], []
+        for p in range(n_pairs):
+            a, b_, _, g = scene.make_pair(900 + 40 * p, 1000, scene.pair_seed(21 + s, p), "odometry")
+            clouds += [a, b_]
+            guesses.append(g)
+        data.append((clouds, guesses))
+    pair_idx = [(2 * i, 2 * i + 1) for i in range(n_pairs)]
+    ref_b = reg.BatchAPDGICP(reg.default_params(**kw))
+    want = []
+    for clouds, guesses in data:
+        ref_b.set_clouds(0, clouds)
+        want.append(ref_b.align(pair_idx, guesses).copy())
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    tickets = []
+    for s, (clouds, guesses) in enumerate(data):
+        b.set_clouds(0, clouds)
+        tickets.append(b.align_enqueue(pair_idx, guesses))
+        if s >= 1:  # collect the previous batch while this one runs
+            got = b.align_collect(tickets[s - 1])
+            assert got.tobytes() == want[s - 1].tobytes(), s - 1
+            if s == 2:
+                dev = b.align_collect(tickets[s - 1], device=True)  # collecting twice is allowed; device form
+                assert dev.cpu().numpy().tobytes() == want[s - 1].tobytes()
+    assert b.align_collect(tickets[-1]).tobytes() == want[-1].tobytes()
+    with pytest.raises(Exception, match="ticket"):
+        b.align_collect(tickets[0])
+    # a batch with non-finite points fails at ITS collect; the batches around it are unaffected
+    bad = [c.copy() for c in data[0][0]]
+    bad[3][5] = np.nan
+    b.set_clouds(0, data[1][0])
+    t_ok = b.align_enqueue(pair_idx, data[1][1])
+    b.set_clouds(0, bad)
+    if optimizer == "gn":
+        t_bad = b.align_enqueue(pair_idx, data[0][1])
+        assert b.align_collect(t_ok).tobytes() == want[1].tobytes()
+        with pytest.raises(Exception, match="non-finite"):
+            b.align_collect(t_bad)
+    else:  # a Levenberg-Marquardt batch polls as it goes: complete (or failed) when enqueue returns
+        with pytest.raises(Exception, match="non-finite"):
+            b.align_enqueue(pair_idx, data[0][1])
+        assert b.align_collect(t_ok).tobytes() == want[1].tobytes()
+    b.set_clouds(0, data[2][0])
+    assert b.align(pair_idx, data[2][1]).tobytes() == want[2].tobytes()
+
+
 def test_large_batch_300_pairs(reg, scene):
     """More pairs than ride home with the status poll (256): the records come from the device buffer instead; the three
     pair groups, their separate covariance launches and a cloud shared by every pair are all in play."""
