@@ -42,10 +42,18 @@ class ShardedBatchAligner:
         b, e = block_partition(n_pairs, self.world)[self.rank]
         return self.gather(self.engine.align_block(list(range(b, e))), n_pairs)
 
-    def gather(self, local, n_pairs: int):
+    def gather(self, local, n_pairs: int, wait: bool = False):
         """The exchange step alone: `local` = this rank's records of a batch of n_pairs ([len(my_block), 96] uint8, on the
         device the group communicates from).  For callers that keep two batches in flight (BatchAPDGICP.align_enqueue /
-        align_collect) and gather batch s while batch s+1 runs."""
+        align_collect) and gather batch s while batch s+1 runs; wait=True returns only when the collective has finished
+        reading `local` (the engine reuses that buffer two batches later)."""
+        import torch
+        out = self._gather(local, n_pairs)
+        if wait and self.dist.is_initialized() and getattr(local, "is_cuda", False):
+            torch.cuda.current_stream(local.device).synchronize()
+        return out
+
+    def _gather(self, local, n_pairs: int):
         import torch
         parts = block_partition(n_pairs, self.world)
         b, e = parts[self.rank]
