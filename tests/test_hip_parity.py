@@ -485,15 +485,14 @@ def test_two_batches_in_flight(reg, scene, optimizer):
     b.set_clouds(0, data[1][0])
     t_ok = b.align_enqueue(pair_idx, data[1][1])
     b.set_clouds(0, bad)
-    if optimizer == "gn":
+    with pytest.raises(Exception, match="non-finite"):
+        # a run that polls as it goes (Levenberg-Marquardt, or Gauss-Newton in several poll chunks) fails in enqueue itself;
+        # a deferred one hands the error out with its own batch, after the batch before it has been collected intact
         t_bad = b.align_enqueue(pair_idx, data[0][1])
+        assert optimizer == "gn"
         assert b.align_collect(t_ok).tobytes() == want[1].tobytes()
-        with pytest.raises(Exception, match="non-finite"):
-            b.align_collect(t_bad)
-    else:  # a Levenberg-Marquardt batch polls as it goes: complete (or failed) when enqueue returns
-        with pytest.raises(Exception, match="non-finite"):
-            b.align_enqueue(pair_idx, data[0][1])
-        assert b.align_collect(t_ok).tobytes() == want[1].tobytes()
+        b.align_collect(t_bad)
+    assert b.align_collect(t_ok).tobytes() == want[1].tobytes()
     b.set_clouds(0, data[2][0])
     assert b.align(pair_idx, data[2][1]).tobytes() == want[2].tobytes()
 
@@ -741,12 +740,14 @@ def test_measurement_hooks(reg, scene):
     assert np.array_equal(np.asarray(res["T"]), np.asarray(ref["T"]))
     ms, launches, pair_iters = b.last_nn_profile()
     ticks, s_per_lane, splits = b.last_ticks()
-    assert ticks == 10 and s_per_lane == 1 and splits == 1
+    default_shape = not any(os.environ.get(v) for v in ("APDGICP_NN_MODE", "APDGICP_NN_S", "APDGICP_NN_T"))  # tools/knob_matrix.sh
+    assert ticks == 10 and (not default_shape or (s_per_lane == 1 and splits == 1))
     assert launches >= 1 and 0.0 < ms / launches < 5.0          # a search launch takes tens of microseconds
     assert 1 <= pair_iters <= 8 * 10
-    st = b.debug_stats()
-    assert st[3] > 0 and st[2] > 0 and st[2] <= st[1]           # waves, chunks scanned <= chunks tested
-    assert b.debug_stats()[3] == 0                              # reading resets
+    if os.environ.get("APDGICP_NN_MODE") != "brute":            # (the brute-force kernels have nothing to count)
+        st = b.debug_stats()
+        assert st[3] > 0 and st[2] > 0 and st[2] <= st[1]       # waves, chunks scanned <= chunks tested
+        assert b.debug_stats()[3] == 0                          # reading resets
 
 
 @pytest.mark.parametrize("n", (8192, 100_000))

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Runs the -m gpu suite under every A/B switch of DESIGN.md section 8 (one line per configuration).
+# usage (inside gpurun): bash tools/knob_matrix.sh
+for cfg in "" "APDGICP_NN_MODE=brute" "APDGICP_KNN_MODE=brute" "APDGICP_NN_W=1" "APDGICP_NN_W=2" "APDGICP_NN_W=4" "APDGICP_NN_W=8" \
+           "APDGICP_NN_S=2" "APDGICP_NN_S=4" "APDGICP_NN_GATE_CAP=0" "APDGICP_KNN_QPW=4" "APDGICP_KNN_QPW=8" "APDGICP_KNN_QPW=16" \
+           "APDGICP_KNN_QPW=64" "APDGICP_KNN_COOP=0" "APDGICP_SORT_REG=0" "APDGICP_FUSE=0" "APDGICP_STREAMS=1" "APDGICP_STREAMS=2" \
+           "APDGICP_POLL_TICKS=1" "APDGICP_POLL_TICKS=3" "APDGICP_STATS=1"; do
+  res=$(env $cfg timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -1)
+  echo "[$cfg] $res"
+done
