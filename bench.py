@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--points", type=int, default=N_PTS)
+    ap.add_argument("--handles", type=int, default=3, help="batch handles = steps kept in flight (1: one handle with three pair groups)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
@@ -89,12 +90,23 @@ def main():
     pair_idx = [(2 * i, 2 * i + 1) for i in range(P)]
 
     params = bench_params(reg)
-    batch = reg.BatchAPDGICP(params, device=local_rank)
-    batch.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
+    # Consecutive steps are independent batches, so several of them are kept in flight: step s runs on batch handle s % H
+    # (H = --handles, 3 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
+    # underfed (32 pairs: three groups of latency-bound tick kernels); with three steps at different phases one handle's
+    # covariance kernels fill the gaps of the others' ticks.  Every handle registers its own copy of the step's clouds.
+    H = max(1, args.handles)
+    batches = []
+    for _ in range(H):
+        bh = reg.BatchAPDGICP(params, device=local_rank)
+        bh.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
+        if H > 1:
+            bh.set_pair_groups(1)
+        batches.append(bh)
+    batch = batches[0]
     pairs_arr = batch.make_pairs(pair_idx, guesses)
     clouds_arg = batch.pack_clouds(d_clouds)   # the pointer array a C caller would hold; the clouds themselves are re-registered every step
 
-    class Engine:  # this rank's block through the C ABI (the synchronous form; the timed loop below keeps two batches in flight)
+    class Engine:  # this rank's block through the C ABI, synchronous form (ShardedBatchAligner.align); the timed loop uses gather() only
         def align_block(self, _indices):
             batch.set_clouds(0, clouds_arg)
             return batch.align_device(pairs_arr)
@@ -103,29 +115,34 @@ def main():
     nn_acc = [0.0, 0, 0]
 
     # A step = set this rank's 64 fresh clouds (packed, sorted, covariances recomputed) + register its 32 pairs + (N > 1)
-    # all-gather the records.  Two steps are in flight: step s+1 is enqueued behind step s on the engine's streams before
-    # the host waits for step s, so the GPU does not idle while the host polls, gathers and launches.
-    def enqueue_step():
-        batch.set_clouds(0, clouds_arg)
-        return batch.align_enqueue(pairs_arr)
+    # all-gather the records.  enqueue returns without waiting (Gauss-Newton: the run length is known); a step is collected
+    # -- waited for, gathered -- just before its handle is needed again, H steps later.
+    def enqueue_step(bh):
+        bh.set_clouds(0, clouds_arg)
+        return bh.align_enqueue(pairs_arr)
 
-    def collect_step(ticket):
-        local = batch.align_collect(ticket, device=True)   # zero-copy view of that step's records on the device
-        out = aligner.gather(local, total_pairs, wait=True)  # (the host has a millisecond of slack per step)
-        ms, k, pr = batch.last_nn_profile()
+    def collect_step(bh, ticket):
+        local = bh.align_collect(ticket, device=True)        # zero-copy view of that step's records on the device
+        out = aligner.gather(local, total_pairs, wait=True)  # (the host has about a millisecond of slack per step)
+        ms, k, pr = bh.last_nn_profile()
         nn_acc[0] += ms
         nn_acc[1] += k
         nn_acc[2] += pr
         return out
 
     def run_steps(count):
-        prev, out = None, None
-        for _ in range(count):
-            t = enqueue_step()
-            if prev is not None:
-                out = collect_step(prev)
-            prev = t
-        return collect_step(prev) if prev is not None else out
+        tickets, out = [None] * H, None
+        for s in range(count):
+            h = s % H
+            if tickets[h] is not None:
+                out = collect_step(batches[h], tickets[h])
+            tickets[h] = enqueue_step(batches[h])
+        for s in range(count, count + H):   # the steps still in flight, oldest first
+            h = s % H
+            if tickets[h] is not None:
+                out = collect_step(batches[h], tickets[h])
+                tickets[h] = None
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -173,7 +190,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1] (8k x 8k scan pair, 20 GN iterations) x {P} independent pairs per GPU per step "
                                    f"(= per-GPU shard of configs[3])", "points": n, "pairs_per_gpu": P, "gn_iterations": GN_ITERS,
                        "nn_mode": os.environ.get("APDGICP_NN_MODE", "pruned"), "nn_sources_per_lane": nn_S, "nn_target_splits": nn_T,
-                       "ticks": ticks, "steps_in_flight": 2},
+                       "ticks": ticks, "steps_in_flight": H, "batch_handles": H},
             "ms_per_gn_iter_batched": round(ms_per_step / GN_ITERS, 4),
             "roofline": {"kernel": "k_nn_pruned (exact fp32 nearest neighbour: Z-curve sorted clouds, bounding-box pruning, LDS-staged "
                                    "target groups)" if os.environ.get("APDGICP_NN_MODE", "pruned") != "brute" else

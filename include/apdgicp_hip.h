@@ -203,6 +203,11 @@ int apdgicp_batch_synchronize(apdgicp_batch* b);
  * n_pairs x sizeof(apdgicp_result)) and/or host_results (may be NULL).  A ticket stays collectable until the SECOND enqueue
  * after its own; collecting is optional (an uncollected batch is waited for when its slot is reused). */
 int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, uint64_t* ticket);
+/* A batch runs as up to three pair groups on three HIP streams (about 8 pairs per group), which is the best a single handle
+ * can do.  A caller that keeps several HANDLES busy at once -- batch s on handle s % 3, each enqueued before the previous
+ * ones are collected -- does better with one group (= one stream, larger launches) per handle: one handle's covariance
+ * phase then fills the latency gaps of the others' optimiser ticks (bench.py: 1.70 -> 1.30 ms per batch of 32). */
+int apdgicp_batch_set_pair_groups(apdgicp_batch* b, int max_groups);
 int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_results, apdgicp_result* host_results);
 /* pcl getFitnessScore(max_range) of every pair at the given poses (T: n_pairs x 16 floats, column-major;
  * NULL = the poses found by the last align of the same pair list): mean squared nearest-neighbour distance of the

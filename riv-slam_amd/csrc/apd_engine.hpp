@@ -598,7 +598,8 @@ class Engine {
   std::vector<int> cov_group_off;   // offsets into cov_list: group g owns [off[g + 1], off[g + 2]); the shared part is [0, off[1])
   // pair groups in flight: about 8 pairs per group up to the number of streams (r01, one scan against K keyframes, GN-20:
   // K = 8: 0.90 / 0.92 / 0.92 ms with 1 / 2 / 3 groups, K = 12: 1.12 / 0.98 / 1.02, K = 24: 1.41 / 1.23 / 1.17)
-  int group_count() const { return std::max(1, std::min<int>((int)gstreams.size() + 1, (npairs + 4) / 8)); }
+  int max_groups = 1 << 30;  // apdgicp_batch_set_pair_groups: a caller that keeps several batches (handles) in flight wants one group each
+  int group_count() const { return std::max(1, std::min<int>(std::min<int>((int)gstreams.size() + 1, max_groups), (npairs + 4) / 8)); }
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
@@ -881,7 +882,7 @@ class Engine {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk_at(ticks), tick_cap - ticks);
       // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
-      const int ng = ticks == 0 ? group_count() : std::max(1, std::min<int>((int)gstreams.size() + 1, n_active / 2));
+      const int ng = ticks == 0 ? group_count() : std::max(1, std::min<int>(std::min<int>((int)gstreams.size() + 1, max_groups), n_active / 2));
       if (ng > 1) {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));

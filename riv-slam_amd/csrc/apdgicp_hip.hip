@@ -673,6 +673,12 @@ int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int
   return 0;
 }
 
+int apdgicp_batch_set_pair_groups(apdgicp_batch* b, int max_groups) {
+  if (!b || max_groups < 1) return fail(APDGICP_ERR_INVALID_ARG, "batch is null or max_groups < 1");
+  b->eng.max_groups = max_groups;
+  return 0;
+}
+
 int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   b->eng.profile_nn = enable != 0;

@@ -89,7 +89,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
+    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
     "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
 
@@ -149,6 +149,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_align.argtypes = [vp, vp, i64, vp]
     L.apdgicp_batch_align_async.argtypes = [vp, vp, i64, C.POINTER(vp)]
     L.apdgicp_batch_align_enqueue.argtypes = [vp, vp, i64, C.POINTER(C.c_uint64)]
+    L.apdgicp_batch_set_pair_groups.argtypes = [vp, C.c_int]
     L.apdgicp_batch_align_collect.argtypes = [vp, C.c_uint64, C.POINTER(vp), vp]
     L.apdgicp_batch_fitness.argtypes = [vp, vp, i64, vp, dbl, vp, vp]
     L.apdgicp_batch_copy_results.argtypes = [vp, vp, i64, i32]
@@ -507,6 +508,10 @@ class BatchAPDGICP:
         dptr = C.c_void_p()
         _check(self.L.apdgicp_batch_align_async(self.b, arr, len(arr), C.byref(dptr)))
         return dptr.value, len(arr) * RESULT_DTYPE.itemsize
+
+    def set_pair_groups(self, max_groups: int):
+        """At most this many pair groups (HIP streams) per batch; 1 for a handle that shares the GPU with other busy handles."""
+        _check(self.L.apdgicp_batch_set_pair_groups(self.b, int(max_groups)))
 
     def align_enqueue(self, pairs, guesses=None) -> int:
         """Launches the whole batch and returns its ticket without waiting (Gauss-Newton; an LM batch is complete on return).

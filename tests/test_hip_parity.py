@@ -497,6 +497,45 @@ def test_two_batches_in_flight(reg, scene, optimizer):
     assert b.align(pair_idx, data[2][1]).tobytes() == want[2].tobytes()
 
 
+def test_three_handles_keep_three_batches_in_flight(reg, scene):
+    """bench.py's schedule: batch s on handle s % 3, one pair group per handle (apdgicp_batch_set_pair_groups), enqueued before
+    the earlier ones are collected.  Every batch equals the synchronous align of a default handle bit for bit."""
+    kw = dict(optimizer=1, max_iterations=6, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0)
+    n_batches, n_pairs = 7, 24   # 24 pairs: a default handle splits them into three groups, these handles do not
+    data = []
+    for s in range(n_batches):
+        clouds, guesses = [], []
+        for p in range(n_pairs):
+            a, b_, _, g = scene.make_pair(700 + 16 * (p % 5), 800, scene.pair_seed(31 + s % 3, p), "odometry")
+            clouds += [a, b_]
+            guesses.append(g)
+        data.append((clouds, guesses))
+    pair_idx = [(2 * i, 2 * i + 1) for i in range(n_pairs)]
+    ref_b = reg.BatchAPDGICP(reg.default_params(**kw))
+    want = []
+    for clouds, guesses in data:
+        ref_b.set_clouds(0, clouds)
+        want.append(ref_b.align(pair_idx, guesses).copy())
+    handles = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(3)]
+    for h in handles:
+        h.set_pair_groups(1)
+    with pytest.raises(Exception):
+        handles[0].set_pair_groups(0)
+    tickets, got = [None] * 3, {}
+    for s, (clouds, guesses) in enumerate(data):
+        h = s % 3
+        if tickets[h] is not None:
+            got[tickets[h][0]] = handles[h].align_collect(tickets[h][1])
+        handles[h].set_clouds(0, clouds)
+        tickets[h] = (s, handles[h].align_enqueue(pair_idx, guesses))
+    for h in range(3):
+        if tickets[h] is not None:
+            got[tickets[h][0]] = handles[h].align_collect(tickets[h][1])
+    assert sorted(got) == list(range(n_batches))
+    for s in range(n_batches):
+        assert got[s].tobytes() == want[s].tobytes(), s
+
+
 def test_large_batch_300_pairs(reg, scene):
     """More pairs than ride home with the status poll (256): the records come from the device buffer instead; the three
     pair groups, their separate covariance launches and a cloud shared by every pair are all in play."""
