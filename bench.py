@@ -46,13 +46,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--points", type=int, default=N_PTS)
-    ap.add_argument("--handles", type=int, default=3, help="batch handles = steps kept in flight (1: one handle with three pair groups)")
+    ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 3, or 4 with a process group; 1: one "
+                                                            "handle with three pair groups)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank (self-test of the N>1 path)")
     args = ap.parse_args()
 
+    # Three or four batch handles (one stream each) plus RCCL's stream are busy at once; the HIP runtime multiplexes the streams
+    # of a process onto 4 hardware queues by default, and a fifth busy stream costs ~5 %.  Must be in the
+    # environment before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +99,7 @@ def main():
     # (H = --handles, 3 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
     # underfed (32 pairs: three groups of latency-bound tick kernels); with three steps at different phases one handle's
     # covariance kernels fill the gaps of the others' ticks.  Every handle registers its own copy of the step's clouds.
-    H = max(1, args.handles)
+    H = args.handles if args.handles > 0 else (4 if use_dist else 3)   # r01, one rank: 1.32 ms per step with 3; with RCCL's stream 1.38 / 1.35 for 3 / 4
     batches = []
     for _ in range(H):
         bh = reg.BatchAPDGICP(params, device=local_rank)
