@@ -738,7 +738,10 @@ class Engine {
     // large (dense) targets: a wave's 64 points touch many more groups (10.8 instead of 1.7 per wave for 100k x 500k), so
     // splitting the scans over 4 waves still pays with a few thousand blocks (r01: 0.170 -> 0.143 ms per iteration)
     const bool big_target = nmax_tgt > SORT_LDS_MAX_N;
-    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : 2;
+    // a handle limited to one pair group shares the GPU with other busy handles: throughput counts there, not the latency of
+    // this launch, and one wave per 64 points does no redundant bound work (three handles in flight: 1.32 -> 1.27 ms per step)
+    const int w_full = max_groups == 1 ? 1 : 2;
+    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
     if (nn_pruned) {
       if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
       else if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
