@@ -30,11 +30,36 @@ __device__ __forceinline__ unsigned expand10(unsigned v) {  // 10 bits -> every 
   return v;
 }
 
+#ifndef APD_CURVE_HILBERT
+#define APD_CURVE_HILBERT 1
+#endif
+// 30-bit position of a point on a space-filling curve through the 1024^3 grid over the cloud's bounding cube.  The order
+// only decides which points share a chunk / group box -- never a result -- so any curve is exact; the Hilbert curve has no
+// jumps (consecutive cells are face neighbours), which makes the boxes of 16 / 128 consecutive points tighter than along the
+// Z-curve.  Skilling's axes-to-transpose transform, then the usual bit interleave.
 __device__ __forceinline__ unsigned morton30(float x, float y, float z, float lx, float ly, float lz, float scale) {
   const float fx = fminf(fmaxf((x - lx) * scale, 0.f), 1023.f);
   const float fy = fminf(fmaxf((y - ly) * scale, 0.f), 1023.f);
   const float fz = fminf(fmaxf((z - lz) * scale, 0.f), 1023.f);
-  return (expand10((unsigned)fx) << 2) | (expand10((unsigned)fy) << 1) | expand10((unsigned)fz);
+  unsigned X0 = (unsigned)fx, X1 = (unsigned)fy, X2 = (unsigned)fz;
+#if APD_CURVE_HILBERT
+#pragma unroll
+  for (unsigned Q = 512u; Q > 1u; Q >>= 1) {
+    const unsigned P = Q - 1u;
+    if (X0 & Q) X0 ^= P;  // (i = 0: invert)
+    if (X1 & Q) X0 ^= P;
+    else { const unsigned t = (X0 ^ X1) & P; X0 ^= t, X1 ^= t; }
+    if (X2 & Q) X0 ^= P;
+    else { const unsigned t = (X0 ^ X2) & P; X0 ^= t, X2 ^= t; }
+  }
+  X1 ^= X0, X2 ^= X1;  // Gray encode
+  unsigned t = 0;
+#pragma unroll
+  for (unsigned Q = 512u; Q > 1u; Q >>= 1)
+    if (X2 & Q) t ^= Q - 1u;
+  X0 ^= t, X1 ^= t, X2 ^= t;
+#endif
+  return (expand10(X0) << 2) | (expand10(X1) << 1) | expand10(X2);
 }
 
 __device__ __forceinline__ float block_reduce_minmax(float v, bool is_max, float* lds, int tid, int nthreads) {
@@ -339,10 +364,25 @@ __global__ void k_morton_keys(const float4* pts, int n, int np2, const int* box6
   const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
   const float top = (float)((1u << bits) - 1u), scale = top / ext;
   const float4 p = pts[i];
-  const unsigned long long cx = (unsigned long long)fminf(fmaxf((p.x - lx) * scale, 0.f), top);
-  const unsigned long long cy = (unsigned long long)fminf(fmaxf((p.y - ly) * scale, 0.f), top);
-  const unsigned long long cz = (unsigned long long)fminf(fmaxf((p.z - lz) * scale, 0.f), top);
-  const unsigned long long m = (expand21(cx) << 2) | (expand21(cy) << 1) | expand21(cz);
+  unsigned X0 = (unsigned)fminf(fmaxf((p.x - lx) * scale, 0.f), top);
+  unsigned X1 = (unsigned)fminf(fmaxf((p.y - ly) * scale, 0.f), top);
+  unsigned X2 = (unsigned)fminf(fmaxf((p.z - lz) * scale, 0.f), top);
+#if APD_CURVE_HILBERT
+  for (unsigned Q = 1u << (bits - 1); Q > 1u; Q >>= 1) {  // Hilbert curve, as in morton30
+    const unsigned P = Q - 1u;
+    if (X0 & Q) X0 ^= P;
+    if (X1 & Q) X0 ^= P;
+    else { const unsigned t = (X0 ^ X1) & P; X0 ^= t, X1 ^= t; }
+    if (X2 & Q) X0 ^= P;
+    else { const unsigned t = (X0 ^ X2) & P; X0 ^= t, X2 ^= t; }
+  }
+  X1 ^= X0, X2 ^= X1;
+  unsigned t = 0;
+  for (unsigned Q = 1u << (bits - 1); Q > 1u; Q >>= 1)
+    if (X2 & Q) t ^= Q - 1u;
+  X0 ^= t, X1 ^= t, X2 ^= t;
+#endif
+  const unsigned long long m = (expand21(X0) << 2) | (expand21(X1) << 1) | expand21(X2);
   keys[i] = (m << idx_bits) | (unsigned long long)(unsigned)i;
 }
 
