@@ -1269,27 +1269,38 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
       if (j0 < n) a0 = c.pts[j0], b0 = (unsigned)c.perm[j0];
       if (j1 < n) a1 = c.pts[j1], b1 = (unsigned)c.perm[j1];
     };
-    int g = -1;
-    if (gany) {
-      g = __builtin_ctzll(gany);
-      gany &= gany - 1;
-      fetch(g, d0, d1, p0, p1);
-    }
+        // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
+    // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
+    // lists overflow less often.  In index order a few waves tightened 36 times (17 along the Z-curve): two clouds of 8192
+    // points 0.123 -> 0.07 ms.
+    const float lbg = lb_point_box(mybox, readlane_f(q.x, 32), readlane_f(q.y, 32), readlane_f(q.z, 32));
+    auto next_group = [&]() {
+      if (!gany) return -1;
+      if constexpr (L < 8) {  // many clouds per launch: throughput counts, index order is 2 % cheaper
+        const int g0_ = __builtin_ctzll(gany);
+        gany &= gany - 1;
+        return g0_;
+      }
+      const bool candl = ((gany >> lane) & 1ull) != 0;
+      const float mlb = wave_minmax_uniform<false>(candl ? lbg : inf);
+      const unsigned long long eq = __ballot(candl && lbg == mlb);
+      const int gsel = __builtin_ctzll(eq ? eq : gany);
+      gany &= ~(1ull << gsel);
+      return gsel;
+    };
+    int g = next_group();
+    if (g >= 0) fetch(g, d0, d1, p0, p1);
     while (g >= 0) {
       c0 = d0, c1 = d1, o0 = p0, o1 = p1;
       unsigned long long qm = __ballot(((gneed >> g) & 1ull) != 0 && sub == 0);
-      g = -1;
-      if (gany) {
-        g = __builtin_ctzll(gany);
-        gany &= gany - 1;
-        fetch(g, d0, d1, p0, p1);
-      }
+      g = next_group();
+      if (g >= 0) fetch(g, d0, d1, p0, p1);
       n_groups++;
       while (qm) {
         const int qq = __builtin_ctzll(qm);  // owner lane of the query
         qm &= qm - 1;
-        n_pairs++;
         const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
+        n_pairs++;
         unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
                                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
         const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
