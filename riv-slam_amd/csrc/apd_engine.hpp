@@ -598,6 +598,7 @@ class Engine {
   std::vector<int> cov_group_off;   // offsets into cov_list: group g owns [off[g + 1], off[g + 2]); the shared part is [0, off[1])
   // pair groups in flight: about 8 pairs per group up to the number of streams (r01, one scan against K keyframes, GN-20:
   // K = 8: 0.90 / 0.92 / 0.92 ms with 1 / 2 / 3 groups, K = 12: 1.12 / 0.98 / 1.02, K = 24: 1.41 / 1.23 / 1.17)
+  bool keep_maha = true;  // false for batch handles: nothing reads mahalanobis_ there unless the optimiser is LM (k_error)
   int max_groups = 1 << 30;  // apdgicp_batch_set_pair_groups: a caller that keeps several batches (handles) in flight wants one group each
   int group_count() const { return std::max(1, std::min<int>(std::min<int>((int)gstreams.size() + 1, max_groups), (npairs + 4) / 8)); }
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
@@ -691,7 +692,7 @@ class Engine {
     work.corr = b_corr.as<int>();
     work.nnpt = b_nnpt.as<float4>();
     work.sqd = b_sqd.as<float>();
-    work.maha = b_maha.as<double>();
+    work.maha = (keep_maha || params.optimizer == APDGICP_OPT_LM) ? b_maha.as<double>() : nullptr;
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();
     work.stats = d_stats.as<unsigned long long>();

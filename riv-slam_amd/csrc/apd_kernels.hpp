@@ -1551,9 +1551,11 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     if (cst.plain_gicp) cd = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T
     const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
     const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
-    double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
-    mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
-    mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
+    if (w.maha) {  // (null in a Gauss-Newton batch: only compute_error and the Mahalanobis getter of a single handle read it)
+      double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
+      mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
+      mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
+    }
 
     const float4 q = tq;  // corr == j here
     const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;

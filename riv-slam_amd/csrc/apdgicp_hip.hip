@@ -492,6 +492,7 @@ int apdgicp_batch_create(const apdgicp_params* p, int device, void* stream, apdg
       return rc;
     }
     b->eng.profile_nn = env_int("APDGICP_PROFILE_NN", 0) != 0;
+    b->eng.keep_maha = false;  // no batch entry point reads the Mahalanobis matrices back
     *out = b;
     return 0;
   });
