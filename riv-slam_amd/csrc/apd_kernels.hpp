@@ -997,8 +997,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
       const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
       float4 c0 = make_float4(inf, inf, inf, 0.f), c1 = c0;
       unsigned o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
-      if (j0 < n) c0 = c.pts[j0], o0 = (unsigned)c.perm[j0];
-      if (j1 < n) c1 = c.pts[j1], o1 = (unsigned)c.perm[j1];
+      if (j0 < n) c0 = c.pts[j0], o0 = __float_as_uint(c0.w);  // (the sorted points carry their original index in .w)
+      if (j1 < n) c1 = c.pts[j1], o1 = __float_as_uint(c1.w);
       while (qm) {
         const int qq = __builtin_ctzll(qm);
         qm &= qm - 1;
@@ -1266,8 +1266,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     auto fetch = [&](int g, float4& a0, float4& a1, unsigned& b0, unsigned& b1) {
       const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
       a0 = make_float4(inf, inf, inf, 0.f), a1 = a0, b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
-      if (j0 < n) a0 = c.pts[j0], b0 = (unsigned)c.perm[j0];
-      if (j1 < n) a1 = c.pts[j1], b1 = (unsigned)c.perm[j1];
+      if (j0 < n) a0 = c.pts[j0], b0 = __float_as_uint(a0.w);  // (the sorted points carry their original index in .w)
+      if (j1 < n) a1 = c.pts[j1], b1 = __float_as_uint(a1.w);
     };
         // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
     // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
@@ -1498,7 +1498,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       for (int jj = 0; jj < kChunk; jj++) {
         const int g = (int)chunk * kChunk + jj;
         t[jj] = tgt.pts[g < M ? g : M - 1];
-        po[jj] = tgt.perm[g < M ? g : M - 1];
+        po[jj] = __float_as_int(t[jj].w);
       }
 #pragma unroll
       for (int jj = 0; jj < kChunk; jj++) {
@@ -1510,7 +1510,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       for (int g = 0; g < M; g++) {
         const float4 t = tgt.pts[g];
         if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
-          const int o = tgt.perm[g];
+          const int o = __float_as_int(t.w);
           if (o < jorig) jorig = o, j = g, tq = t;
         }
       }

@@ -3,7 +3,7 @@
 // k-NN kernels use the boxes only to SKIP chunks whose fp32 lower bound proves they cannot contain a
 // (better) neighbour, and ties are still resolved by the ORIGINAL index (perm).
 //
-//   spts[s]  = pts[perm[s]]                     sorted copy, s = position on the Z-curve
+//   spts[s]  = pts[perm[s]]                     sorted copy, s = position on the curve; .w = the bits of perm[s]
 //   cbox[c]  = {lo.xyz, hi.xyz} of sorted points [16c, 16c+16)          (kChunk = 16)
 //   gbox[g]  = box of chunks [8g, 8g+8)  = 128 sorted points            (kGroup = 8 chunks)
 #pragma once
@@ -134,7 +134,9 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_lds(const SortJob* jobs
   for (int s = tid; s < n; s += SORT_BLK) {
     const int o = (int)(unsigned)keys[s];
     job.perm[s] = o;
-    job.spts[s] = job.pts[o];
+    float4 q = job.pts[o];
+    q.w = __int_as_float(o);  // the sorted copy carries the original index in .w (only x, y, z are coordinates on this path)
+    job.spts[s] = q;
   }
   __syncthreads();
   // chunk boxes from the sorted copy just written by this block (same block -> visible after the barrier
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_reg(const SortJob* jobs
     const int s = tid * E + e;
     if (s < n) {
       const int o = (int)(unsigned)key[e];
-      const float4 q = job.pts[o];
+      float4 q = job.pts[o];
+      q.w = __int_as_float(o);
       job.perm[s] = o;
       job.spts[s] = q;
       bx.lx = fminf(bx.lx, q.x), bx.ly = fminf(bx.ly, q.y), bx.lz = fminf(bx.lz, q.z);
@@ -434,7 +437,9 @@ __global__ void k_gather_sorted(const unsigned long long* keys, const float4* pt
   if (s >= n) return;
   const int o = (int)(keys[s] & ((1ull << idx_bits) - 1ull));
   perm[s] = o;
-  spts[s] = pts[o];
+  float4 q = pts[o];
+  q.w = __int_as_float(o);
+  spts[s] = q;
 }
 
 __global__ void k_boxes(const float4* spts, int n, int pts_per_box, Box* out, int nboxes) {
