@@ -689,9 +689,10 @@ class Engine {
     APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
     APD_TRY(b_errpart.ensure((size_t)npairs * work.nblk_max * 8));
     work.nnpart = b_nnpart.as<unsigned long long>();
-    work.corr = b_corr.as<int>();
+    const bool keep_point_results = keep_maha || params.optimizer == APDGICP_OPT_LM;  // see keep_maha
+    work.corr = keep_point_results ? b_corr.as<int>() : nullptr;
     work.nnpt = b_nnpt.as<float4>();
-    work.sqd = b_sqd.as<float>();
+    work.sqd = keep_point_results ? b_sqd.as<float>() : nullptr;
     work.maha = (keep_maha || params.optimizer == APDGICP_OPT_LM) ? b_maha.as<double>() : nullptr;
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();

@@ -1516,10 +1516,10 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       }
     }
   }
-  w.sqd[(size_t)pair * w.nstride + i] = m;
+  if (w.sqd) w.sqd[(size_t)pair * w.nstride + i] = m;  // (sqd, corr: null in a Gauss-Newton batch, like maha)
   w.nnpt[(size_t)pair * w.nstride + i] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
   const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
-  w.corr[(size_t)pair * w.nstride + i] = corr;
+  if (w.corr) w.corr[(size_t)pair * w.nstride + i] = corr;
   if (corr >= 0) {
     const double* ca = src.cov;
     const double* cb = tgt.cov;
