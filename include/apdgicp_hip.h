@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define APDGICP_ABI_VERSION 1
+#define APDGICP_ABI_VERSION 2   /* 2: + inlier_fraction, wait_producer, get_stream */
 
 typedef enum {
   APDGICP_OK = 0,
@@ -159,7 +159,22 @@ int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xy
  * squared distance with max_range as is); DBL_MAX when no point qualifies.  Callers:
  * loop_detector.cpp:229, scan_matching_odometry_nodelet.cpp:698.  n_inliers may be NULL */
 int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range, double* score, int64_t* n_inliers);
+/* ScanMatchingStatus::inlier_fraction (scan_matching_odometry_nodelet.cpp:701-712): the number of T-transformed source
+ * points whose nearest target point is STRICTLY closer than max_correspondence_dist (squared float distance < dist*dist
+ * in double, as there), divided by the source size in float.  n_inliers may be NULL */
+int apdgicp_inlier_fraction(apdgicp_handle* h, const float T[16], double max_correspondence_dist, double* fraction, int64_t* n_inliers);
 int apdgicp_synchronize(apdgicp_handle* h);
+/* Ordering against the stream that PRODUCED device-resident inputs.  The handle's streams are non-blocking: without this
+ * call nothing orders a kernel that still writes the cloud (on the caller's stream) against the handle's pack kernel.
+ * Everything queued on `producer_stream` (a hipStream_t; NULL = the legacy default stream) before this call completes
+ * before anything the handle enqueues afterwards starts; the host does not wait.  The other direction is the caller's:
+ * a device buffer handed to set_source/set_target/batch_set_cloud(s) may be freed or overwritten only after the handle
+ * has passed the call (apdgicp_synchronize / the align that follows / batch_align_collect of the batch that used it). */
+int apdgicp_wait_producer(apdgicp_handle* h, void* producer_stream);
+/* the hipStream_t the handle enqueues on (its own, or the one given to apdgicp_create): for callers that order their own
+ * work -- or their timing events -- against the handle without a host-side wait.  Every call of a handle ends with all
+ * of its work joined back onto this stream. */
+int apdgicp_get_stream(apdgicp_handle* h, void** stream);
 
 /* ------------------------------------------------------------------ batched registrations
  * Independent (source, target) pairs -- loop-closure candidates (loop_detector.cpp:222-236,404-423)
@@ -194,6 +209,8 @@ int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_p
  * gather results with RCCL.  apdgicp_batch_synchronize() waits for the stream. */
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results);
 int apdgicp_batch_synchronize(apdgicp_batch* b);
+int apdgicp_batch_wait_producer(apdgicp_batch* b, void* producer_stream);   /* see apdgicp_wait_producer */
+int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream);              /* see apdgicp_get_stream */
 /* A stream of batches (one per keyframe, loop_detector.cpp:222-236) with two of them in flight: enqueue launches everything
  * batch s needs -- packing and sorting of clouds set since the last call, covariances, every optimiser tick, the final
  * poll -- and returns without waiting when the run length is known up front (Gauss-Newton; a Levenberg-Marquardt run polls

@@ -346,7 +346,8 @@ int calculate_covariances(Ref& r, Cloud& c) {
   int bad = 0;
 #pragma omp parallel for num_threads(r.num_threads) schedule(guided, 8)
   for (int i = 0; i < n; i++) {
-    std::vector<Cand> heap;
+    static thread_local std::vector<Cand> heap;  // one candidate list per thread, not one allocation per query
+    heap.clear();
     heap.reserve(k + 1);
     c.tree.search(c.pts[i], k, heap);  // A:316 (query point itself is among the k)
     double mean[3] = {0, 0, 0};
@@ -430,7 +431,8 @@ void update_correspondences(Ref& r, const M4& T) {
     pt.x = ((Tf[0][0] * a.x + Tf[0][1] * a.y) + Tf[0][2] * a.z) + Tf[0][3];
     pt.y = ((Tf[1][0] * a.x + Tf[1][1] * a.y) + Tf[1][2] * a.z) + Tf[1][3];
     pt.z = ((Tf[2][0] * a.x + Tf[2][1] * a.y) + Tf[2][2] * a.z) + Tf[2][3];
-    std::vector<Cand> heap;
+    static thread_local std::vector<Cand> heap;
+    heap.clear();
     heap.reserve(2);
     r.tgt.tree.search(pt, 1, heap);  // A:151
     r.sqd[i] = heap[0].d;            // A:153

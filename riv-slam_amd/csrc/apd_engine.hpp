@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/apdgicp_hip.h"
 #include "apd_kernels.hpp"
 
@@ -41,6 +43,41 @@ inline int fail(int code, const std::string& msg) {
     int rc_ = (expr);          \
     if (rc_ < 0) return rc_;   \
   } while (0)
+
+// roctx ranges over the host-side phases (pack / sort / k-NN covariances / optimiser ticks / poll), visible in
+// `rocprofv3 --marker-trace`.  The marker library is looked up at run time -- the copy already in the process (a profiler
+// preloads its own; torch ships one), else ROCm's -- so the library has no link-time dependency on a profiler component and
+// the ranges cost two indirect calls when no tool listens, nothing at all when no marker library exists.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+inline const RoctxApi& roctx_api() {
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    void* sym = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+    void* lib = nullptr;
+    if (!sym)
+      for (const char* name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    a.push = (int (*)(const char*))(sym ? sym : lib ? dlsym(lib, "roctxRangePushA") : nullptr);
+    a.pop = (int (*)())(sym ? dlsym(RTLD_DEFAULT, "roctxRangePop") : lib ? dlsym(lib, "roctxRangePop") : nullptr);
+    if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+    return a;
+  }();
+  return api;
+}
+struct roctx_range {
+  bool on;
+  explicit roctx_range(const char* name) : on(roctx_api().push != nullptr) {
+    if (on) roctx_api().push(name);
+  }
+  ~roctx_range() {
+    if (on) roctx_api().pop();
+  }
+  roctx_range(const roctx_range&) = delete;
+  roctx_range& operator=(const roctx_range&) = delete;
+};
 
 struct DevBuf {
   void* p = nullptr;
@@ -202,12 +239,24 @@ class Engine {
   int profile_stride = 10, profile_phase = 0, cur_tick = 0;
   int last_ticks = 0;
 
+  // The opt-in for more than 64 KB of dynamic LDS is a property of the (function, device) pair, so every engine sets it
+  // for its own device when it is created -- no process-wide "done once" flag that a second device or thread could trip over.
+  static int set_kernel_attributes() {
+    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
+    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SORT_BLK * 8));
+    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SORT_BLK * 8));
+    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * SORT_BLK * 8));
+    APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
+    return 0;
+  }
+
   int init(const apdgicp_params* p, int dev, void* strm) {
     int count = 0;
     APD_HIP(hipGetDeviceCount(&count));
     if (dev < 0 || dev >= count) return fail(APDGICP_ERR_INVALID_ARG, "device index out of range");
     device = dev;
     APD_HIP(hipSetDevice(device));
+    APD_TRY(set_kernel_attributes());
     if (strm) {
       stream = (hipStream_t)strm;
     } else {
@@ -268,6 +317,7 @@ class Engine {
     if (h_probe) e = hipHostFree(h_probe);
     if (ev_poll) e = hipEventDestroy(ev_poll);
     if (ev_main) e = hipEventDestroy(ev_main);
+    if (ev_producer) e = hipEventDestroy(ev_producer);
     for (auto st_ : gstreams) e = hipStreamSynchronize(st_), e = hipStreamDestroy(st_);
     for (auto ev_ : gevents) e = hipEventDestroy(ev_);
     for (auto& pr : nn_events) e = hipEventDestroy(pr.first), e = hipEventDestroy(pr.second);
@@ -306,6 +356,18 @@ class Engine {
     return c;
   }
 
+  // Device-resident inputs are produced on the CALLER's stream; the engine's streams are non-blocking, so nothing orders
+  // the two unless asked: everything queued on `producer` so far will have finished before anything this engine enqueues
+  // from now on starts (an event on the producer, a wait on the engine's stream -- the host does not block).
+  hipEvent_t ev_producer = nullptr;
+  int wait_producer(void* producer) {
+    APD_HIP(hipSetDevice(device));
+    if (!ev_producer) APD_HIP(hipEventCreateWithFlags(&ev_producer, hipEventDisableTiming));
+    APD_HIP(hipEventRecord(ev_producer, (hipStream_t)producer));
+    APD_HIP(hipStreamWaitEvent(stream, ev_producer, 0));
+    return 0;
+  }
+
   // ------------------------------------------------------------------ clouds
   int set_cloud(int slot, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token) {
     if (slot < 0) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud slot");
@@ -313,6 +375,7 @@ class Engine {
     if (n > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud too large");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
     APD_HIP(hipSetDevice(device));
+    roctx_range rr("apdgicp:pack");
     if ((int)clouds.size() <= slot) clouds.resize(slot + 1);
     Cloud& c = clouds[slot];
     // the previous contents may still be in use by queued kernels on this stream; stream order protects us
@@ -343,6 +406,7 @@ class Engine {
     if (!xyz || !ns) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
     APD_HIP(hipSetDevice(device));
+    roctx_range rr("apdgicp:pack");
     if ((int)clouds.size() < first + count) clouds.resize(first + count);
     bool grew = false;
     int nmax = 0;
@@ -386,14 +450,17 @@ class Engine {
     std::vector<SortJob> small, regjobs[3];
     std::vector<int> large;
     int np2max = 1;
-    bool grew = false;
+    bool grew = false, any = false;
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
       if (c.n <= 0 || c.sorted) continue;
+      any = true;
       const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts, nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
       grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || (ngr + nsup) * sizeof(Box) > c.gbox.cap;
     }
+    if (!any) return 0;
     if (grew) APD_HIP(hipStreamSynchronize(stream));  // old buffers may still be read by queued kernels
+    roctx_range rr("apdgicp:sort");
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
       if (c.n <= 0 || c.sorted) continue;
@@ -422,24 +489,13 @@ class Engine {
     }
     if (!small.empty()) {
       APD_TRY(d_sortjobs.upload(small.data(), small.size() * sizeof(SortJob), stream));
-      static bool attr_set = false;
-      if (!attr_set) {
-        APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
-        attr_set = true;
-      }
       hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_sortjobs.as<SortJob>());
       APD_HIP(hipGetLastError());
     }
     for (int cls = 0; cls < 3; cls++) {
       if (regjobs[cls].empty()) continue;
       APD_TRY(d_sortjobs_reg[cls].upload(regjobs[cls].data(), regjobs[cls].size() * sizeof(SortJob), stream));
-      const void* fn = cls == 0 ? (const void*)k_sort_cloud_reg<4> : cls == 1 ? (const void*)k_sort_cloud_reg<8> : (const void*)k_sort_cloud_reg<16>;
       const size_t lds = (size_t)(4 << cls) * SORT_BLK * 8;
-      static bool attr_set[3] = {false, false, false};
-      if (!attr_set[cls]) {
-        APD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[cls] = true;
-      }
       const SortJob* dj = d_sortjobs_reg[cls].as<SortJob>();
       const dim3 grid((unsigned)regjobs[cls].size());
       if (cls == 0) hipLaunchKernelGGL(k_sort_cloud_reg<4>, grid, dim3(SORT_BLK), lds, stream, dj);
@@ -554,6 +610,7 @@ class Engine {
   // one covariance launch for the clouds ids[0..count) (device copy of the list: d_list) on stream `st`
   int launch_knn(const int* ids, const int* d_list, int count, hipStream_t st) {
     if (count <= 0) return 0;
+    roctx_range rr("apdgicp:knn_cov");
     int nmax = 0;
     long long total = 0;
     for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
@@ -563,7 +620,7 @@ class Engine {
       int qpw = env_int("APDGICP_KNN_QPW", 0);
       if (qpw != 4 && qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;  // measured (r01): 2 clouds of 8k 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
-      static const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
+      const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
       if (coop && qpw == 16)
         hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
@@ -577,11 +634,6 @@ class Engine {
         hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {
-      static bool attr_set = false;
-      if (!attr_set) {
-        APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
-        attr_set = true;
-      }
       const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)count);
       hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                          params.regularization, d_errflag.as<int>());
@@ -825,7 +877,10 @@ class Engine {
   int finish_align() {
     if (!pending) return 0;
     pending = false;
-    APD_HIP(hipEventSynchronize(ev_poll));
+    {
+      roctx_range rr("apdgicp:poll");
+      APD_HIP(hipEventSynchronize(ev_poll));
+    }
     last_ticks = pending_ticks;
     if (profile_nn) APD_TRY(collect_nn_profile());
     if (h_status[pending_npairs]) {
@@ -899,11 +954,14 @@ class Engine {
         }
         cov_group_off.clear();
       }
-      for (int t = 0; t < todo; t++, cur_tick++)
-        for (int g = 0; g < ng; g++) {
-          const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
-          APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
-        }
+      {
+        roctx_range rr("apdgicp:ticks");
+        for (int t = 0; t < todo; t++, cur_tick++)
+          for (int g = 0; g < ng; g++) {
+            const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
+            APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+          }
+      }
       for (int g = 1; g < ng; g++) {
         APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
         APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
@@ -926,7 +984,10 @@ class Engine {
         return 0;
       }
       const auto t_enq = std::chrono::steady_clock::now();
-      APD_HIP(hipEventSynchronize(ev_poll));
+      {
+        roctx_range rr("apdgicp:poll");
+        APD_HIP(hipEventSynchronize(ev_poll));
+      }
       if (dbg_t)
         fprintf(stderr, "[apdgicp] %d ticks: enqueue %.3f ms, wait %.3f ms\n", todo, std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());

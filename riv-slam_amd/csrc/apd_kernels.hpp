@@ -2118,7 +2118,7 @@ __global__ void k_transform_points(const float4* pts /* original order */, int n
 // fitness (pcl::Registration::getFitnessScore): per pair, sum and count of the nearest-neighbour squared
 // distances <= max_range2 taken from the merged nn partials of a search at the pose in st[pair].x0.
 // out[2*pair] += d2 (double), out[2*pair+1] += 1
-__global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out) {
+__global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, const PairDesc* pairs, Work w, double max_range2, double* out, int strict) {
   __shared__ double red[(LIN_BLK / 64) * 2];
   const int pair = pair_of(w, blockIdx.y);
   const int N = pairs[pair].s.n, tid = threadIdx.x;
@@ -2133,7 +2133,8 @@ __global__ __launch_bounds__(LIN_BLK) void k_fitness(const CloudDesc* clouds, co
       bestp = v < bestp ? v : bestp;
     }
     const float m = __uint_as_float((unsigned)(bestp >> 32));
-    if ((unsigned)bestp != kNoChunk && (double)m <= max_range2) acc[0] = (double)m, acc[1] = 1.0;
+    // pcl getFitnessScore keeps d <= max_range; the odometry status counts inliers with d < max^2 (scan_matching_odometry_nodelet.cpp:707)
+    if ((unsigned)bestp != kNoChunk && (strict ? (double)m < max_range2 : (double)m <= max_range2)) acc[0] = (double)m, acc[1] = 1.0;
   }
   block_reduce<2, LIN_BLK>(acc, red, tid);
   if (tid == 0) {

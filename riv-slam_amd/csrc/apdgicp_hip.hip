@@ -449,27 +449,68 @@ int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xy
   });
 }
 
+// nearest-neighbour statistics of the T-transformed source: sum and count of the squared distances inside the range
+static int nn_range_stats(apdgicp_handle* h, const float T[16], double max_range2, int strict, double* sum, double* cnt) {
+  APD_TRY(ensure_pair(h));
+  Engine& e = h->eng;
+  roctx_range rr("apdgicp:fitness");
+  double T16[16];
+  for (int q = 0; q < 16; q++) T16[q] = (double)T[q];
+  APD_HIP(hipMemcpyAsync(e.d_T.p, T16, sizeof(T16), hipMemcpyHostToDevice, e.stream));
+  hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, e.stream, e.d_state.as<PairState>(), e.d_T.as<double>(), (int)ST_NEED_LIN, 0);
+  APD_TRY(e.launch_nn(e.whole()));
+  APD_HIP(hipMemsetAsync(e.d_probe.p, 0, 2 * sizeof(double), e.stream));
+  hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max, 1), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
+                     max_range2, e.d_probe.as<double>(), strict);
+  APD_HIP(hipMemcpyAsync(e.h_probe, e.d_probe.p, 2 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
+  APD_HIP(hipStreamSynchronize(e.stream));
+  h->have_corr = false;  // the nn partials were overwritten at another pose
+  *sum = e.h_probe[0], *cnt = e.h_probe[1];
+  return 0;
+}
+
 int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range, double* score, int64_t* n_inliers) {
   return guarded([&]() -> int {
     if (!h || !T || !score) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
-    APD_TRY(ensure_pair(h));
-    Engine& e = h->eng;
-    double T16[16];
-    for (int q = 0; q < 16; q++) T16[q] = (double)T[q];
-    APD_HIP(hipMemcpyAsync(e.d_T.p, T16, sizeof(T16), hipMemcpyHostToDevice, e.stream));
-    hipLaunchKernelGGL(k_set_probe, dim3(1), dim3(1), 0, e.stream, e.d_state.as<PairState>(), e.d_T.as<double>(), (int)ST_NEED_LIN, 0);
-    APD_TRY(e.launch_nn(e.whole()));
-    APD_HIP(hipMemsetAsync(e.d_probe.p, 0, 2 * sizeof(double), e.stream));
-    hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max, 1), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(), e.d_pairs.as<PairDesc>(), e.work,
-                       max_range, e.d_probe.as<double>());
-    APD_HIP(hipMemcpyAsync(e.h_probe, e.d_probe.p, 2 * sizeof(double), hipMemcpyDeviceToHost, e.stream));
-    APD_HIP(hipStreamSynchronize(e.stream));
-    h->have_corr = false;  // the nn partials were overwritten at another pose
-    const double cnt = e.h_probe[1];
-    *score = cnt > 0 ? e.h_probe[0] / cnt : std::numeric_limits<double>::max();  // pcl returns max() when nothing is in range
+    double sum = 0, cnt = 0;
+    APD_TRY(nn_range_stats(h, T, max_range, 0, &sum, &cnt));
+    *score = cnt > 0 ? sum / cnt : std::numeric_limits<double>::max();  // pcl returns max() when nothing is in range
     if (n_inliers) *n_inliers = (int64_t)cnt;
     return 0;
   });
+}
+
+int apdgicp_inlier_fraction(apdgicp_handle* h, const float T[16], double max_correspondence_dist, double* fraction, int64_t* n_inliers) {
+  return guarded([&]() -> int {
+    if (!h || !T || !fraction) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    double sum = 0, cnt = 0;
+    APD_TRY(nn_range_stats(h, T, max_correspondence_dist * max_correspondence_dist, 1, &sum, &cnt));
+    *fraction = (double)((float)(int)cnt / (float)h->eng.clouds[kSrc].n);  // static_cast<float>(num_inliers) / aligned->size()
+    if (n_inliers) *n_inliers = (int64_t)cnt;
+    return 0;
+  });
+}
+
+int apdgicp_wait_producer(apdgicp_handle* h, void* producer_stream) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  return h->eng.wait_producer(producer_stream);
+}
+
+int apdgicp_get_stream(apdgicp_handle* h, void** stream) {
+  if (!h || !stream) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  *stream = (void*)h->eng.stream;
+  return 0;
+}
+
+int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream) {
+  if (!b || !stream) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+  *stream = (void*)b->eng.stream;
+  return 0;
+}
+
+int apdgicp_batch_wait_producer(apdgicp_batch* b, void* producer_stream) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  return b->eng.wait_producer(producer_stream);
 }
 
 int apdgicp_synchronize(apdgicp_handle* h) {
@@ -646,7 +687,7 @@ int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n
                        (int)n_pairs);
     APD_TRY(e.launch_nn(e.whole()));
     hipLaunchKernelGGL(k_fitness, dim3((unsigned)e.work.nblk_max, (unsigned)n_pairs), dim3(LIN_BLK), 0, e.stream, e.d_desc.as<CloudDesc>(),
-                       e.d_pairs.as<PairDesc>(), e.work, max_range, d_out);
+                       e.d_pairs.as<PairDesc>(), e.work, max_range, d_out, 0);
     std::vector<double> h((size_t)n_pairs * 2);
     APD_HIP(hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));

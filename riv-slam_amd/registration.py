@@ -85,7 +85,8 @@ SYMBOLS = [
     "apdgicp_swap_source_and_target", "apdgicp_compute_covariances", "apdgicp_get_covariances",
     "apdgicp_set_covariances", "apdgicp_linearize", "apdgicp_compute_error", "apdgicp_get_correspondences",
     "apdgicp_get_mahalanobis", "apdgicp_align", "apdgicp_align_host_loop", "apdgicp_get_final_hessian",
-    "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_synchronize",
+    "apdgicp_transform_source", "apdgicp_fitness_score", "apdgicp_inlier_fraction", "apdgicp_synchronize", "apdgicp_wait_producer",
+    "apdgicp_batch_wait_producer", "apdgicp_get_stream", "apdgicp_batch_get_stream",
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
@@ -139,6 +140,11 @@ def load_library(path: str | None = None):
     L.apdgicp_get_final_hessian.argtypes = [vp, vp]
     L.apdgicp_transform_source.argtypes = [vp, vp, vp, i64, i64]
     L.apdgicp_fitness_score.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
+    L.apdgicp_inlier_fraction.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
+    L.apdgicp_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.apdgicp_batch_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.apdgicp_wait_producer.argtypes = [vp, vp]
+    L.apdgicp_batch_wait_producer.argtypes = [vp, vp]
     L.apdgicp_batch_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
     for f in (L.apdgicp_batch_destroy, L.apdgicp_batch_clear, L.apdgicp_batch_compute_covariances, L.apdgicp_batch_synchronize):
         f.argtypes = [vp]
@@ -212,6 +218,15 @@ def _cloud_arg(cloud):
         if a.ndim != 2 or a.shape[1] < 3:
             raise ValueError("cloud must be [n, >=3]")
     return _ptr(a), a.shape[0], a.strides[0], 0, a
+
+
+def _producer_stream(keep):
+    """The stream a torch CUDA tensor was (by convention) produced on: torch's current stream.  None for anything else
+    (raw DevicePoints: the caller orders them with wait_producer() itself)."""
+    if hasattr(keep, "data_ptr") and getattr(keep, "is_cuda", False):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(keep.device).cuda_stream)
+    return None
 
 
 def _colmajor(T, dtype):
@@ -295,15 +310,32 @@ class FastAPDGICP:
         self._push()
 
     # ---- clouds (A:90-108); token = identity of the caller's cloud object (pointer equality in the reference)
-    def setInputSource(self, cloud, token: int = 0):
+    # Device-resident inputs (torch CUDA tensors): the handle's stream first waits for torch's current stream (the producer),
+    # and the tensor is retained until the handle has certainly consumed it -- the next call that waits for the handle's
+    # stream -- so a temporary (`g.setInputSource(x.cuda())`) cannot be recycled by torch's allocator under the pack kernel.
+    def _set_cloud(self, fn, slot, cloud, token):
         p, n, stride, dev, keep = _cloud_arg(cloud)
-        _check(self.L.apdgicp_set_source(self.h, p, n, stride, dev, token))
-        self.n_src = n
+        if dev:
+            if self._keep.get(slot) is not None:   # an earlier device cloud of this slot may still be queued for packing
+                _check(self.L.apdgicp_synchronize(self.h))
+                self._keep.clear()
+            ps = _producer_stream(keep)
+            if ps is not None:
+                _check(self.L.apdgicp_wait_producer(self.h, ps))
+        _check(fn(self.h, p, n, stride, dev, token))
+        if dev:
+            self._keep[slot] = keep
+        return n
+
+    def wait_producer(self, stream_ptr: int = 0):
+        """Orders the handle behind everything queued so far on the given hipStream_t (0: the legacy default stream)."""
+        _check(self.L.apdgicp_wait_producer(self.h, C.c_void_p(stream_ptr)))
+
+    def setInputSource(self, cloud, token: int = 0):
+        self.n_src = self._set_cloud(self.L.apdgicp_set_source, SOURCE, cloud, token)
 
     def setInputTarget(self, cloud, token: int = 0):
-        p, n, stride, dev, keep = _cloud_arg(cloud)
-        _check(self.L.apdgicp_set_target(self.h, p, n, stride, dev, token))
-        self.n_tgt = n
+        self.n_tgt = self._set_cloud(self.L.apdgicp_set_target, TARGET, cloud, token)
 
     def clearSource(self):
         _check(self.L.apdgicp_clear_source(self.h))
@@ -386,6 +418,7 @@ class FastAPDGICP:
         g = None if guess is None else _colmajor(guess, np.float32)
         fn = self.L.apdgicp_align_host_loop if host_loop else self.L.apdgicp_align
         _check(fn(self.h, _ptr(g) if g is not None else None, C.byref(self.result)))
+        self._keep.clear()   # align waits for the handle's stream: every queued pack has run
         self._converged = bool(self.result.converged)
         self._final = self.result.matrix()
         if want_output:
@@ -416,6 +449,19 @@ class FastAPDGICP:
         self.last_inliers = cnt.value
         return score.value
 
+    def stream_ptr(self) -> int:
+        st = C.c_void_p()
+        _check(self.L.apdgicp_get_stream(self.h, C.byref(st)))
+        return st.value or 0
+
+    def inlierFraction(self, max_correspondence_dist: float = 0.5, T=None) -> float:
+        """ScanMatchingStatus.inlier_fraction (scan_matching_odometry_nodelet.cpp:701-712): strict `<` on the squared distance."""
+        Tc = _colmajor(self._final if T is None else T, np.float32)
+        frac, cnt = C.c_double(), C.c_int64()
+        _check(self.L.apdgicp_inlier_fraction(self.h, _ptr(Tc), max_correspondence_dist, C.byref(frac), C.byref(cnt)))
+        self.last_inliers = cnt.value
+        return frac.value
+
     @property
     def nr_iterations(self):
         return int(self.result.iterations)
@@ -430,6 +476,9 @@ class BatchAPDGICP:
         self.b = C.c_void_p()
         _check(self.L.apdgicp_batch_create(C.byref(self.params), device, stream, C.byref(self.b)))
         self.n_clouds = 0
+        # device-resident inputs retained until the batch has consumed them: [objects set since the last enqueue], and per
+        # ticket the objects its pack kernels read (released by collect / synchronize / a blocking align)
+        self._keep_new, self._keep_ticket = [], {}
 
     def close(self):
         if getattr(self, "b", None):
@@ -450,14 +499,28 @@ class BatchAPDGICP:
         _check(self.L.apdgicp_batch_clear(self.b))
         self.n_clouds = 0
 
+    def _device_input(self, keep):
+        ps = _producer_stream(keep[0] if isinstance(keep, list) and keep else keep)
+        if ps is not None:
+            _check(self.L.apdgicp_batch_wait_producer(self.b, ps))
+        self._keep_new.append(keep)
+
+    def wait_producer(self, stream_ptr: int = 0):
+        """Orders the batch behind everything queued so far on the given hipStream_t (0: the legacy default stream)."""
+        _check(self.L.apdgicp_batch_wait_producer(self.b, C.c_void_p(stream_ptr)))
+
     def add_cloud(self, cloud) -> int:
         p, n, stride, dev, keep = _cloud_arg(cloud)
+        if dev:
+            self._device_input(keep)
         idx = _check(self.L.apdgicp_batch_add_cloud(self.b, p, n, stride, dev))
         self.n_clouds = idx + 1
         return idx
 
     def set_cloud(self, index: int, cloud) -> int:
         p, n, stride, dev, keep = _cloud_arg(cloud)
+        if dev:
+            self._device_input(keep)
         idx = _check(self.L.apdgicp_batch_set_cloud(self.b, index, p, n, stride, dev))
         self.n_clouds = max(self.n_clouds, idx + 1)
         return idx
@@ -478,7 +541,9 @@ class BatchAPDGICP:
     def set_clouds(self, first_index: int, clouds):
         """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride -- or pack_clouds(list)"""
         packed = clouds if isinstance(clouds, tuple) and clouds and clouds[0] == "packed_clouds" else self.pack_clouds(clouds)
-        _, ptrs, ns, stride, dev, n, _keep = packed
+        _, ptrs, ns, stride, dev, n, keep = packed
+        if dev and keep:
+            self._device_input(keep)   # (one producer wait for the whole list: torch's current stream)
         _check(self.L.apdgicp_batch_set_clouds(self.b, first_index, n, ptrs, ns, stride, dev))
         self.n_clouds = max(self.n_clouds, first_index + n)
 
@@ -500,6 +565,7 @@ class BatchAPDGICP:
         arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
         out = np.zeros(len(arr), dtype=RESULT_DTYPE)
         _check(self.L.apdgicp_batch_align(self.b, arr, len(arr), _ptr(out)))
+        self._keep_new.clear(), self._keep_ticket.clear()   # a blocking align: every queued pack has run
         return out
 
     def align_async(self, pairs, guesses=None):
@@ -519,6 +585,7 @@ class BatchAPDGICP:
         arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
         ticket = C.c_uint64()
         _check(self.L.apdgicp_batch_align_enqueue(self.b, arr, len(arr), C.byref(ticket)))
+        self._keep_ticket[ticket.value], self._keep_new = self._keep_new, []
         self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 1 >= ticket.value}, ticket.value: len(arr)}
         return ticket.value
 
@@ -528,6 +595,8 @@ class BatchAPDGICP:
         n = getattr(self, "_ticket_pairs", {}).get(ticket)
         if n is None:
             raise ValueError(f"ticket {ticket} is not one of the last two enqueued batches")
+        for t in [t for t in self._keep_ticket if t <= ticket]:   # stream order: everything up to this batch has run
+            del self._keep_ticket[t]
         if device:
             dptr = C.c_void_p()
             _check(self.L.apdgicp_batch_align_collect(self.b, ticket, C.byref(dptr), None))
@@ -580,8 +649,15 @@ class BatchAPDGICP:
         _check(self.L.apdgicp_batch_fitness(self.b, arr, n, _ptr(Tc) if Tc is not None else None, max_range, _ptr(scores), _ptr(inl)))
         return scores, inl
 
+    def stream_ptr(self) -> int:
+        """The handle's hipStream_t as an integer (wrap it with torch.cuda.ExternalStream to record events on it)."""
+        st = C.c_void_p()
+        _check(self.L.apdgicp_batch_get_stream(self.b, C.byref(st)))
+        return st.value or 0
+
     def synchronize(self):
         _check(self.L.apdgicp_batch_synchronize(self.b))
+        self._keep_new.clear(), self._keep_ticket.clear()
 
     def copy_results_to(self, dst, n_pairs: int):
         """dst: torch uint8 tensor (device or host) or numpy array with room for n_pairs records."""

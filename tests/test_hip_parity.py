@@ -381,6 +381,62 @@ def test_fitness_score(reg, golden):
         assert abs(got - want) < 1e-9 * want and g.last_inliers == sel.sum()
 
 
+def test_inlier_fraction_is_strict(reg, golden):
+    """ScanMatchingStatus.inlier_fraction (scan_matching_odometry_nodelet.cpp:701-712): `sq < d*d`, strictly, count / size in float."""
+    import apdgicp_np as O
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(src)
+    g.setInputTarget(tgt)
+    T = g.align(guess)
+    _, sq = O.nn1(O.transform_points_f32(T.astype(np.float64), src), tgt)
+    exact = float(np.sqrt(np.float64(np.sort(sq)[len(sq) // 2])))   # a threshold that IS some point's distance: `<` vs `<=` differ
+    for d in (0.5, 0.1, exact, 1e-9):
+        want = int((sq.astype(np.float64) < d * d).sum())
+        got = g.inlierFraction(d)
+        assert g.last_inliers == want and got == float(np.float32(want) / np.float32(len(src))), d
+    assert g.getFitnessScore(exact * exact) > 0 and g.last_inliers >= int((sq.astype(np.float64) < exact * exact).sum())
+
+
+def test_temporary_device_tensors_are_safe(reg, scene):
+    """A device cloud handed over as a temporary must stay alive, and the handle must wait for the stream that produced it:
+    torch's caching allocator would otherwise recycle the block under the queued pack kernel."""
+    import torch
+    s, t, _, guess = scene.make_pair(4096, 4096, scene.pair_seed(7, 1), "odometry")
+    want = None
+    for rep_ in range(6):
+        g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+        big = torch.zeros(64 << 20, device="cuda")          # keeps torch's stream busy in front of the producer
+        for _ in range(4):
+            big.add_(1.0)
+        g.setInputSource((torch.from_numpy(s).cuda() + big[: s.size].view(s.shape) * 0.0))   # produced late on torch's stream, temporary
+        junk1 = torch.full(s.shape, 1e6, device="cuda")     # same size: would reuse the block if it had been released
+        g.setInputTarget(torch.from_numpy(t).cuda() * 1.0)
+        junk2 = torch.full(t.shape, -1e6, device="cuda")
+        T = g.align(guess)
+        info = (info_of(g), T.tobytes())
+        want = want or info
+        assert info == want
+        del junk1, junk2, big
+    h = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    h.setInputSource(s), h.setInputTarget(t)
+    assert h.align(guess).tobytes() == want[1] and info_of(h) == want[0]
+    # the batch path: temporaries across an enqueue / collect pipeline
+    b = reg.BatchAPDGICP(reg.default_params(optimizer=reg.OPT_GN, max_iterations=4, max_correspondence_distance=2.0))
+    ref_ = reg.BatchAPDGICP(reg.default_params(optimizer=reg.OPT_GN, max_iterations=4, max_correspondence_distance=2.0))
+    ref_.set_clouds(0, [s, t])
+    want_b = ref_.align([(0, 1)], [guess]).tobytes()
+    tickets = []
+    for rep_ in range(4):
+        b.set_clouds(0, [torch.from_numpy(s).cuda() * 1.0, torch.from_numpy(t).cuda() * 1.0])
+        junk = [torch.full(s.shape, 3e5, device="cuda") for _ in range(4)]
+        tickets.append(b.align_enqueue([(0, 1)], [guess]))
+        if len(tickets) == 2:
+            assert b.align_collect(tickets.pop(0)).tobytes() == want_b
+        del junk
+    assert b.align_collect(tickets.pop(0)).tobytes() == want_b
+
+
 # ------------------------------------------------------------------ batched registrations (8e / C3)
 def test_batch_matches_single(reg, golden, scene):
     clouds, pairs, guesses = [], [], []

@@ -90,3 +90,22 @@ def test_two_ranks_gather_all_results_in_order(pkg, n_pairs):
     reg = importlib.import_module("riv-slam_amd.registration")
     recs = np.frombuffer(outs[0], dtype=reg.RESULT_DTYPE)
     assert len(recs) == n_pairs and recs["n_linearize"].min() >= 1
+
+
+def test_bench_spawns_its_own_ranks_before_touching_torch():
+    """`python bench.py --gpus N` without a launcher (how the driver starts the scaling run): N child ranks with the
+    torch.distributed environment, started by a parent that has not imported torch; only rank 0 reaches stdout."""
+    import json
+    import subprocess
+    env = dict(os.environ, APDGICP_BENCH_SPAWN_PROBE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    assert lines == [{"rank": 0, "world": 4, "local_rank": 0, "master": "127.0.0.1", "torch_imported": False}]
+    # under a launcher (WORLD_SIZE set) the same file is a plain rank and spawns nothing
+    env2 = dict(env, RANK="1", WORLD_SIZE="4", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout)["rank"] == 1

@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch of the dominant kernel (k_nn_pruned, batch launches only) from the two separate PMC passes
-(rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE): writes profiles/pmc_nn_latest.json, which bench.py
-reports as roofline.traffic.   usage: pmc_nn_json.py fetch.db write.db out.json
+"""Per-launch PMC numbers of the dominant kernel (the nearest-neighbour search, batch launches only) from separate
+rocprofv3 --pmc passes: writes profiles/pmc_nn_latest.json, which bench.py reports as roofline.traffic / roofline_issue
+when the launch shape matches its own.
+usage: pmc_nn_json.py out.json points kind pass1.db [pass2.db ...]
 FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (it reports half of a wide coalesced read)."""
 import json
 import sqlite3
 import sys
 
-
-def avg(dbfile, counter):
+out_path, points, kind = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+vals, shape = {}, None
+for dbfile in sys.argv[4:]:
     db = sqlite3.connect(dbfile)
-    r = db.execute("select avg(value), count(*), max(grid_size_y) from counters_collection where counter_name = ? and kernel_name like '%k_nn_pruned%' "
-                   "and grid_size_y >= 8", (counter,)).fetchone()  # the batch's pair-group launches, not the single-pair leg
-    return float(r[0]), int(r[1]), int(r[2])
-
-
-f, nf, py = avg(sys.argv[1], "FETCH_SIZE")
-w, nw, _ = avg(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "k_nn_pruned<1, 2>", "config": f"{py} pairs (one pair group) x 8192 x 8192 per launch",
-       "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "dispatches": [nf, nw],
-       "hbm_bytes_per_launch": int(round((2.0 * f + w) * 1024)),
-       "note": "separate --pmc passes (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE); FETCH_SIZE doubled per MI355X_MICROARCH.md "
-               "(gfx950 reports half of a wide coalesced read); pair-group launches of the batch only (grid y >= 8)"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+    # the batch's pair-group launches (grid y = pairs per launch >= 8), not the single-pair legs; one kernel instantiation only
+    rows = db.execute("select kernel_name, grid_size_x, grid_size_y, workgroup_size_x, counter_name, avg(value), count(*) from counters_collection "
+                      "where kernel_name like '%k_nn_pruned%' and grid_size_y >= 8 group by kernel_name, grid_size_x, grid_size_y, workgroup_size_x, "
+                      "counter_name").fetchall()
+    shapes = {(r[0].split("(")[0].replace("void ", ""), r[1], r[2], r[3]) for r in rows}
+    assert len(shapes) == 1, f"{dbfile}: expected exactly one batch instantiation of k_nn_pruned, found {shapes}"
+    assert shape in (None, next(iter(shapes))), (shape, shapes)
+    shape = next(iter(shapes))
+    for r in rows:
+        vals[r[4]] = (float(r[5]), int(r[6]))
+kernel, gx, gy, wg = shape
+out = {"kernel": kernel, "grid": [gx, gy, 1], "workgroup": wg, "points": points, "pairs_per_launch": gy, "kind": kind, "nn_mode": "pruned",
+       "source": "profiles/pmc_nn_latest.json (tools/pmc_nn_json.py over the rocprofv3 --pmc passes of tools/refresh_evidence.sh)",
+       "dispatches": {k: v[1] for k, v in vals.items()}}
+for k, v in vals.items():
+    out[k] = v[0]
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    out["hbm_bytes_per_launch"] = int(round((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024))
+    out["hbm_note"] = "2 x FETCH_SIZE (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> bytes"
+json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out))

@@ -1,17 +1,34 @@
 #!/bin/bash
-# Regenerates the judged evidence on the GPU box: kernel stats, the two PMC passes, roofline traffic, and the bench line.
-# usage: gpurun -- 'bash tools/refresh_evidence.sh'; then copy gpurun_out/ev/* into profiles/ (named per round)
+# Regenerates the judged evidence on the GPU box into gpurun_out/ev/ (copy the *.md / *.json you want judged into profiles/,
+# named per round).   usage: gpurun -- 'bash tools/refresh_evidence.sh r02'
+#   kernel_stats.md      rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
+#   bench_profiled.json  the JSON line printed by that same profiled run (its roofline.avg_launch_ms must agree with the table)
+#   pmc_*.md             separate --pmc passes (never combined with other trace domains): HBM bytes and the issue-side SQ counters
+#   pmc_nn_latest.json   per-launch PMC numbers of the batch's nearest-neighbour launches (bench.py's roofline.traffic / roofline_issue)
+#   bench.json           the un-profiled default run
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ev
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ev/ks -o k -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics > gpurun_out/ev/ks.log 2>&1
-python3 tools/rocpd_summary.py $(find gpurun_out/ev/ks -name "*.db" | head -1) "round 1 (final): python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics under rocprofv3 --kernel-trace --stats" > gpurun_out/ev/kernel_stats.md
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/ev/pf -o k -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics > gpurun_out/ev/pf.log 2>&1
-python3 tools/rocpd_summary.py $(find gpurun_out/ev/pf -name "*.db" | head -1) "round 1 (final) PMC pass 1: FETCH_SIZE (KB per dispatch; double it on gfx950 for wide coalesced reads)" > gpurun_out/ev/pmc_fetch_size.md
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/ev/pw -o k -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics > gpurun_out/ev/pw.log 2>&1
-python3 tools/rocpd_summary.py $(find gpurun_out/ev/pw -name "*.db" | head -1) "round 1 (final) PMC pass 2: WRITE_SIZE (KB per dispatch)" > gpurun_out/ev/pmc_write_size.md
-python3 tools/pmc_nn_json.py $(find gpurun_out/ev/pf -name "*.db" | head -1) $(find gpurun_out/ev/pw -name "*.db" | head -1) gpurun_out/ev/pmc_nn_latest.json
-cp gpurun_out/ev/pmc_nn_latest.json profiles/pmc_nn_latest.json
-timeout 600 python3 bench.py > gpurun_out/ev/bench.json 2> gpurun_out/ev/bench.err
-head -c 900 gpurun_out/ev/bench.json; echo
-head -14 gpurun_out/ev/kernel_stats.md; grep -i "FETCH_SIZE\|WRITE_SIZE" gpurun_out/ev/pmc_fetch_size.md gpurun_out/ev/pmc_write_size.md | grep "nn_pruned\|knn_cov\|linearize"
-rm -rf gpurun_out/ev/ks gpurun_out/ev/pf gpurun_out/ev/pw
+ev=gpurun_out/ev; mkdir -p $ev
+DRV="python3 bench.py --gpus 1 --steps 20 --warmup 5"
+PMC="python3 bench.py --gpus 1 --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-diagnostics"
+timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks -o k -- $DRV --no-cpu-baseline > $ev/bench_profiled.json 2> $ev/ks.err
+python3 tools/rocpd_summary.py $(find $ev/ks -name "*.db" | head -1) "$tag: '$DRV --no-cpu-baseline' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats.md
+pass() {  # name, counters...
+  name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $ev/p_$name -o k -- $PMC > $ev/p_$name.log 2>&1
+  db=$(find $ev/p_$name -name "*.db" | head -1)
+  if [ -n "$db" ]; then python3 tools/rocpd_summary.py $db "$tag PMC pass '$name': $* ('$PMC')" > $ev/pmc_$name.md; else echo "pass $name produced no db"; tail -5 $ev/p_$name.log; fi
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+pass busy SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT
+pass occ GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64
+dbs=$(for n in fetch write insts busy; do find $ev/p_$n -name "*.db" | head -1; done)
+python3 tools/pmc_nn_json.py $ev/pmc_nn_latest.json 8192 odometry $dbs > /dev/null && cp $ev/pmc_nn_latest.json profiles/pmc_nn_latest.json
+timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
+for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ; do rm -rf $d; done
+find $ev/ks -type f ! -name "*.db" -delete
+head -c 1500 $ev/bench.json; echo
+head -14 $ev/kernel_stats.md
+for n in fetch write insts busy occ; do echo "== $n"; grep "k_nn_pruned\|knn_cov_coop\|k_linearize\|^| kernel" $ev/pmc_$n.md | head -8; done
