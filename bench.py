@@ -350,6 +350,7 @@ def main():
                 executed = chunks_scanned * 16 * 64 * 8.0          # x 64 lanes (queries) x 8 flop
                 out["nn_work"] = {"executed_distance_flops_per_launch": executed, "bruteforce_flops_per_launch": flops_alg,
                                   "executed_share_of_bruteforce": round(executed / flops_alg, 5),
+                                  "points_that_kept_their_neighbour_share": round(float(st[6]) / max(1.0, float(st[3]) * 64.0), 4),
                                   "executed_TFLOPs": round(executed / (avg_nn_ms * 1e-3) / 1e12, 2),
                                   "bruteforce_equivalent_TFLOPs": round(flops_alg / (avg_nn_ms * 1e-3) / 1e12, 1),
                                   "note": "the pruned search returns the brute-force result bit for bit; bruteforce_equivalent is NOT a hardware "

@@ -248,7 +248,7 @@ int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* l
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
 /* pruning diagnostics, collected only when the environment has APDGICP_STATS=1 (else zeros); reading
  * resets them.  [0..3] nearest neighbour: groups scanned, chunks tested, chunks scanned, waves;
- * [4..9] covariance k-NN: groups loaded, (NN: batches of 64 group boxes visited), -, waves sampled, list tightenings, (query, group) steps;
+ * [4..9] covariance k-NN: groups loaded, (NN: batches of 64 group boxes visited), (NN: points that kept their neighbour without a search), waves sampled, list tightenings, (query, group) steps;
  * [10..15] sampled phase timers (s_memtime ticks) of whichever of the two kernels ran last (tools/prune_stats.py, tools/knn_time.py) */
 int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]);
 

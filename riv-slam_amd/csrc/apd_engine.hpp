@@ -184,12 +184,18 @@ class Engine {
   CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_active;
   std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
   bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
-  DevBuf b_nnpart, b_corr, b_nnpt, b_sqd, b_maha, b_blkpart, b_errpart;
+  DevBuf b_nnpart, b_corr, b_nnpt, b_nnaux, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
   int nn_S = 2;
   int nn_W = 0;  // waves per block of k_nn_pruned<1, W> sharing the same 64 points (APDGICP_NN_W = 1, 2, 4; 0: by load)
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
   bool nn_gate_cap = true; // optimiser ticks stop the search at the correspondence gate (APDGICP_NN_GATE_CAP=0: unbounded)
+  // Neighbour keeping (nn_warm_start): a full search prunes with the squared radius r^2 (1 + skin_rel)^2 + skin_abs^2 instead of
+  // r^2, which buys later iterations the right to keep the neighbour without searching while the point has moved by less than
+  // the margin (APDGICP_NN_SKIN=0 disables; APDGICP_NN_SKIN_REL / _ABS in metres override)
+  bool nn_skin = true;
+  float nn_skin_rel = 0.25f, nn_skin_abs = 0.02f;
+  bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
   bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
@@ -282,6 +288,10 @@ class Engine {
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
+    nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
+    nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
+    if (const char* v = getenv("APDGICP_NN_SKIN_REL")) nn_skin_rel = std::max(0.f, (float)atof(v));
+    if (const char* v = getenv("APDGICP_NN_SKIN_ABS")) nn_skin_abs = std::max(0.f, (float)atof(v));
     sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
     // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
     // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
@@ -307,7 +317,7 @@ class Engine {
     for (auto& c : clouds) c.release_all();
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_active}) t->dev.release();
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
-                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (h_poll) e = hipHostFree(h_poll);
     if (alt.h_poll) e = hipHostFree(alt.h_poll);
@@ -736,6 +746,7 @@ class Engine {
     APD_TRY(b_nnpart.ensure((size_t)npairs * T * ns * 8));
     APD_TRY(b_corr.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_nnpt.ensure((size_t)npairs * ns * 16));
+    APD_TRY(b_nnaux.ensure((size_t)npairs * ns * 16));
     APD_TRY(b_sqd.ensure((size_t)npairs * ns * 4));
     APD_TRY(b_maha.ensure((size_t)npairs * 6 * ns * 8));
     APD_TRY(b_blkpart.ensure((size_t)npairs * work.nblk_max * kRed * 8));
@@ -744,6 +755,9 @@ class Engine {
     const bool keep_point_results = keep_maha || params.optimizer == APDGICP_OPT_LM;  // see keep_maha
     work.corr = keep_point_results ? b_corr.as<int>() : nullptr;
     work.nnpt = b_nnpt.as<float4>();
+    work.nnaux = nn_skin && nn_pruned ? b_nnaux.as<float4>() : nullptr;
+    work.skin_mul = (1.f + nn_skin_rel) * (1.f + nn_skin_rel);
+    work.skin_add = nn_skin_abs * nn_skin_abs;
     work.sqd = keep_point_results ? b_sqd.as<float>() : nullptr;
     work.maha = (keep_maha || params.optimizer == APDGICP_OPT_LM) ? b_maha.as<double>() : nullptr;
     work.blkpart = b_blkpart.as<double>();
@@ -765,7 +779,7 @@ class Engine {
 
   int launch_nn(Span sp) {
     const int src_blocks = nn_pruned ? (nmax_src + 64 * nn_S - 1) / (64 * nn_S) : (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
-    const dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)work.T, nn_pruned ? 1u : (unsigned)sp.np);
+    dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)work.T, nn_pruned ? 1u : (unsigned)sp.np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = profile_nn && ((cur_tick + profile_phase) % profile_stride == 0);
     if (timed) {
@@ -796,7 +810,12 @@ class Engine {
     // this launch, and one wave per 64 points does no redundant bound work (three handles in flight: 1.32 -> 1.27 ms per step)
     const int w_full = max_groups == 1 ? 1 : 2;
     const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
-    if (nn_pruned) {
+    // throughput regime (one wave per 64 points) with neighbour keeping on: blocks of 256 points that pack the points still
+    // searching into as few waves as they fill (k_nn_compact)
+    if (nn_pruned && nn_S == 1 && W == 1 && work.nnaux && nn_compact) {
+      grid.x = (unsigned)((nmax_src + 255) / 256);
+      APD_NN_LAUNCH(k_nn_compact<4>, 256);
+    } else if (nn_pruned) {
       if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
       else if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
       else if (nn_S == 1 && W == 2) APD_NN_LAUNCH((k_nn_pruned<1, 2>), 128);

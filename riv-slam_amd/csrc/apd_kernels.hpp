@@ -72,6 +72,9 @@ constexpr int kRed = 32;        // doubles per block partial: 21 H + 6 b + cost 
 constexpr int kChunk = 16;      // NN index granularity: the winner is located inside a 16-target chunk
 constexpr unsigned kNoChunk = 0xFFFFFFFFu;
 constexpr unsigned kTieBit = 0x80000000u;  // set in a chunk id when the minimum was reached in more than one chunk
+constexpr unsigned kKeptBit = 0x40000000u; // set in a chunk id when the search PROVED that the previous neighbour (Work::nnpt) is still the
+                                           // unique nearest neighbour: k_linearize takes index and point from there, no re-scan of the chunk
+constexpr unsigned kChunkMask = ~(kTieBit | kKeptBit);
 
 struct Work {
   unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
@@ -79,6 +82,12 @@ struct Work {
   float4* nnpt;                // [pair][nstride]   nearest neighbour found by the previous linearize, ungated: its coordinates and, in
                                //                   .w, the bits of its sorted index (-1: none) -- one coalesced load instead of index + gather:
                                //                   a warm start for the pruned search, never an input of the result
+  float4* nnaux;               // [pair][nstride]   {transformed point, s} at the point's last FULL search: every target other than the
+                               //                   neighbour found then was at a computed squared distance >= s.  While the pose moves the
+                               //                   point by less than the gap between s and the neighbour, the neighbour cannot change and
+                               //                   the search is skipped for this point (see nn_search); s = 0: no such knowledge
+  float skin_mul, skin_add;    // a full search prunes with the radius best * skin_mul + skin_add instead of best, so that s exceeds the
+                               // neighbour distance by a margin (skin_mul = 1, skin_add = 0: off)
   float* sqd;                  // [pair][nstride]   sq_distances_ (A:153)
   double* maha;                // [pair][6][nstride] mahalanobis_ upper triangle (A:191)
   double* blkpart;             // [pair][nblk_max][kRed]
@@ -533,12 +542,75 @@ constexpr int GB_BATCH = 64;   // group boxes staged per LDS batch (1.5 KB): sma
 // during an optimiser tick that is the better trade.  txy/tz/cbl: this wave's tile; gbl: shared by the block.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }  // same-wave LDS write -> read
 
-template <int S, int W>
+// Warm start of ONE point of a search, shared by k_nn_pruned and k_nn_compact.
+//
+// The neighbour found by the previous iteration is a real target point, so its distance at the new pose is a valid upper
+// bound of the minimum and makes the pruning effective from the first group on.  It only changes which chunks are visited,
+// never the result.
+//
+// Keeping a neighbour without searching.  A full search leaves behind, per point, the transformed point p0 it ran for and a
+// bound s: every target other than the neighbour q it found had a computed squared distance >= s at p0 (the second smallest
+// distance among the scanned targets, and everything it never scanned lies beyond its pruning radius, which was inflated
+// by the skin: r^2 -> r^2 * skin_mul + skin_add).  At a later pose the point sits at p1.  With eps bounding the relative
+// rounding error of the fp32 distance (5 roundings of non-negative terms: < 3.1e-7) and |p1 - p0| its displacement,
+//     D(t, p1) >= (sqrt(s) (1 - eps) - |p1 - p0|)^2 (1 - eps)      for every target t != q,
+// so when that exceeds D(q, p1) -- evaluated directly -- q is still the unique nearest neighbour, bit for bit what the
+// full search would return, and the point takes no part in the search.  (A point without any target inside the cap keeps
+// that status the same way, with the cap in place of D(q, p1).)  The test evaluates the inequality with 4e-6 of slack on
+// every factor.
+struct NNStart {
+  float px, py, pz, best;
+  unsigned bestc;
+  bool kept, hinted;
+};
+__device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, const float* Tf, const Work& w, int pair, int ii, bool cold, bool skin_on) {
+  const float inf = __builtin_inff();
+  NNStart o;
+  const float4 p = src.pts[ii];
+  o.px = xf_row(Tf + 0, p.x, p.y, p.z), o.py = xf_row(Tf + 4, p.x, p.y, p.z), o.pz = xf_row(Tf + 8, p.x, p.y, p.z);
+  o.best = w.cap, o.bestc = kNoChunk, o.kept = false;
+  const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
+  const int hint = cold ? -1 : __float_as_int(t.w);
+  float dq = w.cap;  // distance to the previous neighbour at this pose (the cap when there was none inside it)
+  o.hinted = hint >= 0 && hint < M;
+  if (o.hinted) {
+    dq = sqdist1(t.x, t.y, t.z, o.px, o.py, o.pz);
+    if (dq < o.best) o.best = dq, o.bestc = (unsigned)(hint / kChunk);
+  }
+  if (skin_on) {
+    const float4 a = w.nnaux[(size_t)pair * w.nstride + ii];
+    const float mv = sqrtf(sqdist1(a.x, a.y, a.z, o.px, o.py, o.pz));
+    const float lo = sqrtf(a.w) * (1.f - 4e-6f) - mv * (1.f + 4e-6f);
+    // The record describes the targets OTHER than the neighbour on record, so it is only usable while that neighbour is
+    // the one k_linearize last wrote: a neighbour that has left the cap (k_linearize then records "none") takes the full
+    // search.  hint == -1 with a.w > 0: the last full search found no target inside the cap, and s covers every target.
+    const bool ok = a.w > 0.f && lo > 0.f && lo * lo * (1.f - 4e-6f) > fminf(dq, w.cap) * (1.f + 4e-6f) && (o.hinted ? dq < w.cap : hint == -1) &&
+                    w.cap < inf;
+    if (ok) {
+      o.kept = true;
+      if (o.hinted) o.best = dq, o.bestc = (unsigned)(hint / kChunk) | kKeptBit;
+      else o.best = w.cap, o.bestc = kNoChunk;
+    }
+  }
+  return o;
+}
+
+// OWN = false: the classic form -- the W waves of the block share the points [base, base + 64 S) and warm-start them here.
+// OWN = true (k_nn_compact, W == 1): the wave was handed its points by the caller -- px/py/pz/best/bestc/kept/hinted_in are
+// inputs, pidx[s] is the index of the point a lane works for (-1: none; such a lane must come in with kept = true) -- and owns
+// ALL of its LDS (gbl included), so nothing here synchronises with the other waves of the block.
+template <int S, int W, bool OWN = false>
 __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T0, const Work& w, int pair, int base, int lane,
                                           int wid, bool cold, float4* txy, float2* tz, float* cbl, float* gbl, unsigned long long* mrg /* [W][64*S] */,
-                                          float (&px)[S], float (&py)[S], float (&pz)[S], float (&best)[S], unsigned (&bestc)[S]) {
+                                          float2* mrg2 /* [W][64*S] */, float (&px)[S], float (&py)[S], float (&pz)[S], float (&best)[S],
+                                          unsigned (&bestc)[S], int (&pidx)[S], bool (&kept)[S], bool hinted_in = true) {
+  static_assert(!OWN || W == 1, "a wave that owns its points shares nothing with the block");
   const int N = src.n, M = tgt.n;
   const int tid = wid * 64 + lane;
+  auto block_sync = [&]() {
+    if (OWN) wave_lds_fence();
+    else __syncthreads();
+  };
   const bool tstat = w.stats && wid == 0 && (blockIdx.x & 15) == 0;  // phase timing: sampled waves only
   long long tcy[4] = {0, 0, 0, 0}, tm = tstat ? clock64() : 0;
   float Tf[12];
@@ -555,24 +627,37 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   }
   const float inf = __builtin_inff();
 
-  // Warm start: the neighbour found by the previous iteration is a real target point, so its
-  // distance at the new pose is a valid upper bound of the minimum and makes the pruning effective
-  // from the first group on.  It only changes which chunks are visited, never the result.
-  bool all_hinted = true;
+  bool all_hinted = hinted_in;
+  float bestR[S], sk_mul[S], sk_add[S];   // pruning radius of the point and how it follows `best` (kept points: always -1)
+  float g1[S], g2[S];                     // smallest and second smallest computed distance among the SCANNED targets
+  const bool skin_on = !cold && w.nnaux != nullptr && w.skin_mul > 0.f;
+  const float k_mul = skin_on ? w.skin_mul : 1.f, k_add = skin_on ? w.skin_add : 0.f;
 #pragma unroll
   for (int s = 0; s < S; s++) {
-    const int i = base + s * 64 + lane;
-    const int ii = i < N ? i : N - 1;
-    const float4 p = src.pts[ii];
-    px[s] = xf_row(Tf + 0, p.x, p.y, p.z), py[s] = xf_row(Tf + 4, p.x, p.y, p.z), pz[s] = xf_row(Tf + 8, p.x, p.y, p.z);
-    best[s] = w.cap, bestc[s] = kNoChunk;
-    const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
-    const int hint = cold ? -1 : __float_as_int(t.w);
-    if (hint >= 0 && hint < M) {
-      const float d = sqdist1(t.x, t.y, t.z, px[s], py[s], pz[s]);
-      if (d < best[s]) best[s] = d, bestc[s] = (unsigned)(hint / kChunk);
-    } else {
-      all_hinted = false;
+    if (!OWN) {
+      const int i = base + s * 64 + lane;
+      pidx[s] = i < N ? i : -1;
+      const NNStart st = nn_warm_start(src, M, Tf, w, pair, i < N ? i : N - 1, cold, skin_on);
+      px[s] = st.px, py[s] = st.py, pz[s] = st.pz, best[s] = st.best, bestc[s] = st.bestc, kept[s] = st.kept;
+      all_hinted &= st.hinted;
+    }
+    g1[s] = inf, g2[s] = inf;
+    sk_mul[s] = kept[s] ? 0.f : k_mul, sk_add[s] = kept[s] ? -1.f : k_add;
+    bestR[s] = kept[s] ? -1.f : fmaf(best[s], sk_mul[s], sk_add[s]);
+  }
+  if (!OWN) {
+    bool allk = true;
+#pragma unroll
+    for (int s = 0; s < S; s++) allk &= kept[s];
+    if (__all(allk)) {  // (the W waves of a block hold the same points: they all leave here, or none does)
+      if (w.stats && tid == 0) atomicAdd(w.stats + 3, 1ull), atomicAdd(w.stats + 6, 64ull * S);
+      return;
+    }
+    if (w.stats && wid == 0) {
+      unsigned long long nk = 0;
+#pragma unroll
+      for (int s = 0; s < S; s++) nk += __popcll(__ballot(kept[s]));
+      if (lane == 0) atomicAdd(w.stats + 6, nk);
     }
   }
   // seeded cold start only when (almost) nobody has a hint; a few lanes without one (no target inside the cap last
@@ -581,9 +666,10 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   // bounding box of this wave's (transformed) points
   Box wbox;
   {
-    float lx = px[0], ly = py[0], lz = pz[0], hx = px[0], hy = py[0], hz = pz[0];
+    float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;  // (points that kept their neighbour need nothing)
 #pragma unroll
-    for (int s = 1; s < S; s++) {
+    for (int s = 0; s < S; s++) {
+      if (kept[s]) continue;
       lx = fminf(lx, px[s]), ly = fminf(ly, py[s]), lz = fminf(lz, pz[s]);
       hx = fmaxf(hx, px[s]), hy = fmaxf(hy, py[s]), hz = fmaxf(hz, pz[s]);
     }
@@ -615,7 +701,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   auto lane_needs = [&](const Box& bx) {
     bool need = false;
 #pragma unroll
-    for (int s = 0; s < S; s++) need |= lb_point_box(bx, px[s], py[s], pz[s]) <= best[s];
+    for (int s = 0; s < S; s++) need |= lb_point_box(bx, px[s], py[s], pz[s]) <= bestR[s];
     return need;
   };
   auto scan_tile = [&](int g) {
@@ -632,9 +718,9 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       const int ch = __builtin_ctz(cmask);
       cmask &= cmask - 1;
       n_cscan++;
-      float m[S];
+      float m[S], m2[S];  // smallest / second smallest distance of this chunk (v_min3 + v_med3 + v_min per two targets)
 #pragma unroll
-      for (int s = 0; s < S; s++) m[s] = inf;
+      for (int s = 0; s < S; s++) m[s] = inf, m2[s] = inf;
 #pragma unroll
       for (int jj = 0; jj < kChunk / 2; jj++) {
         const float4 A = txy[ch * (kChunk / 2) + jj];
@@ -643,14 +729,17 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         for (int s = 0; s < S; s++) {
           const float d0 = sqdist1(A.x, A.z, Z.x, px[s], py[s], pz[s]);
           const float d1 = sqdist1(A.y, A.w, Z.y, px[s], py[s], pz[s]);
+          m2[s] = fminf(m2[s], __builtin_amdgcn_fmed3f(m[s], d0, d1));
           m[s] = fminf(fminf(m[s], d0), d1);
         }
       }
       const unsigned c = (unsigned)(g * kGroupChunks + ch);
 #pragma unroll
       for (int s = 0; s < S; s++) {
-        if (m[s] < best[s]) best[s] = m[s], bestc[s] = c;
-        else if (m[s] == best[s] && m[s] < inf && (bestc[s] & ~kTieBit) != c) bestc[s] |= kTieBit;
+        g2[s] = fminf(fmaxf(g1[s], m[s]), fminf(g2[s], m2[s]));
+        g1[s] = fminf(g1[s], m[s]);
+        if (m[s] < best[s]) best[s] = m[s], bestc[s] = c, bestR[s] = fmaf(m[s], sk_mul[s], sk_add[s]);
+        else if (m[s] == best[s] && m[s] < inf && (bestc[s] & kChunkMask) != c) bestc[s] |= kTieBit;
       }
     }
   };
@@ -661,9 +750,9 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   static_assert(GB_BATCH == kSuperGroups, "one batch of group boxes per super box");
   const bool use_super = M > SORT_LDS_MAX_N;
   const int nsuper = (ngroups + GB_BATCH - 1) / GB_BATCH;
-  float rad0 = best[0];
+  float rad0 = bestR[0];
 #pragma unroll
-  for (int s = 1; s < S; s++) rad0 = fmaxf(rad0, best[s]);
+  for (int s = 1; s < S; s++) rad0 = fmaxf(rad0, bestR[s]);
   rad0 = wave_minmax_uniform<true>(rad0);
   for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
   unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
@@ -676,14 +765,14 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     smask &= smask - 1;
     const int nbb = min(GB_BATCH, ngroups - gb0);
     n_batches++;
-    __syncthreads();  // uniform over the block's waves (the batch loop is): nobody still reads the previous batch
+    block_sync();  // uniform over the block's waves (the batch loop is): nobody still reads the previous batch
     if (gb0 == 0) {
 #pragma unroll
       for (int u = 0; u < NPRE; u++)
         if (u * 64 * W + tid < 6 * 64) gbl[u * 64 * W + tid] = gpre[u];
     }
     for (int e = (gb0 == 0 ? 6 * 64 : 0) + tid; e < 6 * nbb; e += 64 * W) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
-    __syncthreads();
+    block_sync();
     for (int sb = 0; sb < nbb; sb += 64) {  // 64 groups at a time: their need bits fit one mask
       const int nb = min(64, nbb - sb);
       const float* boxes = gbl + 6 * sb;
@@ -710,9 +799,9 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       // `best` just before its scan.  First one test per LANE: group `lane` against the box of all points of
       // this wave with the wave's largest radius (a lower bound of every per-point bound, so it only removes
       // groups no lane needs); the per-point tests then run on the few survivors, 4 per trip.
-      float rad = best[0];
+      float rad = bestR[0];
 #pragma unroll
-      for (int s = 1; s < S; s++) rad = fmaxf(rad, best[s]);
+      for (int s = 1; s < S; s++) rad = fmaxf(rad, bestR[s]);
       rad = wave_minmax_uniform<true>(rad);
       unsigned long long pre = nb < 64 ? (1ull << nb) - 1ull : ~0ull;
       if (rad < inf) pre &= __ballot(lb_box_box(wbox, lds_box(boxes, min(lane, nb - 1))) <= rad);
@@ -758,12 +847,16 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   }
   if (W > 1) {  // merge the waves' partial minima: smallest distance; the same minimum in two different chunks is a tie
 #pragma unroll
-    for (int s = 0; s < S; s++) mrg[(wid * S + s) * 64 + lane] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
+    for (int s = 0; s < S; s++) {
+      mrg[(wid * S + s) * 64 + lane] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
+      mrg2[(wid * S + s) * 64 + lane] = make_float2(g1[s], g2[s]);
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < S; s++) {
       float bb = __uint_as_float((unsigned)(mrg[s * 64 + lane] >> 32));
       unsigned cc = (unsigned)mrg[s * 64 + lane];
+      float a1 = mrg2[s * 64 + lane].x, a2 = mrg2[s * 64 + lane].y;
 #pragma unroll
       for (int o = 1; o < W; o++) {
         const unsigned long long v = mrg[(o * S + s) * 64 + lane];
@@ -772,11 +865,32 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         if (bo < bb) {
           bb = bo, cc = co;
         } else if (bo == bb && bo < inf) {
-          if ((co & ~kTieBit) != (cc & ~kTieBit)) cc |= kTieBit;
+          if ((co & kChunkMask) != (cc & kChunkMask)) cc |= kTieBit;
           cc |= co & kTieBit;
         }
+        const float2 gg = mrg2[(o * S + s) * 64 + lane];  // the waves scanned disjoint sets of targets
+        a2 = fminf(fmaxf(a1, gg.x), fminf(a2, gg.y));
+        a1 = fminf(a1, gg.x);
       }
       best[s] = bb, bestc[s] = cc;
+      g1[s] = a1, g2[s] = a2;
+    }
+  }
+  // what this search leaves behind for the next one (points that kept their neighbour keep their old record)
+  if (w.nnaux && wid == 0) {
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const int i = pidx[s];
+      if (i < 0 || kept[s]) continue;
+      float sb = 0.f;
+      if (skin_on && !(bestc[s] & kTieBit) && bestc[s] != kNoChunk) {
+        // everything never scanned lies beyond the final pruning radius (radii only shrink); among the scanned targets the
+        // neighbour itself is g1 (if it is not, e.g. it was only ever seen as the hint, nothing is claimed)
+        if (g1[s] == best[s]) sb = fminf(g2[s], fmaf(best[s], k_mul, k_add));
+      } else if (skin_on && bestc[s] == kNoChunk) {
+        sb = fminf(g1[s], fmaf(best[s], k_mul, k_add));  // no target inside the cap: the nearest one seen, or the radius
+      }
+      w.nnaux[(size_t)pair * w.nstride + i] = make_float4(px[s], py[s], pz[s], sb);
     }
   }
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
@@ -794,6 +908,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   __shared__ float cbl[W][6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
   __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
+  __shared__ float2 mrg2[W > 1 ? W * 64 * S : 1];
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
@@ -808,7 +923,9 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   if (base >= N) return;
   float px[S], py[S], pz[S], best[S];
   unsigned bestc[S];
-  nn_search<S, W>(src, tgt, T0, w, pair, base, lane, wid, cold, txy[wid], tz[wid], cbl[wid], gbl, mrg, px, py, pz, best, bestc);
+  int pidx[S];
+  bool kept[S];
+  nn_search<S, W>(src, tgt, T0, w, pair, base, lane, wid, cold, txy[wid], tz[wid], cbl[wid], gbl, mrg, mrg2, px, py, pz, best, bestc, pidx, kept);
   if (wid != 0) return;
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
 #pragma unroll
@@ -816,6 +933,75 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
     const int i = base + s * 64 + lane;
     if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
   }
+}
+
+// k_nn_compact: the same search for optimiser ticks in which many points keep their neighbour (nn_warm_start).  A wave pays
+// for a chunk scan whether one of its lanes needs it or all 64 do, so kept points scattered over the waves save little.
+// Here a block of W waves warm-starts 64 W consecutive points, writes the results of the kept ones, packs the others into
+// as few waves as they fill (still consecutive on the curve, i.e. compact) and only those waves search -- each on its own,
+// with its own LDS, exactly like a one-wave block of k_nn_pruned.  Which wave searches for a point never changes a result.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  __shared__ float4 txy[W][kGroupPts / 2];
+  __shared__ float2 tz[W][kGroupPts / 2];
+  __shared__ float cbl[W][6 * kGroupChunks];
+  __shared__ float gbl[W][6 * GB_BATCH];
+  __shared__ float4 cpt[64 * W];  // packed points: transformed position, best
+  __shared__ int2 cci[64 * W];    // (chunk of the hint | kNoChunk, point index | bit 30: no hint)
+  __shared__ int wcnt[W];
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const int pair = pair_of(w, by);
+  const int status = st[pair].status;
+  const bool cold = st[pair].n_lin == 0;
+  const PairDesc pd = pairs[pair];
+  const Rigid T0 = st[pair].x0;
+  if (status != ST_NEED_LIN) return;
+  const CloudDesc src = pd.s, tgt = pd.t;
+  const int N = src.n, M = tgt.n, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int base = (int)bx * (64 * W);
+  if (base >= N) return;
+  const int i = base + tid;
+  const bool valid = i < N;
+  const bool skin_on = !cold && w.nnaux != nullptr && w.skin_mul > 0.f;
+  float Tf[12];
+  load_Tf(T0, Tf);
+  const NNStart s0 = nn_warm_start(src, M, Tf, w, pair, valid ? i : N - 1, cold, skin_on);
+  unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
+  if (valid && s0.kept) out[i] = ((unsigned long long)__float_as_uint(s0.best) << 32) | s0.bestc;
+  const bool active = valid && !s0.kept;
+  const unsigned long long am = __ballot(active);
+  if (lane == 0) wcnt[wid] = __popcll(am);
+  __syncthreads();
+  int off = 0, total = 0;
+#pragma unroll
+  for (int o = 0; o < W; o++) {
+    const int c = wcnt[o];
+    off += o < wid ? c : 0;
+    total += c;
+  }
+  if (active) {
+    const int pos = off + __popcll(am & ((1ull << lane) - 1ull));
+    cpt[pos] = make_float4(s0.px, s0.py, s0.pz, s0.best);
+    cci[pos] = make_int2((int)s0.bestc, i | (s0.hinted ? 0 : 1 << 30));
+  }
+  __syncthreads();
+  if (w.stats && lane == 0) atomicAdd(w.stats + 6, (unsigned long long)__popcll(__ballot(valid && s0.kept)));
+  if (wid * 64 >= total) {  // nothing left for this wave
+    if (w.stats && lane == 0) atomicAdd(w.stats + 3, 1ull);
+    return;
+  }
+  const int e = wid * 64 + lane;
+  const bool has = e < total;
+  const float4 cp = cpt[has ? e : total - 1];
+  const int2 ci = cci[has ? e : total - 1];
+  float px[1] = {cp.x}, py[1] = {cp.y}, pz[1] = {cp.z}, best[1] = {cp.w};
+  unsigned bestc[1] = {(unsigned)ci.x};
+  int pidx[1] = {has ? (ci.y & ~(1 << 30)) : -1};
+  bool kept[1] = {!has};
+  nn_search<1, 1, true>(src, tgt, T0, w, pair, 0, lane, 0, cold, txy[wid], tz[wid], cbl[wid], gbl[wid], nullptr, nullptr, px, py, pz, best, bestc, pidx,
+                        kept, !has || (ci.y & (1 << 30)) == 0);
+  if (has) out[pidx[0]] = ((unsigned long long)__float_as_uint(best[0]) << 32) | bestc[0];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1484,11 +1670,14 @@ __device__ __forceinline__ void block_reduce_lds(const double* v, double* lds /*
 // acc[29] receives this point's contribution (zero when it has no correspondence).
 __device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
                                                 int want_Hb, int pair, int i, const float4 p, float ptx, float pty, float ptz, float m,
-                                                unsigned chunk, bool tie, double* acc) {
+                                                unsigned chunk, bool tie, bool kept, double* acc) {
   const int N = src.n, M = tgt.n;
   int j = -1;
   float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);  // the neighbour itself
-  if (chunk != kNoChunk) {
+  if (kept) {  // the search proved the previous neighbour still is the nearest one (kKeptBit): index and point are on record
+    tq = w.nnpt[(size_t)pair * w.nstride + i];
+    j = __float_as_int(tq.w);
+  } else if (chunk != kNoChunk) {
     // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
     int jorig = 0x7fffffff;
     if (!tie) {
@@ -1517,7 +1706,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     }
   }
   if (w.sqd) w.sqd[(size_t)pair * w.nstride + i] = m;  // (sqd, corr: null in a Gauss-Newton batch, like maha)
-  w.nnpt[(size_t)pair * w.nstride + i] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+  if (!kept) w.nnpt[(size_t)pair * w.nstride + i] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
   const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
   if (w.corr) w.corr[(size_t)pair * w.nstride + i] = corr;
   if (corr >= 0) {
@@ -1691,15 +1880,17 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     }
     const float m = __uint_as_float((unsigned)(bestp >> 32));
     unsigned chunk = (unsigned)bestp;
+    bool kept = false;
     if (chunk != kNoChunk) {
       tie |= (chunk & kTieBit) != 0;
-      chunk &= ~kTieBit;
+      kept = (chunk & kKeptBit) != 0 && !tie;
+      chunk &= kChunkMask;
     }
     float Tf[12];
     load_Tf(T, Tf);
     const float4 p = src.pts[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
-    linearize_point(src, tgt, T, w, cst, want_Hb, pair, i, p, ptx, pty, ptz, m, chunk, tie, acc);
+    linearize_point(src, tgt, T, w, cst, want_Hb, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, acc);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
   block_reduce_lds<29, LIN_BLK>(acc, red, red_scratch, tid);

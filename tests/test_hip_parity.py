@@ -663,6 +663,75 @@ def test_pruned_search_is_bitwise_the_brute_force_search(reg, scene):
         assert np.array_equal(Ta, Tb) and info_of(a) == info_of(b)
 
 
+def _handle_with_env(reg, cls, env, **kw):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return cls(reg.default_params(**kw))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("odometry", "loop"))
+def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
+    """Neighbour keeping (nn_search: a point whose previous neighbour is PROVEN to still be the nearest skips the search)
+    must not change a single bit: GN-20 and LM runs with the skin on (several settings), off, and with the brute-force
+    search; the counters must show that points really were kept."""
+    gn = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0,
+              azimuth_variance_deg=1.0)
+    lm = dict(max_correspondence_distance=2.0, transformation_epsilon=1e-4, azimuth_variance_deg=1.0)
+    clouds, pairs, guesses = [], [], []
+    for i in range(6):
+        n = (8192, 4100, 2048, 3000, 8192, 1500)[i]
+        s_, t_, _, g_ = scene.make_pair(n, n + 100 * i, scene.pair_seed(21, i), kind)
+        clouds += [s_, t_]
+        pairs.append((2 * i, 2 * i + 1))
+        guesses.append(g_)
+    envs = ({"APDGICP_NN_SKIN": "0"}, {}, {"APDGICP_NN_SKIN_REL": "0.5", "APDGICP_NN_SKIN_ABS": "0.05"},
+            {"APDGICP_NN_SKIN_REL": "0.0", "APDGICP_NN_SKIN_ABS": "0.0"}, {"APDGICP_NN_SKIN_REL": "0.02", "APDGICP_NN_SKIN_ABS": "0.001", "APDGICP_NN_W": "2"},
+            {"APDGICP_NN_W": "4"}, {"APDGICP_NN_MODE": "brute"},
+            # one pair group per handle = the throughput regime of bench.py: k_nn_compact (blocks of 256 points that pack the
+            # points still searching into fewer waves), and the same regime with one-wave blocks of k_nn_pruned
+            {"ONE_GROUP": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_COMPACT": "0"}, {"ONE_GROUP": "1", "APDGICP_NN_SKIN": "0"},
+            {"ONE_GROUP": "1", "APDGICP_NN_SKIN_REL": "0.3", "APDGICP_NN_SKIN_ABS": "0.03"})
+    for kw in (gn, lm):
+        want = None
+        for env in envs:
+            env = dict(env)
+            one_group = env.pop("ONE_GROUP", None)
+            b = _handle_with_env(reg, reg.BatchAPDGICP, dict(env, APDGICP_STATS="1"), **kw)
+            if one_group:
+                b.set_pair_groups(1)
+            b.set_clouds(0, clouds)
+            res = b.align(pairs, guesses)
+            st = b.debug_stats()
+            got = res.tobytes()
+            want = want or got
+            assert got == want, (env, kw is gn)
+            if env.get("APDGICP_NN_SKIN") == "0" or env.get("APDGICP_NN_MODE") == "brute":
+                assert st[6] == 0
+            elif kw is gn and "APDGICP_NN_SKIN_REL" not in env:
+                assert st[6] > 0.3 * 18 * sum(len(clouds[2 * i]) for i in range(6)), st   # most points, most iterations
+    # a single handle: correspondences, distances and H, b after the last linearize of an align are those of a cold search
+    s_, t_, _, g_ = scene.make_pair(8192, 8192, scene.pair_seed(21, 50), kind)
+    a = _handle_with_env(reg, reg.FastAPDGICP, {}, **gn)
+    z = _handle_with_env(reg, reg.FastAPDGICP, {"APDGICP_NN_SKIN": "0"}, **gn)
+    out = []
+    for h in (a, z):
+        h.setInputSource(s_), h.setInputTarget(t_)
+        T = h.align(g_)
+        c, q = h.correspondences()
+        out.append((T, c, q.view(np.uint32), h.mahalanobis(), h.getFinalHessian()))
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_register_sort_equals_lds_sort(reg, scene):
     """k_sort_cloud_reg<4|8|16> (keys in registers, shuffles, few barriers) must produce the permutation and the boxes of
     k_sort_cloud_lds: everything downstream -- covariances, correspondences, fp32 distances -- is bitwise the same."""

@@ -77,6 +77,8 @@ def test_bench_force_dist_prints_world_size_and_rccl_version():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "2", "--repeats", "3", "--pairs-per-gpu", "8",
                         "--points", "2048", "--no-cpu-baseline", "--no-diagnostics"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
     assert d["world_size"] == 1 and d["rccl_version"] and d["n_gpus"] == 1 and d["timing"]["repeats"] == 3
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["bound"] == "hbm"
