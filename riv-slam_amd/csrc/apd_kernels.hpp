@@ -1530,47 +1530,75 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   if (!valid) return;  // whole groups leave together: the butterflies below never see a missing partner
 
   // ---- C
+  // Every lane sorts its EPL entries with a fixed network (optimal ones for 3 / 6 / 12 keys: 3 / 12 / 39 compare-exchanges),
+  // the sorted sub-lists go back into the row, and the k neighbours come out of an L-way merge: per round one butterfly
+  // over the heads and, in the lane that held the winner, the next entry of its list (requested one round ahead).  A
+  // round used to scan all EPL register entries of every lane: 86 instructions against 20.
   unsigned long long e[EPL];
-  {
-    const unsigned long long* row = lst + slot * KQ_STRIDE;
+  unsigned long long* row = lst + slot * KQ_STRIDE;
 #pragma unroll
-    for (int t = 0; t < EPL; t++) {
-      const int a = sub + L * t;
-      e[t] = a < cnt ? row[a] : ~0ull;
+  for (int t = 0; t < EPL; t++) {
+    const int a = sub + L * t;
+    e[t] = a < cnt ? row[a] : ~0ull;
+  }
+  {
+    auto cx = [&](int a, int b) {
+      const unsigned long long x = e[a], y = e[b];
+      const bool lt = x < y;
+      e[a] = lt ? x : y, e[b] = lt ? y : x;
+    };
+    if constexpr (EPL == 3) {
+      cx(0, 2), cx(0, 1), cx(1, 2);
+    } else if constexpr (EPL == 6) {
+      cx(0, 5), cx(1, 3), cx(2, 4), cx(1, 2), cx(3, 4), cx(0, 3), cx(2, 5), cx(0, 1), cx(2, 3), cx(4, 5), cx(1, 2), cx(3, 4);
+    } else {
+      static_assert(EPL == 12, "sorting networks for 3, 6 and 12 entries per lane");
+      cx(0, 8), cx(1, 7), cx(2, 6), cx(3, 11), cx(4, 10), cx(5, 9), cx(0, 1), cx(2, 5), cx(3, 4), cx(6, 9), cx(7, 8), cx(10, 11), cx(0, 2);
+      cx(1, 6), cx(5, 10), cx(9, 11), cx(0, 3), cx(1, 2), cx(4, 6), cx(5, 7), cx(8, 11), cx(9, 10), cx(1, 4), cx(3, 5), cx(6, 8), cx(7, 10);
+      cx(1, 3), cx(2, 5), cx(6, 9), cx(8, 10), cx(2, 3), cx(4, 5), cx(6, 7), cx(8, 9), cx(4, 6), cx(5, 7), cx(3, 4), cx(5, 6), cx(7, 8);
     }
   }
-  // k rounds of selection in registers; the winners' indices go to LDS (the row is free: its keys are in e[])
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int* sel = (int*)(lst + slot * KQ_STRIDE);
-  {
-    unsigned long long lb = 0;  // keys below lb were taken in earlier rounds
-    for (int r = 0; r < k; r++) {
-      unsigned long long bk = ~0ull;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (every lane of the wave has read its entries)
+  unsigned long long* mine = row + sub * EPL;
 #pragma unroll
-      for (int t = 0; t < EPL; t++) {
-        const unsigned long long x = e[t];
-        if (x >= lb && x < bk) bk = x;
+  for (int t = 2; t < EPL; t++) mine[t] = e[t];  // (the first two stay in registers: head and next)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int mysel[KNN_NC / L];  // the neighbours of rank sub, sub + L, ...: the ones this lane gathers
+#pragma unroll
+  for (int t = 0; t < KNN_NC / L; t++) mysel[t] = i;
+  {
+    unsigned long long head = e[0], next = e[1];
+    int cpos = 1;  // position of `next` in this lane's list
+#pragma unroll
+    for (int t = 0; t < KNN_NC / L; t++) {
+#pragma unroll
+      for (int u = 0; u < L; u++) {
+        if (t * L + u < k) {  // (uniform)
+          unsigned long long bk = group_min_u64<L>(head);
+          if (bk == ~0ull) {
+            atomicExch(err_flag, 2);
+            bk = (unsigned long long)(unsigned)i;  // keeps the gathers in range
+          }
+          if (sub == u) mysel[t] = (int)(unsigned)bk;
+          if (head == bk) {  // keys are unique: one lane of the query
+            head = next;
+            cpos++;
+            next = cpos < EPL ? mine[cpos] : ~0ull;
+          }
+        }
       }
-      bk = group_min_u64<L>(bk);
-      if (bk == ~0ull) {
-        atomicExch(err_flag, 2);
-        bk = (unsigned long long)(unsigned)i;  // keeps the gathers in range
-      }
-      lb = bk + 1ull;
-      if (sub == 0) sel[r] = (int)(unsigned)bk;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // gathers: lane sub fetches the neighbours of rank sub, sub+L, ... -- all loads in flight together
   float4 nbv[KNN_NC / L];
 #pragma unroll
   for (int t = 0; t < KNN_NC / L; t++) {
     const int r = sub + L * t;
     nbv[t] = q;
-    if (r < k) nbv[t] = c.opts[sel[r]];
+    if (r < k) nbv[t] = c.opts[mysel[t]];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  float* nbl = (float*)(lst + slot * KQ_STRIDE);  // [rank][xyz], overwrites sel (already consumed)
+  float* nbl = (float*)row;  // [rank][xyz], overwrites the sorted lists (already consumed)
 #pragma unroll
   for (int t = 0; t < KNN_NC / L; t++) {
     const int r = sub + L * t;
