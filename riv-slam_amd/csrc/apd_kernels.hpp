@@ -1366,6 +1366,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   int idx_bits = 1;
   while ((1 << idx_bits) < n) idx_bits++;
   __syncthreads();
+  float tau_q = inf;  // (L == 4) the k-th smallest class minimum
   {
     float cmp[NCL];  // minima of the classes sub + L*m
 #pragma unroll
@@ -1380,9 +1381,69 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
         cmp[m] = fminf(cmp[m], j < n ? sqdist1(t.x, t.y, t.z, q.x, q.y, q.z) : inf);
       }
     }
+    if constexpr (L == 4) {
+      // Four lanes per query: the 32 class minima stay where they are, 8 per lane, and are sorted in place by a bitonic
+      // network over (lane, register) -- element sub * 8 + r; every merge starts with the mirror step i <-> i ^ (kk - 1), so
+      // all compare-exchanges are ascending -- 12 in-lane stages and 3 stages whose partner sits in another lane of the quad
+      // (quad_perm): 190 instructions instead of the 32 LDS reads and the 480 of a full network run by every lane.  The
+      // keys are non-negative floats (or +inf): their bit patterns order like unsigned integers, no canonicalisation needed.
+      unsigned v[8];
 #pragma unroll
-    for (int m = 0; m < NCL; m++) cml[slot * (KNN_NC + 1) + sub + L * m] = cmp[m];
+      for (int m = 0; m < 8; m++) v[m] = __float_as_uint(cmp[m]);
+      auto ce = [&](int a, int b) {
+        const unsigned lo = min(v[a], v[b]), hi = max(v[a], v[b]);
+        v[a] = lo, v[b] = hi;
+      };
+      auto in_lane = [&](int j) {  // partners r <-> r ^ j
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if ((r & j) == 0) ce(r, r ^ j);
+      };
+      auto mirror_in_lane = [&](int kk) {  // partners r <-> r ^ (kk - 1)
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if (r < (r ^ (kk - 1))) ce(r, r ^ (kk - 1));
+      };
+      mirror_in_lane(2);
+      mirror_in_lane(4), in_lane(1);
+      mirror_in_lane(8), in_lane(2), in_lane(1);
+      {  // kk = 16: element i <-> i ^ 15: lane sub ^ 1, register r ^ 7
+        const bool lower = (sub & 1) == 0;
+        unsigned y[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[7 - r], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = lower ? min(v[r], y[r]) : max(v[r], y[r]);
+      }
+      in_lane(4), in_lane(2), in_lane(1);
+      {  // kk = 32: i <-> i ^ 31: lane sub ^ 3, register r ^ 7; then i <-> i ^ 8: lane sub ^ 1, same register
+        const bool lower3 = sub < 2, lower1 = (sub & 1) == 0;
+        unsigned y[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[7 - r], 0x1B, 0xf, 0xf, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = lower3 ? min(v[r], y[r]) : max(v[r], y[r]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[r], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = lower1 ? min(v[r], y[r]) : max(v[r], y[r]);
+      }
+      in_lane(4), in_lane(2), in_lane(1);
+      // the k-th smallest: element k - 1 = register (k - 1) & 7 of lane (k - 1) >> 3 of the quad
+      unsigned pick = v[0];
+#pragma unroll
+      for (int r = 1; r < 8; r++) pick = ((k - 1) & 7) == r ? v[r] : pick;
+      cmp[0] = __uint_as_float((unsigned)__shfl((int)pick, owner + ((k - 1) >> 3), 64));
+    } else {
+#pragma unroll
+      for (int m = 0; m < NCL; m++) cml[slot * (KNN_NC + 1) + sub + L * m] = cmp[m];
+    }
+    tau_q = cmp[0];
   }
+  float tau_d = inf;
+  if constexpr (L == 4) {
+    tau_d = tau_q;
+  } else {
   __syncthreads();
   float cm[KNN_NC];
 #pragma unroll
@@ -1405,10 +1466,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
       }
     }
   }
-  float tau_d = inf;
 #pragma unroll
   for (int s = 0; s < KNN_NC; s++)
     if (s == k - 1) tau_d = cm[s];
+  }
   if (!valid) tau_d = -1.f;
   unsigned tau_hi = __float_as_uint(tau_d), tau_lo = 0xFFFFFFFFu;  // tau key = (tau_hi << 32) | tau_lo
 
