@@ -1553,8 +1553,9 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
         const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
         const unsigned long long k1 = ((unsigned long long)__float_as_uint(sqdist1(c1.x, c1.y, c1.z, qx, qy, qz)) << 32) | o1;
         unsigned long long* row = lst + (qq / L) * KQ_STRIDE;
-        int cntq = __builtin_amdgcn_readlane(cnt, qq);
         unsigned long long m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
+        if ((m0 | m1) == 0) continue;  // the box passed the test, none of its 128 points does
+        int cntq = __builtin_amdgcn_readlane(cnt, qq);
         if (cntq + __popcll(m0) + __popcll(m1) > KQ_CAP) {
           // List full: tau becomes the k-th smallest key of (stored keys U this group's hits); only
           // keys <= tau survive.  tau only decreases, so nothing of the final answer is ever dropped,
