@@ -484,6 +484,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ float readlane_f63(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63)); }
 // wave-wide min / max through DPP (row_shr 1,2,4,8, row_bcast 15/31; lanes without a source keep their own value),
 // result read from lane 63 into an SGPR: uniform, no LDS traffic
 template <bool MAX>
@@ -498,6 +499,35 @@ __device__ __forceinline__ float wave_minmax_uniform(float v) {
   v = step(v, APD_DPP_F(0x143, 0xc));
 #undef APD_DPP_F
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+
+// The same reductions with the DPP modifier on the min / max itself (one instruction per step instead of copy + v_mov_dpp +
+// canonicalise + op) -- the compiler does not fold them -- for the bounding box of a wave's points: three minima and three
+// maxima, interleaved so that no step reads a register written less than two instructions earlier (the DPP read-after-
+// VALU-write hazard needs two wait states; the leading s_nop covers the producers of the inputs).
+__device__ __forceinline__ void wave_box_uniform(float& lx, float& ly, float& lz, float& hx, float& hy, float& hz) {
+#define APD_BOX_STEP(ctrl)                                                \
+  "v_min_f32_dpp %0, %0, %0 " ctrl "\n v_min_f32_dpp %1, %1, %1 " ctrl "\n" \
+  "v_min_f32_dpp %2, %2, %2 " ctrl "\n v_max_f32_dpp %3, %3, %3 " ctrl "\n" \
+  "v_max_f32_dpp %4, %4, %4 " ctrl "\n v_max_f32_dpp %5, %5, %5 " ctrl "\n"
+  asm volatile("s_nop 1\n" APD_BOX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") APD_BOX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                   APD_BOX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") APD_BOX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                       APD_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") APD_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(lx), "+v"(ly), "+v"(lz), "+v"(hx), "+v"(hy), "+v"(hz));
+#undef APD_BOX_STEP
+  lx = readlane_f63(lx), ly = readlane_f63(ly), lz = readlane_f63(lz), hx = readlane_f63(hx), hy = readlane_f63(hy), hz = readlane_f63(hz);
+}
+// wave-wide maximum of one value (lane 63 -> SGPR); the wait states sit between the dependent steps
+__device__ __forceinline__ float wave_max_uniform(float v) {
+  asm volatile(
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "s_nop 1\n v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      : "+v"(v));
+  return readlane_f63(v);
 }
 
 // one wave stages one 128-target group into its LDS tile: lane l loads targets 2l, 2l+1, and lanes
@@ -673,8 +703,8 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       lx = fminf(lx, px[s]), ly = fminf(ly, py[s]), lz = fminf(lz, pz[s]);
       hx = fmaxf(hx, px[s]), hy = fmaxf(hy, py[s]), hz = fmaxf(hz, pz[s]);
     }
-    wbox = Box{wave_minmax_uniform<false>(lx), wave_minmax_uniform<false>(ly), wave_minmax_uniform<false>(lz),
-               wave_minmax_uniform<true>(hx), wave_minmax_uniform<true>(hy), wave_minmax_uniform<true>(hz)};
+    wave_box_uniform(lx, ly, lz, hx, hy, hz);
+    wbox = Box{lx, ly, lz, hx, hy, hz};
   }
   if (tstat) { const long long t = clock64(); tcy[0] += t - tm, tm = t; }
 
@@ -753,7 +783,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   float rad0 = bestR[0];
 #pragma unroll
   for (int s = 1; s < S; s++) rad0 = fmaxf(rad0, bestR[s]);
-  rad0 = wave_minmax_uniform<true>(rad0);
+  rad0 = wave_max_uniform(rad0);
   for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
   unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
   if (use_super && rad0 < inf) {
@@ -802,7 +832,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       float rad = bestR[0];
 #pragma unroll
       for (int s = 1; s < S; s++) rad = fmaxf(rad, bestR[s]);
-      rad = wave_minmax_uniform<true>(rad);
+      rad = wave_max_uniform(rad);
       unsigned long long pre = nb < 64 ? (1ull << nb) - 1ull : ~0ull;
       if (rad < inf) pre &= __ballot(lb_box_box(wbox, lds_box(boxes, min(lane, nb - 1))) <= rad);
       // This wave scans the groups with index = wid (mod W), so those are the only ones it has to test.  The split must not
@@ -874,6 +904,35 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       }
       best[s] = bb, bestc[s] = cc;
       g1[s] = a1, g2[s] = a2;
+    }
+  }
+  // The exact index: among the targets of the winning chunk at distance `best`, the one with the lowest ORIGINAL index (the
+  // oracle's rule).  Resolved here, by the waves that searched, and handed to k_linearize through nnpt + kKeptBit: the
+  // re-scan used to run in every wave of k_linearize that held a single point without the bit, i.e. in nearly all of them
+  // even when nine points in ten had kept their neighbour.  (Equal minima in several chunks -- kTieBit -- stay with
+  // k_linearize's scan of the whole target.)
+  if (wid == 0) {
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & kTieBit);
+      if (resolve) {
+        const int c0 = (int)(bestc[s] & kChunkMask) * kChunk;
+        float4 t[kChunk];
+#pragma unroll
+        for (int jj = 0; jj < kChunk; jj++) t[jj] = tgt.pts[min(c0 + jj, M - 1)];
+        int j = -1, jorig = 0x7fffffff;
+        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < kChunk; jj++) {
+          const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
+          const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
+          if (c0 + jj < M && d == best[s] && po < jorig) jorig = po, j = c0 + jj, tq = t[jj];
+        }
+        if (j >= 0) {
+          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+          bestc[s] |= kKeptBit;
+        }
+      }
     }
   }
   // what this search leaves behind for the next one (points that kept their neighbour keep their old record)
