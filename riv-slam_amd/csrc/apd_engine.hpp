@@ -833,8 +833,12 @@ class Engine {
     const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
-    hipLaunchKernelGGL(k_linearize, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
-                       consts(), mode);
+    if (mode == 2)
+      hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
+                         consts(), mode);
+    else
+      hipLaunchKernelGGL(k_linearize<false>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
+                         consts(), mode);
     return 0;
   }
 

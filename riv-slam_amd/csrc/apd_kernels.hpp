@@ -917,16 +917,19 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & kTieBit);
       if (resolve) {
         const int c0 = (int)(bestc[s] & kChunkMask) * kChunk;
-        float4 t[kChunk];
-#pragma unroll
-        for (int jj = 0; jj < kChunk; jj++) t[jj] = tgt.pts[min(c0 + jj, M - 1)];
         int j = -1, jorig = 0x7fffffff;
         float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int h = 0; h < kChunk; h += 8) {  // eight loads in flight at a time: 32 registers, not 64
+          float4 t[8];
 #pragma unroll
-        for (int jj = 0; jj < kChunk; jj++) {
-          const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
-          const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
-          if (c0 + jj < M && d == best[s] && po < jorig) jorig = po, j = c0 + jj, tq = t[jj];
+          for (int jj = 0; jj < 8; jj++) t[jj] = tgt.pts[min(c0 + h + jj, M - 1)];
+#pragma unroll
+          for (int jj = 0; jj < 8; jj++) {
+            const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
+            const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
+            if (c0 + h + jj < M && d == best[s] && po < jorig) jorig = po, j = c0 + h + jj, tq = t[jj];
+          }
         }
         if (j >= 0) {
           w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
@@ -1787,19 +1790,20 @@ __device__ __forceinline__ void block_reduce(double* v, double* lds /* [BLK/64][
 // 16 values ([value][lane], padded rows), lane (q, c) adds the 16 lanes' values of quarter q of column c in lane order, the
 // four quarter sums of a column are added in quarter order.  Fixed order -> bitwise reproducible, like the DPP tree.
 // scratch: BLK/64 x RED_LDS_WAVE doubles.
-constexpr int RED_LDS_COLS = 16, RED_LDS_STRIDE = 65, RED_LDS_WAVE = RED_LDS_COLS * RED_LDS_STRIDE + 64;
-template <int R, int BLK>
-__device__ __forceinline__ void block_reduce_lds(const double* v, double* lds /* [BLK/64][R] */, double* scratch, int tid) {
+constexpr int RED_LDS_COLS = 8, RED_LDS_STRIDE = 65, RED_LDS_WAVE = RED_LDS_COLS * RED_LDS_STRIDE + 64;  // 8 values per pass: 4.7 KB per wave
+template <int R, int BLK, typename Gen>
+__device__ __forceinline__ void block_reduce_lds(Gen&& gen /* gen(r): this lane's value of sum r */, double* lds /* [BLK/64][R] */, double* scratch,
+                                                 int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   double* buf = scratch + wave * RED_LDS_WAVE;
   double* part = buf + RED_LDS_COLS * RED_LDS_STRIDE;
-  const int col = lane & (RED_LDS_COLS - 1), rb = (lane / RED_LDS_COLS) * 16;  // quarter q = lane / 16 adds lanes 16q .. 16q + 15
+  const int col = lane & 15, rb = (lane / 16) * 16;  // quarter q = lane / 16 adds lanes 16q .. 16q + 15 of column lane & 15 (< nr)
 #pragma unroll
   for (int r0 = 0; r0 < R; r0 += RED_LDS_COLS) {
     const int nr = R - r0 < RED_LDS_COLS ? R - r0 : RED_LDS_COLS;
 #pragma unroll
     for (int u = 0; u < RED_LDS_COLS; u++)
-      if (u < nr) buf[u * RED_LDS_STRIDE + lane] = v[r0 + u];
+      if (u < nr) buf[u * RED_LDS_STRIDE + lane] = gen(r0 + u);
     wave_lds_fence();
     double p = 0.0;
     if (col < nr) {
@@ -1814,12 +1818,20 @@ __device__ __forceinline__ void block_reduce_lds(const double* v, double* lds /*
   __syncthreads();
 }
 
+// what one source point contributes to linearize (A:229-258); all zero without a correspondence
+struct LinPoint {
+  Sym3 Mi;                    // RCR^-1, A:191
+  double vx, vy, vz;          // transed_mean_A
+  double mex, mey, mez, cost; // M e, e^T M e
+  double matched;
+};
+
 // The per-point part of update_correspondences + linearize (A:137-258) once the 1-NN search has produced the
 // minimum distance m and the chunk it was found in: exact index, gate, APD covariance, RCR^-1, e, J, H, b.
-// acc[29] receives this point's contribution (zero when it has no correspondence).
+// lp receives this point's quantities (left all zero when it has no correspondence); lin_term turns them into the 29 sums.
 __device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
-                                                int want_Hb, int pair, int i, const float4 p, float ptx, float pty, float ptz, float m,
-                                                unsigned chunk, bool tie, bool kept, double* acc) {
+                                                int pair, int i, const float4 p, float ptx, float pty, float ptz, float m, unsigned chunk,
+                                                bool tie, bool kept, LinPoint& lp) {
   const int N = src.n, M = tgt.n;
   int j = -1;
   float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);  // the neighbour itself
@@ -1829,20 +1841,19 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
   } else if (chunk != kNoChunk) {
     // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
     int jorig = 0x7fffffff;
-    if (!tie) {
-      float4 t[kChunk];
-      int po[kChunk];  // original indices, fetched with the points (no dependent load behind the distance test)
+    if (!tie) {  // (only results of the brute-force search get here: the pruned search resolves its own, see nn_search)
+#pragma unroll 1
+      for (int h = 0; h < kChunk; h += 4) {
+        float4 t[4];
 #pragma unroll
-      for (int jj = 0; jj < kChunk; jj++) {
-        const int g = (int)chunk * kChunk + jj;
-        t[jj] = tgt.pts[g < M ? g : M - 1];
-        po[jj] = __float_as_int(t[jj].w);
-      }
+        for (int jj = 0; jj < 4; jj++) t[jj] = tgt.pts[min((int)chunk * kChunk + h + jj, M - 1)];
 #pragma unroll
-      for (int jj = 0; jj < kChunk; jj++) {
-        const int g = (int)chunk * kChunk + jj;
-        const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
-        if (g < M && d == m && po[jj] < jorig) jorig = po[jj], j = g, tq = t[jj];
+        for (int jj = 0; jj < 4; jj++) {
+          const int g = (int)chunk * kChunk + h + jj;
+          const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, ptx, pty, ptz);
+          const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
+          if (g < M && d == m && po < jorig) jorig = po, j = g, tq = t[jj];
+        }
       }
     } else {  // rare: the same fp32 minimum in several chunks (duplicates / exact ties): look at every target
       for (int g = 0; g < M; g++) {
@@ -1901,42 +1912,58 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     const double vy = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
     const double vz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
     const double ex = (double)q.x - vx, ey = (double)q.y - vy, ez = (double)q.z - vz;  // A:237
-    const double mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
-    const double mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
-    const double mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
-    acc[27] = ex * mex + ey * mey + ez * mez;  // A:240
-    acc[28] = 1.0;
-    if (want_Hb) {
-      // J = [skew(v) | -I] (A:248-250).  MA = M * skew(v), columns:
-      const double m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;     // MA[:,0]
-      const double m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;  // MA[:,1]
-      const double m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;     // MA[:,2]
-      // H upper triangle, row-major order (0,0),(0,1)...(0,5),(1,1)...(5,5)
-      // rotation block skew^T M skew: row p = skew[:,p] . MA[:,q]
-      acc[0] = vz * m0y - vy * m0z;    // (0,0)
-      acc[1] = vz * m1y - vy * m1z;    // (0,1)
-      acc[2] = vz * m2y - vy * m2z;    // (0,2)
-      acc[3] = -m0x;                   // (0,3) = -(MA)[0][0]   (top-right block = -MA^T)
-      acc[4] = -m0y;                   // (0,4) = -(MA)[1][0]
-      acc[5] = -m0z;                   // (0,5)
-      acc[6] = -vz * m1x + vx * m1z;   // (1,1)
-      acc[7] = -vz * m2x + vx * m2z;   // (1,2)
-      acc[8] = -m1x;                   // (1,3)
-      acc[9] = -m1y;                   // (1,4)
-      acc[10] = -m1z;                  // (1,5)
-      acc[11] = vy * m2x - vx * m2y;   // (2,2)
-      acc[12] = -m2x;                  // (2,3)
-      acc[13] = -m2y;                  // (2,4)
-      acc[14] = -m2z;                  // (2,5)
-      acc[15] = Mi.xx, acc[16] = Mi.xy, acc[17] = Mi.xz;  // (3,3),(3,4),(3,5)
-      acc[18] = Mi.yy, acc[19] = Mi.yz;                   // (4,4),(4,5)
-      acc[20] = Mi.zz;                                    // (5,5)
-      // b = J^T M e : rotation part skew^T (Me), translation part -(Me)   (A:254)
-      acc[21] = vz * mey - vy * mez;
-      acc[22] = -vz * mex + vx * mez;
-      acc[23] = vy * mex - vx * mey;
-      acc[24] = -mex, acc[25] = -mey, acc[26] = -mez;
-    }
+    lp.Mi = Mi;
+    lp.vx = vx, lp.vy = vy, lp.vz = vz;
+    lp.mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
+    lp.mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
+    lp.mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
+    lp.cost = ex * lp.mex + ey * lp.mey + ez * lp.mez;  // A:240
+    lp.matched = 1.0;
+  }
+}
+
+// This point's contribution to sum r of the 29 (21 H upper triangle, row-major; 6 b; cost; matched), from the per-point
+// quantities above.  Written as a function of r so that the block reduction can produce the sums a few at a time: 29 live
+// fp64 accumulators cost the kernel a wave per SIMD.  J = [skew(v) | -I] (A:248-250), MA = M * skew(v).
+__device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int r) {
+  const Sym3& Mi = lp.Mi;
+  const double vx = lp.vx, vy = lp.vy, vz = lp.vz, mex = lp.mex, mey = lp.mey, mez = lp.mez;
+  if (r == 27) return lp.cost;
+  if (r == 28) return lp.matched;
+  if (!want_Hb) return 0.0;
+  const double m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;     // MA[:,0]
+  const double m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;  // MA[:,1]
+  const double m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;     // MA[:,2]
+  switch (r) {
+    // rotation block skew^T M skew: row p = skew[:,p] . MA[:,q]; top-right block = -MA^T
+    case 0: return vz * m0y - vy * m0z;    // (0,0)
+    case 1: return vz * m1y - vy * m1z;    // (0,1)
+    case 2: return vz * m2y - vy * m2z;    // (0,2)
+    case 3: return -m0x;                   // (0,3)
+    case 4: return -m0y;                   // (0,4)
+    case 5: return -m0z;                   // (0,5)
+    case 6: return -vz * m1x + vx * m1z;   // (1,1)
+    case 7: return -vz * m2x + vx * m2z;   // (1,2)
+    case 8: return -m1x;                   // (1,3)
+    case 9: return -m1y;                   // (1,4)
+    case 10: return -m1z;                  // (1,5)
+    case 11: return vy * m2x - vx * m2y;   // (2,2)
+    case 12: return -m2x;                  // (2,3)
+    case 13: return -m2y;                  // (2,4)
+    case 14: return -m2z;                  // (2,5)
+    case 15: return Mi.xx;                 // (3,3)
+    case 16: return Mi.xy;
+    case 17: return Mi.xz;
+    case 18: return Mi.yy;                 // (4,4)
+    case 19: return Mi.yz;
+    case 20: return Mi.zz;                 // (5,5)
+    // b = J^T M e : rotation part skew^T (Me), translation part -(Me)   (A:254)
+    case 21: return vz * mey - vy * mez;
+    case 22: return -vz * mex + vx * mez;
+    case 23: return vy * mex - vx * mey;
+    case 24: return -mex;
+    case 25: return -mey;
+    default: return -mez;
   }
 }
 
@@ -1996,7 +2023,13 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 }
 
 // want_Hb: 0 = cost only, 1 = H, b, cost, 2 = also run the GN/LM step (k_lm_solve's work) in the last block
-__global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
+// FUSED = false: the per-point pass alone (want_Hb 0 or 1): without the optimiser step's register footprint (a 6x6 LDL^T, so3_exp
+// and the pose products, all in registers on one lane) the kernel fits 6 waves per SIMD instead of 4.
+#ifndef APD_LIN_WPE
+#define APD_LIN_WPE 6  // fused kernel: ask for 6 waves per SIMD; the spills land in the one-lane optimiser step of the last block
+#endif
+template <bool FUSED>
+__global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ? APD_LIN_WPE : 1, 8))) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
   unsigned bx, by;
@@ -2011,9 +2044,9 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
   if ((int)(bx * LIN_BLK) >= N) return;
   const int i = (int)bx * LIN_BLK + tid;
 
-  double acc[29];
-#pragma unroll
-  for (int r = 0; r < 29; r++) acc[r] = 0.0;
+  LinPoint lp;
+  lp.Mi = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
 
   if (i < N) {
     unsigned long long bestp = ~0ull;
@@ -2039,18 +2072,19 @@ __global__ __launch_bounds__(LIN_BLK) void k_linearize(const CloudDesc* clouds, 
     load_Tf(T, Tf);
     const float4 p = src.pts[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
-    linearize_point(src, tgt, T, w, cst, want_Hb, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, acc);
+    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, lp);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
-  block_reduce_lds<29, LIN_BLK>(acc, red, red_scratch, tid);
+  block_reduce_lds<29, LIN_BLK>([&](int r) { return lin_term(lp, want_Hb, r); }, red, red_scratch, tid);
   if (tid < 29) {
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < LIN_BLK / 64; wv++) s += red[wv * 29 + tid];
     double* row = w.blkpart + ((size_t)pair * w.nblk_max + bx) * kRed + tid;
-    if (want_Hb == 2) st_coh(row, s);
+    if (FUSED && want_Hb == 2) st_coh(row, s);
     else *row = s;
   }
+  if constexpr (FUSED)
   if (want_Hb == 2) {  // the last block of the pair to arrive takes the GN/LM step: no k_lm_solve launch
     __shared__ PairState ls;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
