@@ -906,8 +906,8 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       g1[s] = a1, g2[s] = a2;
     }
   }
-  // The exact index: among the targets of the winning chunk at distance `best`, the one with the lowest ORIGINAL index (the
-  // oracle's rule).  Resolved here, by the waves that searched, and handed to k_linearize through nnpt + kKeptBit: the
+  // The exact index: among the targets of the winning chunk at distance `best`, the one with the lowest ORIGINAL index (ties
+  // resolve like a linear scan in the caller's point order).  Resolved here, by the waves that searched, and handed to k_linearize through nnpt + kKeptBit: the
   // re-scan used to run in every wave of k_linearize that held a single point without the bit, i.e. in nearly all of them
   // even when nine points in ten had kept their neighbour.  (Equal minima in several chunks -- kTieBit -- stay with
   // k_linearize's scan of the whole target.)
