@@ -266,7 +266,10 @@ def main():
         # begin/end timestamps (hipExtLaunchKernelGGL events on the launching stream, sampled launches of the timed region)
         avg_nn_ms = nn_ms / max(1, nn_launches)
         pairs_per_launch = nn_pairs / max(1, nn_launches)
-        bytes_per_pair = 16.0 * (n + n) + 16.0 * n + 8.0 * n
+        nn_kernel = batch.last_nn_kernel()
+        keeps = nn_kernel.startswith("k_nn_compact") or os.environ.get("APDGICP_NN_SKIN", "1") != "0"
+        # per pair and launch: both sorted clouds 16(N+M), warm-start hints 16N, (neighbour keeping) the points' records 16N, result 8N
+        bytes_per_pair = 16.0 * (n + n) + 16.0 * n + (16.0 * n if keeps and nn_mode != "brute" else 0.0) + 8.0 * n
         bytes_per_launch = bytes_per_pair * pairs_per_launch
         nn_gbs = bytes_per_launch / (avg_nn_ms * 1e-3) / 1e9 if avg_nn_ms > 0 else 0.0
         # whole-registration algorithmic bytes, SURVEY 8d: B_reg = 40(N+M) + L(108N + 16M)
@@ -279,8 +282,9 @@ def main():
             pass
         # PMC numbers come from a separate committed profiling run (rocprofv3 --pmc passes cannot run inside this process):
         # reported only when that run had this launch shape, and tagged with where they come from
+        step_issue = None
         if pmc and pmc.get("points") == n and pmc.get("pairs_per_launch") == round(pairs_per_launch) and pmc.get("nn_mode", "pruned") == nn_mode \
-                and pmc.get("kind", "odometry") == args.kind:
+                and pmc.get("kind", "odometry") == args.kind and pmc.get("kernel", "").replace(" ", "") == nn_kernel.replace(" ", ""):
             traffic = pmc.get("hbm_bytes_per_launch")
             if pmc.get("SQ_INSTS_VALU"):
                 valu_rate = pmc["SQ_INSTS_VALU"] / (avg_nn_ms * 1e-3)
@@ -289,6 +293,19 @@ def main():
                          "valu_instructions_per_launch": pmc["SQ_INSTS_VALU"], "source": pmc.get("source", "profiles/pmc_nn_latest.json"),
                          "note": "VALU wave-instructions per launch (PMC, committed profile of the same launch shape) / this run's launch "
                                  "time, against the measured plain-fp32 issue ceiling (62 Tlane-op/s / 64)"}
+            # the whole step against the same roof: VALU instructions of every batch kernel x its launches per step / ms_per_step
+            sk = pmc.get("step_kernels") or {}
+            per_step = 0.0
+            for name, cs in sk.items():
+                launches = GN_ITERS if ("k_nn_" in name or "k_linearize" in name) else 1
+                per_step += cs.get("SQ_INSTS_VALU", 0.0) * launches
+            if per_step > 0 and P == 32:
+                rate = per_step / (ms_per_step * 1e-3)
+                step_issue = {"bound": "valu-issue", "achieved": round(rate / 1e9, 1), "peak": round(VALU_WAVE_INSTR_PEAK / 1e9, 2),
+                              "unit": "G wave-instructions/s", "frac": round(rate / VALU_WAVE_INSTR_PEAK, 4),
+                              "valu_instructions_per_step": per_step, "source": pmc.get("source"),
+                              "note": "sum over the step's batch kernels (search and linearize x 20 ticks, covariances, sort, pack) of their PMC "
+                                      "VALU instruction counts / ms_per_step"}
         out = {
             "metric": "APD-GICP registrations/s (8k-pt scan pairs, GN-20, covariances recomputed)",
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -306,17 +323,19 @@ def main():
                        "registrations_per_s": {"p10": round(total_pairs * K / float(np.percentile(host_s, 90)), 1),
                                                "p90": round(total_pairs * K / float(np.percentile(host_s, 10)), 1)}},
             "ms_per_gn_iter_batched": round(ms_per_step / GN_ITERS, 4),
-            "roofline": {"kernel": ("k_nn_pruned<%d, 1> (exact fp32 nearest neighbour: Hilbert-sorted clouds, bounding-box pruning, LDS-staged "
-                                    "target groups)" % nn_S) if nn_mode != "brute" else "k_nn_partial (brute-force fp32 nearest neighbour, LDS-tiled)",
+            "roofline": {"kernel": nn_kernel + (" (exact fp32 nearest neighbour: Hilbert-sorted clouds, bounding-box pruning, LDS-staged target "
+                                                "groups, neighbours kept while provably unchanged)" if nn_mode != "brute" else
+                                                " (brute-force fp32 nearest neighbour, LDS-tiled)"),
                          "bound": "hbm", "achieved": round(nn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": (pmc.get("source", "profiles/pmc_nn_latest.json") if traffic else None),
                          "avg_launch_ms": round(avg_nn_ms, 5), "launches_timed": nn_launches, "pairs_per_launch": round(pairs_per_launch, 2),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "achieved = algorithmic bytes per launch (16(N+M) + 16N + 8N per pair) / the kernel's average duration in "
+                         "note": "achieved = algorithmic bytes per launch (16(N+M) + 16N + 16N + 8N per pair) / the kernel's average duration in "
                                  "the timed region (HIP events on the launching stream).  The working set is MALL/L2 resident and the kernel "
                                  "is issue/latency bound, so the HBM fraction is small by construction; roofline_issue is the roof that binds"},
             "roofline_issue": issue,
+            "roofline_issue_step": step_issue,
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,
                                   "note": "whole step: B_reg x pairs / ms_per_step"},

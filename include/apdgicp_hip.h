@@ -246,6 +246,8 @@ int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* laun
  * timed, with a phase rotating from align to align, because timing every launch costs ~5 % of a step) */
 int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered);
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
+/* name of the nearest-neighbour kernel the last launch used (e.g. "k_nn_compact<4>", "(k_nn_pruned<1, 8>)", "k_nn_partial<4>") */
+int apdgicp_batch_last_nn_kernel(apdgicp_batch* b, char* name, int capacity);
 /* pruning diagnostics, collected only when the environment has APDGICP_STATS=1 (else zeros); reading
  * resets them.  [0..3] nearest neighbour: groups scanned, chunks tested, chunks scanned, waves;
  * [4..9] covariance k-NN: groups loaded, (NN: batches of 64 group boxes visited), (NN: points that kept their neighbour without a search), waves sampled, list tightenings, (query, group) steps;

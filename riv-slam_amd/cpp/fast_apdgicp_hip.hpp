@@ -142,13 +142,13 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   CovVector getSourceCovariances() { return get_covs(APDGICP_SOURCE, input_ ? input_->size() : 0); }
   CovVector getTargetCovariances() { return get_covs(APDGICP_TARGET, target_ ? target_->size() : 0); }
 
-  // ---- LsqRegistration probes (lsq_registration_impl.hpp:45-52); H6/B6: any type with double* data()
-  template <typename H6>
-  void getFinalHessian(H6& H) {
-    if (handle_) apdgicp_get_final_hessian(handle_, H.data());
+  // ---- LsqRegistration probes (lsq_registration.hpp:55-57, lsq_registration_impl.hpp:45-52)
+  /// the reference returns `const Eigen::Matrix<double, 6, 6>&`; here it is fetched from the device into a member first
+  const Eigen::Matrix<double, 6, 6>& getFinalHessian() {
+    if (handle_ && apdgicp_get_final_hessian(handle_, final_hessian_.data()) != 0) report("getFinalHessian");
+    return final_hessian_;
   }
-  template <typename H6 = Eigen::Matrix4d, typename B6 = Eigen::Matrix4d>
-  double evaluateCost(const Matrix4& relative_pose, H6* H = nullptr, B6* b = nullptr) {
+  double evaluateCost(const Matrix4& relative_pose, Eigen::Matrix<double, 6, 6>* H = nullptr, Eigen::Matrix<double, 6, 1>* b = nullptr) {
     push_params();
     double T[16], cost = 0.0;
     for (int i = 0; i < 16; i++) T[i] = (double)relative_pose.data()[i];
@@ -156,6 +156,14 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     return cost;
   }
   const apdgicp_result& lastResult() const { return result_; }
+  /// clouds up to this many points get their aligned copy from a host loop (0: always the device kernel)
+  void setHostTransformMax(std::size_t n) { host_transform_max_ = n; }
+  /// ScanMatchingStatus::inlier_fraction (scan_matching_odometry_nodelet.cpp:701-712) at the last pose, on the device
+  double inlierFraction(double max_correspondence_dist = 0.5) {
+    double f = 0.0;
+    if (!handle_ || apdgicp_inlier_fraction(handle_, result_.T, max_correspondence_dist, &f, nullptr) != 0) report("inlierFraction");
+    return f;
+  }
 
  protected:
   // pcl::Registration::align -> this (fast_apdgicp_impl.hpp:121-130 + lsq_registration_impl.hpp:55-80)
@@ -175,10 +183,21 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     converged_ = result_.converged != 0;
     nr_iterations_ = result_.iterations;
     if (result_.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:72
-    // pcl::transformPointCloud(*input_, output, final_transformation_), :79
+    // pcl::transformPointCloud(*input_, output, final_transformation_), :79.  The reference does this on the host, and for a
+    // scan-sized cloud so does this class: the source is already here, and one pass over it (a few microseconds) is cheaper
+    // than a kernel, a copy back and a second wait for the device.  Large clouds go through the device.
     output.points = input_->points;
-    if (apdgicp_transform_source(handle_, result_.T, &output.points[0].x, (int64_t)output.size(), (int64_t)sizeof(PointSource)) != 0)
+    if (output.size() <= host_transform_max_) {
+      const float* T = result_.T;  // column-major
+      for (auto& pt : output.points) {
+        const float x = pt.x, y = pt.y, z = pt.z;
+        pt.x = T[0] * x + T[4] * y + T[8] * z + T[12];
+        pt.y = T[1] * x + T[5] * y + T[9] * z + T[13];
+        pt.z = T[2] * x + T[6] * y + T[10] * z + T[14];
+      }
+    } else if (apdgicp_transform_source(handle_, result_.T, &output.points[0].x, (int64_t)output.size(), (int64_t)sizeof(PointSource)) != 0) {
       report("transformPointCloud");
+    }
   }
 
  private:
@@ -203,6 +222,8 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   apdgicp_handle* handle_ = nullptr;
   apdgicp_params params_;
   apdgicp_result result_{};
+  Eigen::Matrix<double, 6, 6> final_hessian_ = Eigen::Matrix<double, 6, 6>::Identity();
+  std::size_t host_transform_max_ = 65536;
 };
 
 }  // namespace fast_gicp

@@ -181,7 +181,9 @@ class Engine {
   std::vector<float> h_guesses;
   DevBuf d_state, d_results, d_errflag, d_probe, d_stage, d_T;
   DevBuf d_keys, d_box6, d_stats;
-  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_active;
+  CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_tilejobs[3], d_active;
+  DevBuf d_tkeys;          // sorted tiles of the clouds being sorted by the tiled path
+  bool sort_tiled = true;  // 2048 < n <= 16384: four tile blocks + merge + boxes (APDGICP_SORT_TILED=0: one block per cloud)
   std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
   bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
   DevBuf b_nnpart, b_corr, b_nnpt, b_nnaux, b_sqd, b_maha, b_blkpart, b_errpart;
@@ -244,6 +246,7 @@ class Engine {
   // `profile_stride`-th tick are timed, with a phase that rotates from align to align (unbiased over ticks)
   int profile_stride = 10, profile_phase = 0, cur_tick = 0;
   int last_ticks = 0;
+  const char* last_nn_kernel = "";  // the search kernel of the last launch (bench.py names it in its roofline object)
 
   // The opt-in for more than 64 KB of dynamic LDS is a property of the (function, device) pair, so every engine sets it
   // for its own device when it is created -- no process-wide "done once" flag that a second device or thread could trip over.
@@ -253,6 +256,7 @@ class Engine {
     APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SORT_BLK * 8));
     APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * SORT_BLK * 8));
     APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
+    APD_HIP(hipFuncSetAttribute((const void*)k_merge_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
     return 0;
   }
 
@@ -293,6 +297,7 @@ class Engine {
     if (const char* v = getenv("APDGICP_NN_SKIN_REL")) nn_skin_rel = std::max(0.f, (float)atof(v));
     if (const char* v = getenv("APDGICP_NN_SKIN_ABS")) nn_skin_abs = std::max(0.f, (float)atof(v));
     sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
+    sort_tiled = env_int("APDGICP_SORT_TILED", 1) != 0;
     // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
     // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
     nn_W = env_int("APDGICP_NN_W", 0);
@@ -315,7 +320,8 @@ class Engine {
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
-    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_active}) t->dev.release();
+    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_tilejobs[0], &d_tilejobs[1], &d_tilejobs[2], &d_active}) t->dev.release();
+    d_tkeys.release();
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
@@ -328,6 +334,10 @@ class Engine {
     if (ev_poll) e = hipEventDestroy(ev_poll);
     if (ev_main) e = hipEventDestroy(ev_main);
     if (ev_producer) e = hipEventDestroy(ev_producer);
+    for (HostStage& hs : h_stage) {
+      if (hs.ev) e = hipEventDestroy(hs.ev);
+      if (hs.p) e = hipHostFree(hs.p);
+    }
     for (auto st_ : gstreams) e = hipStreamSynchronize(st_), e = hipStreamDestroy(st_);
     for (auto ev_ : gevents) e = hipEventDestroy(ev_);
     for (auto& pr : nn_events) e = hipEventDestroy(pr.first), e = hipEventDestroy(pr.second);
@@ -378,6 +388,13 @@ class Engine {
     return 0;
   }
 
+  struct HostStage {
+    char* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+  } h_stage[2];
+  int h_stage_cur = 0;
+
   // ------------------------------------------------------------------ clouds
   int set_cloud(int slot, const float* xyz, int64_t n, int64_t stride_bytes, int on_device, uint64_t token) {
     if (slot < 0) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud slot");
@@ -393,15 +410,31 @@ class Engine {
     APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
     if (!on_device) {
-      const size_t bytes = (size_t)(n - 1) * stride_bytes + 12;
-      APD_HIP(hipStreamSynchronize(stream));  // staging buffer reuse
-      APD_TRY(d_stage.ensure(bytes));
-      APD_HIP(hipMemcpyAsync(d_stage.p, xyz, bytes, hipMemcpyHostToDevice, stream));
-      raw = (const char*)d_stage.p;
+      // Host clouds (the odometry nodelet hands over pcl::PointXYZI, 32 bytes a point): the three coordinates are packed into
+      // {x, y, z, 1} on the host, straight into one of two pinned staging buffers, and ONE asynchronous copy puts them where
+      // the pack kernel would have.  The caller's buffer is free when this returns, and nothing waits for the GPU: a staging
+      // buffer is only rewritten after the event behind its last copy has fired (two calls ago).
+      HostStage& hs = h_stage[h_stage_cur ^= 1];
+      if (!hs.ev) APD_HIP(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+      else APD_HIP(hipEventSynchronize(hs.ev));
+      if ((size_t)n * 16 > hs.cap) {
+        if (hs.p) APD_HIP(hipHostFree(hs.p));
+        hs.p = nullptr, hs.cap = 0;
+        const size_t cap = std::max<size_t>((size_t)n * 16 * 5 / 4, 1 << 16);
+        APD_HIP(hipHostMalloc((void**)&hs.p, cap, hipHostMallocDefault));
+        hs.cap = cap;
+      }
+      float4* dst = (float4*)hs.p;
+      for (int64_t q = 0; q < n; q++) {
+        const float* sp = (const float*)(raw + q * stride_bytes);
+        dst[q] = make_float4(sp[0], sp[1], sp[2], 1.0f);
+      }
+      APD_HIP(hipMemcpyAsync(c.opts.p, hs.p, (size_t)n * 16, hipMemcpyHostToDevice, stream));
+      APD_HIP(hipEventRecord(hs.ev, stream));
+    } else {
+      hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.opts.as<float4>());
+      APD_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.opts.as<float4>());
-    APD_HIP(hipGetLastError());
-    if (!on_device) APD_HIP(hipStreamSynchronize(stream));  // the host buffer may be released by the caller now
     c.n = (int)n;
     c.sorted = false;  // Z-curve sort is deferred so that a batch of clouds is sorted by ONE launch
     c.cov_valid = false;
@@ -458,6 +491,8 @@ class Engine {
   // Z-curve sort + chunk/group boxes of every cloud that was (re)set since the last call
   int sort_clouds() {
     std::vector<SortJob> small, regjobs[3];
+    std::vector<TileJob> tilejobs[3];
+    size_t tkeys_bytes = 0;
     std::vector<int> large;
     int np2max = 1;
     bool grew = false, any = false;
@@ -483,7 +518,13 @@ class Engine {
         SortJob j;
         j.pts = c.opts.as<float4>(), j.spts = c.pts.as<float4>(), j.perm = c.perm.as<int>();
         j.cbox = c.cbox.as<Box>(), j.gbox = c.gbox.as<Box>(), j.n = c.n, j.pad_ = 0;
-        if (c.n > 2048 && sort_in_registers) {  // k_sort_cloud_reg<E>: 1024*E/2 < n <= 1024*E
+        if (c.n > 2048 && sort_in_registers && sort_tiled) {  // four tiles of 1024 / 2048 / 4096 keys
+          const int cls = c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2;
+          TileJob tjb;
+          tjb.job = j, tjb.keys = (unsigned long long*)tkeys_bytes /* offset, fixed up below */, tjb.nt = 1024 << cls, tjb.pad_ = 0;
+          tkeys_bytes += (size_t)4 * tjb.nt * 8;
+          tilejobs[cls].push_back(tjb);
+        } else if (c.n > 2048 && sort_in_registers) {  // k_sort_cloud_reg<E>: 1024*E/2 < n <= 1024*E
           regjobs[c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2].push_back(j);
         } else {
           small.push_back(j);
@@ -512,6 +553,29 @@ class Engine {
       else if (cls == 1) hipLaunchKernelGGL(k_sort_cloud_reg<8>, grid, dim3(SORT_BLK), lds, stream, dj);
       else hipLaunchKernelGGL(k_sort_cloud_reg<16>, grid, dim3(SORT_BLK), lds, stream, dj);
       APD_HIP(hipGetLastError());
+    }
+    if (tkeys_bytes) {
+      if (tkeys_bytes > d_tkeys.cap) APD_HIP(hipStreamSynchronize(stream));
+      APD_TRY(d_tkeys.ensure(tkeys_bytes));
+      for (int cls = 0; cls < 3; cls++) {
+        if (tilejobs[cls].empty()) continue;
+        int nmax_c = 0;
+        for (TileJob& tjb : tilejobs[cls]) {
+          tjb.keys = (unsigned long long*)(d_tkeys.as<char>() + (size_t)tjb.keys);
+          nmax_c = std::max(nmax_c, tjb.job.n);
+        }
+        APD_TRY(d_tilejobs[cls].upload(tilejobs[cls].data(), tilejobs[cls].size() * sizeof(TileJob), stream));
+        const TileJob* dj = d_tilejobs[cls].as<TileJob>();
+        const unsigned cnt = (unsigned)tilejobs[cls].size();
+        const int nt = 1024 << cls;
+        const size_t lds = (size_t)nt * 8;
+        if (cls == 0) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
+        else if (cls == 1) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
+        else hipLaunchKernelGGL(k_sort_tiles<4>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
+        hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned)(4 * nt / SORT_BLK), cnt), dim3(SORT_BLK), (size_t)4 * nt * 8, stream, dj);
+        hipLaunchKernelGGL(k_boxes_sorted, dim3((unsigned)(((nmax_c + 15) / 16 + 255) / 256), cnt), dim3(256), 0, stream, dj);
+        APD_HIP(hipGetLastError());
+      }
     }
     for (int id : large) {  // generic path: keys in global memory, one launch per bitonic stage
       Cloud& c = clouds[id];
@@ -801,7 +865,7 @@ class Engine {
     w.cap = nn_cap;
     // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
     // a profiler reports them, not the stream's idle gaps around it
-#define APD_NN_LAUNCH(KERNEL, BLOCK) hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w)
+#define APD_NN_LAUNCH(KERNEL, BLOCK) (last_nn_kernel = #KERNEL, hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w))
     const long long tick_blocks = (long long)npairs * src_blocks;  // the whole batch: all groups tick together
     // large (dense) targets: a wave's 64 points touch many more groups (10.8 instead of 1.7 per wave for 100k x 500k), so
     // splitting the scans over 4 waves still pays with a few thousand blocks (r01: 0.170 -> 0.143 ms per iteration)

@@ -320,6 +320,160 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_reg(const SortJob* jobs
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same sort spread over several CUs (2048 < n <= 16384): one block per QUARTER of the padded cloud sorts its tile with
+// the register network above (E = 1, 2 or 4 keys per thread; every block first reduces the bounding box of the WHOLE cloud,
+// so all tiles use the same keys as the one-block kernels), a second launch merges the four sorted tiles by rank -- a key's
+// final position is its position in its own tile plus the number of smaller keys in each of the other three, three
+// branch-free binary searches over tiles staged in LDS -- and scatters the points, a third one builds the boxes.  The keys
+// are unique, so the permutation is exactly the one-block kernels': 64 us on one CU -> three short launches (a single
+// registration spends a third of its time in the sort; a batch sorts on 4 x as many CUs).
+struct TileJob {
+  SortJob job;
+  unsigned long long* keys;  // [4][NT] sorted tiles
+  int nt;                    // tile size = padded size / 4 (1024, 2048 or 4096)
+  int pad_;
+};
+
+template <int E>
+__global__ __launch_bounds__(SORT_BLK) void k_sort_tiles(const TileJob* jobs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long xch[];  // [E][1024]
+  __shared__ float red[SORT_BLK / 64];
+  const TileJob tj = jobs[blockIdx.y];
+  const SortJob& job = tj.job;
+  constexpr int NT = SORT_BLK * E;
+  if (tj.nt != NT) return;  // (a launch covers the clouds of one size class)
+  const int n = job.n, tid = threadIdx.x, tile = blockIdx.x;
+  const float inf = __builtin_inff();
+  float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
+  for (int i = tid; i < n; i += SORT_BLK) {
+    const float4 q = job.pts[i];
+    lx = fminf(lx, q.x), ly = fminf(ly, q.y), lz = fminf(lz, q.z);
+    hx = fmaxf(hx, q.x), hy = fmaxf(hy, q.y), hz = fmaxf(hz, q.z);
+  }
+  lx = block_reduce_minmax(lx, false, red, tid, SORT_BLK);
+  ly = block_reduce_minmax(ly, false, red, tid, SORT_BLK);
+  lz = block_reduce_minmax(lz, false, red, tid, SORT_BLK);
+  hx = block_reduce_minmax(hx, true, red, tid, SORT_BLK);
+  hy = block_reduce_minmax(hy, true, red, tid, SORT_BLK);
+  hz = block_reduce_minmax(hz, true, red, tid, SORT_BLK);
+  const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
+  const float scale = 1023.f / ext;
+  unsigned long long key[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int i = tile * NT + tid * E + e;
+    if (i < n) {
+      const float4 q = job.pts[i];
+      key[e] = ((unsigned long long)morton30(q.x, q.y, q.z, lx, ly, lz, scale) << 32) | (unsigned)i;
+    } else {
+      key[e] = ~0ull;
+    }
+  }
+#pragma unroll
+  for (int k = 2; k <= NT; k <<= 1) {
+    for (int j = k >> 1; j >= 64 * E; j >>= 1) {  // partner in another wave: through LDS
+      const int pt = tid ^ (j / E);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) xch[e * SORT_BLK + tid] = key[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int i = tid * E + e;
+        const unsigned long long o = xch[e * SORT_BLK + pt];
+        const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+        key[e] = ((o < key[e]) == take_min) ? o : key[e];
+      }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const int j = m * E;
+      if (j < k) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int i = tid * E + e;
+          const unsigned long long o = shfl_xor_u64(key[e], m, tid & 63);
+          const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+          key[e] = ((o < key[e]) == take_min) ? o : key[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = E / 2; j > 0; j >>= 1) {
+      if (j < k) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          if ((e & j) == 0) {
+            const int i = tid * E + e;
+            const bool up = (i & k) == 0;
+            const unsigned long long a = key[e], b = key[e | j];
+            if ((a > b) == up) key[e] = b, key[e | j] = a;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) tj.keys[(size_t)tile * NT + tid * E + e] = key[e];
+}
+
+// grid (4 * nt / 1024, clouds): thread g of a cloud owns key g of the concatenated tiles
+__global__ __launch_bounds__(SORT_BLK) void k_merge_tiles(const TileJob* jobs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tl[];  // [4][nt]
+  const TileJob tj = jobs[blockIdx.y];
+  const SortJob& job = tj.job;
+  const int nt = tj.nt, tid = threadIdx.x;
+  if ((int)(blockIdx.x * SORT_BLK) >= 4 * nt) return;
+  for (int e = tid; e < 4 * nt; e += SORT_BLK) tl[e] = tj.keys[e];
+  __syncthreads();
+  const int g = blockIdx.x * SORT_BLK + tid, tile = g / nt, p = g - tile * nt;
+  const unsigned long long key = tl[g];
+  if (key == ~0ull) return;  // padding
+  int rank = p;
+  int pos[3] = {0, 0, 0};
+  const unsigned long long* other[3];
+#pragma unroll
+  for (int u = 0; u < 3; u++) other[u] = tl + (size_t)((tile + 1 + u) & 3) * nt;
+  for (int step = nt >> 1; step > 0; step >>= 1) {  // three searches side by side
+#pragma unroll
+    for (int u = 0; u < 3; u++) pos[u] += other[u][pos[u] + step - 1] < key ? step : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 3; u++) rank += pos[u] + (other[u][pos[u]] < key ? 1 : 0);
+  const int o = (int)(unsigned)key;
+  float4 q = job.pts[o];
+  q.w = __int_as_float(o);
+  job.perm[rank] = o;
+  job.spts[rank] = q;
+}
+
+// chunk and group boxes of the sorted copy: one thread per chunk, 8 neighbouring lanes per group.  grid (ceil(nchunks / 256), clouds)
+__global__ __launch_bounds__(256) void k_boxes_sorted(const TileJob* jobs) {
+  const SortJob job = jobs[blockIdx.y].job;
+  const int n = job.n, c = blockIdx.x * 256 + threadIdx.x;
+  const float inf = __builtin_inff();
+  Box bx{inf, inf, inf, -inf, -inf, -inf};
+  if (c * 16 < n) {
+#pragma unroll 4
+    for (int e = 0; e < 16; e++) {
+      const int sidx = c * 16 + e;
+      if (sidx < n) {
+        const float4 q = job.spts[sidx];
+        bx.lx = fminf(bx.lx, q.x), bx.ly = fminf(bx.ly, q.y), bx.lz = fminf(bx.lz, q.z);
+        bx.hx = fmaxf(bx.hx, q.x), bx.hy = fmaxf(bx.hy, q.y), bx.hz = fmaxf(bx.hz, q.z);
+      }
+    }
+    job.cbox[c] = bx;
+  }
+#pragma unroll
+  for (int m = 1; m < kGroupChunks; m <<= 1) {
+    bx.lx = fminf(bx.lx, __shfl_xor(bx.lx, m, 64)), bx.ly = fminf(bx.ly, __shfl_xor(bx.ly, m, 64)), bx.lz = fminf(bx.lz, __shfl_xor(bx.lz, m, 64));
+    bx.hx = fmaxf(bx.hx, __shfl_xor(bx.hx, m, 64)), bx.hy = fmaxf(bx.hy, __shfl_xor(bx.hy, m, 64)), bx.hz = fmaxf(bx.hz, __shfl_xor(bx.hz, m, 64));
+  }
+  if (c % kGroupChunks == 0 && c * 16 < n) job.gbox[c / kGroupChunks] = bx;
+}
+
 // ---- generic path for large clouds (n > SORT_LDS_MAX_N): keys in global memory
 __global__ void k_bbox_atomic(const float4* pts, int n, int* box6 /* ordered-int encoded, init lo=+inf hi=-inf */) {
   __shared__ float red[256 / 64];

@@ -753,6 +753,12 @@ int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* l
   return 0;
 }
 
+int apdgicp_batch_last_nn_kernel(apdgicp_batch* b, char* name, int capacity) {
+  if (!b || !name || capacity < 1) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+  snprintf(name, (size_t)capacity, "%s", b->eng.last_nn_kernel);
+  return 0;
+}
+
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   if (ticks) *ticks = b->eng.last_ticks;

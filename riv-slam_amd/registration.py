@@ -90,7 +90,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_debug_stats",
+    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_last_nn_kernel", "apdgicp_batch_debug_stats",
     "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
 
@@ -164,6 +164,7 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_last_nn_profile.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.apdgicp_batch_debug_stats.argtypes = [vp, vp]
+    L.apdgicp_batch_last_nn_kernel.argtypes = [vp, C.c_char_p, i32]
     L.apdgicp_submap_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.apdgicp_submap_destroy.argtypes = [vp]
     L.apdgicp_submap_assemble.argtypes = [vp, i32, vp, vp, i64, i64, i32, vp, vp, C.POINTER(i64)]
@@ -683,6 +684,11 @@ class BatchAPDGICP:
         ms, n, pr = C.c_double(), C.c_int64(), C.c_int64()
         _check(self.L.apdgicp_batch_last_nn_profile(self.b, C.byref(ms), C.byref(n), C.byref(pr)))
         return ms.value, n.value, pr.value
+
+    def last_nn_kernel(self) -> str:
+        buf = C.create_string_buffer(96)
+        _check(self.L.apdgicp_batch_last_nn_kernel(self.b, buf, 96))
+        return buf.value.decode().strip("()")
 
     def last_ticks(self):
         a, s, t = C.c_int(), C.c_int(), C.c_int()

@@ -6,6 +6,7 @@
 // prints: converged iterations T[16] (column-major) and the first transformed output point
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "fast_apdgicp_hip.hpp"
@@ -35,6 +36,87 @@ static pcl::PointCloud<PointT>::Ptr make_cloud(const float* xyz, int n) {
   return c;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Timing of the real caller path: HOST pcl::PointXYZI clouds through the pcl::Registration interface, wall clock around
+// the calls the reference makes.  (1) the three protocols of fast_apdgicp/src/align.cpp:52-104 -- single, 100 times,
+// 100 times with one cloud's covariances reused -- and (2) scan-to-keyframe odometry as in
+// scan_matching_odometry_nodelet.cpp:449-471: the keyframe stays (pointer-equal target: cached), every frame brings a new
+// source cloud object, align(*aligned, guess), getFinalTransformation().  Prints one JSON object.
+#include <algorithm>
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void stats(std::vector<double> v, const char* name, bool last) {
+  std::sort(v.begin(), v.end());
+  auto q = [&](double f) { return v[(size_t)std::min<double>(v.size() - 1, f * (v.size() - 1) + 0.5)]; };
+  std::printf("\"%s\": {\"median\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"min\": %.4f, \"max\": %.4f, \"n\": %zu}%s", name, q(0.5), q(0.1), q(0.9), v.front(),
+              v.back(), v.size(), last ? "" : ", ");
+}
+
+static int run_protocols(const float* s, int ns, const float* t, int nt, const float* guess) {
+  using Reg = fast_gicp::FastAPDGICPHip<PointT, PointT>;
+  auto registration = select_registration_method_hip();
+  Reg& reg = *dynamic_cast<Reg*>(registration.get());
+  pcl::PointCloud<PointT>::ConstPtr target = make_cloud(t, nt), source = make_cloud(s, ns);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  pcl::Registration<PointT, PointT>::Matrix4 g;
+  for (int i = 0; i < 16; i++) g.data()[i] = guess[i];
+  for (int i = 0; i < 5; i++) {  // warm-up: allocations, code objects
+    reg.clearTarget(), reg.clearSource();
+    reg.setInputTarget(target), reg.setInputSource(source), reg.align(*aligned, g);
+  }
+  std::printf("{\"points\": [%d, %d], \"iterations\": %d, ", ns, nt, reg.lastResult().iterations + 1);
+  // ---- align.cpp: single
+  std::vector<double> single, multi, reuse, odom;
+  for (int r = 0; r < 30; r++) {
+    const double t1 = now_ms();
+    reg.clearTarget(), reg.clearSource();
+    reg.setInputTarget(target), reg.setInputSource(source), reg.align(*aligned, g);
+    single.push_back(now_ms() - t1);
+  }
+  // ---- align.cpp: 100 times (per-call times of the loop; the loop total is their sum)
+  double t0 = now_ms();
+  for (int i = 0; i < 100; i++) {
+    const double t1 = now_ms();
+    reg.clearTarget(), reg.clearSource();
+    reg.setInputTarget(target), reg.setInputSource(source), reg.align(*aligned, g);
+    multi.push_back(now_ms() - t1);
+  }
+  const double multi_total = now_ms() - t0;
+  // ---- align.cpp: 100 times, reusing the covariances of one cloud
+  pcl::PointCloud<PointT>::ConstPtr target_ = target, source_ = source;
+  t0 = now_ms();
+  for (int i = 0; i < 100; i++) {
+    const double t1 = now_ms();
+    reg.swapSourceAndTarget();
+    reg.clearSource();
+    reg.setInputTarget(target_), reg.setInputSource(source_), reg.align(*aligned);   // (as there: no guess)
+    target_.swap(source_);
+    reuse.push_back(now_ms() - t1);
+  }
+  const double reuse_total = now_ms() - t0;
+  // ---- odometry: cached keyframe, a NEW source cloud object every frame (two objects with the scan's points, alternating)
+  pcl::PointCloud<PointT>::ConstPtr frames[2] = {make_cloud(s, ns), make_cloud(s, ns)};
+  reg.clearTarget(), reg.clearSource();
+  reg.setInputTarget(target);
+  for (int i = 0; i < 220; i++) {
+    const double t1 = now_ms();
+    reg.setInputTarget(target);             // matching() sets the keyframe on every frame: pointer-equal, cached
+    reg.setInputSource(frames[i & 1]);
+    reg.align(*aligned, g);
+    const auto T = reg.getFinalTransformation();
+    (void)T;
+    if (i >= 20) odom.push_back(now_ms() - t1);
+  }
+  stats(single, "align_cpp_single_ms", false);
+  stats(multi, "align_cpp_100_times_per_call_ms", false);
+  std::printf("\"align_cpp_100_times_total_ms\": %.3f, ", multi_total);
+  stats(reuse, "align_cpp_100_times_reuse_per_call_ms", false);
+  std::printf("\"align_cpp_100_times_reuse_total_ms\": %.3f, ", reuse_total);
+  stats(odom, "odometry_frame_ms", false);
+  std::printf("\"converged\": %d, \"inlier_fraction\": %.6f}\n", reg.hasConverged() ? 1 : 0, reg.inlierFraction(0.5));
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("compile-only\n");
@@ -48,6 +130,7 @@ int main(int argc, char** argv) {
   std::vector<float> s(3 * n[0]), t(3 * n[1]);
   if (std::fread(s.data(), 4, s.size(), f) != s.size() || std::fread(t.data(), 4, t.size(), f) != t.size()) return 2;
   std::fclose(f);
+  if (argc > 2 && std::string(argv[2]) == "--protocol") return run_protocols(s.data(), n[0], t.data(), n[1], guess);
 
   auto registration = select_registration_method_hip();
   auto source = make_cloud(s.data(), n[0]);

@@ -38,6 +38,8 @@ struct ShimMatrix {
     return x;
   }
 };
+template <typename S, int R, int C>
+using Matrix = ShimMatrix<S, R, C>;
 using Matrix4f = ShimMatrix<float, 4, 4>;
 using Matrix4d = ShimMatrix<double, 4, 4>;
 template <typename T>

@@ -57,3 +57,24 @@ def test_adapter_matches_python_binding(golden, scene, tmp_path):
     want = Tp[:3, :3] @ src[0] + Tp[:3, 3]
     assert np.abs(p0[:3] - want).max() < 1e-4 and p0[3] == 42.0   # intensity carried over like pcl::transformPointCloud
     assert int(vals[22]) == 1   # setInputTargetDevice (device-resident submap as target): the same registration
+
+
+@pytest.mark.gpu
+def test_adapter_protocol_timing_mode(scene, tmp_path):
+    """align.cpp's protocols and the odometry frame loop through the adapter with host clouds (tests/measure/odometry_protocol.py
+    runs the same binary at 8192 points for profiles/)."""
+    import json
+    exe = build_exe()
+    src, tgt, _, guess = scene.make_pair(2048, 2048, scene.pair_seed(2, 0), "odometry")
+    path = tmp_path / "pair.bin"
+    with open(path, "wb") as f:
+        np.array([len(src), len(tgt)], dtype=np.int32).tofile(f)
+        np.asfortranarray(guess).T.astype(np.float32).tofile(f)
+        src.astype(np.float32).tofile(f)
+        tgt.astype(np.float32).tofile(f)
+    out = subprocess.run([exe, str(path), "--protocol"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["converged"] == 1 and 0.0 < d["inlier_fraction"] <= 1.0
+    for k in ("align_cpp_single_ms", "align_cpp_100_times_per_call_ms", "align_cpp_100_times_reuse_per_call_ms", "odometry_frame_ms"):
+        assert 0.0 < d[k]["p10"] <= d[k]["median"] <= d[k]["p90"] < 50.0, (k, d[k])

@@ -739,19 +739,17 @@ def test_register_sort_equals_lds_sort(reg, scene):
     for n, m in ((2049, 4096), (4097, 8192), (8193, 12000), (16384, 9000)):
         src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(8, n), "odometry")
         out = []
-        for flag in ("1", "0"):
-            os.environ["APDGICP_SORT_REG"] = flag
-            try:
-                g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
-            finally:
-                os.environ.pop("APDGICP_SORT_REG", None)
+        # the tiled multi-block sort (default), one register-sorting block per cloud, one LDS-sorting block per cloud
+        for env in ({}, {"APDGICP_SORT_TILED": "0"}, {"APDGICP_SORT_REG": "0"}):
+            g = _handle_with_env(reg, reg.FastAPDGICP, env, max_correspondence_distance=2.0)
             g.setInputSource(src)
             g.setInputTarget(tgt)
             c, H, b = g.linearize(guess.astype(np.float64))
             corr, sqd = g.correspondences()
             out.append((g.getSourceCovariances(), g.getTargetCovariances(), corr, sqd, c, H, b))
-        for x, y in zip(*out):
-            assert np.array_equal(np.asarray(x), np.asarray(y))
+        for other in out[1:]:
+            for x, y in zip(out[0], other):
+                assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
 def test_exact_ties_resolve_to_the_lowest_original_index(reg):
