@@ -186,16 +186,19 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     // pcl::transformPointCloud(*input_, output, final_transformation_), :79.  The reference does this on the host, and for a
     // scan-sized cloud so does this class: the source is already here, and one pass over it (a few microseconds) is cheaper
     // than a kernel, a copy back and a second wait for the device.  Large clouds go through the device.
-    output.points = input_->points;
-    if (output.size() <= host_transform_max_) {
+    if (input_->size() <= host_transform_max_) {  // one pass: copy the point (all its fields) and move its coordinates
       const float* T = result_.T;  // column-major
-      for (auto& pt : output.points) {
+      const std::size_t n = input_->size();
+      output.points.resize(n);
+      for (std::size_t q = 0; q < n; q++) {
+        PointSource pt = input_->points[q];
         const float x = pt.x, y = pt.y, z = pt.z;
         pt.x = T[0] * x + T[4] * y + T[8] * z + T[12];
         pt.y = T[1] * x + T[5] * y + T[9] * z + T[13];
         pt.z = T[2] * x + T[6] * y + T[10] * z + T[14];
+        output.points[q] = pt;
       }
-    } else if (apdgicp_transform_source(handle_, result_.T, &output.points[0].x, (int64_t)output.size(), (int64_t)sizeof(PointSource)) != 0) {
+    } else if ((output.points = input_->points, true) && apdgicp_transform_source(handle_, result_.T, &output.points[0].x, (int64_t)output.size(), (int64_t)sizeof(PointSource)) != 0) {
       report("transformPointCloud");
     }
   }

@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -231,6 +232,8 @@ class Engine {
     long long nn_pairs_acc = 0;
     bool pending = false;
     int pending_npairs = 0, pending_ticks = 0;
+    int poll_seq = 0;
+    bool pending_spin = false;
   } alt;
   bool pending = false;          // the current slot's final poll has been enqueued but not waited for
   int pending_npairs = 0, pending_ticks = 0;
@@ -943,6 +946,26 @@ class Engine {
     return 0;
   }
 
+  // waits for the poll just enqueued on the current slot: spinning on its sequence word when it posts one (bounded: a GPU
+  // that takes longer than a few hundred microseconds gets the sleeping wait), else on the event
+  int poll_seq = 0;
+  bool pending_spin = false;
+  int wait_poll() {
+    if (pending_spin) {
+      volatile int* h_seq = (volatile int*)((int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65538);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned it = 0;; it++) {
+        if (*h_seq == poll_seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          return 0;
+        }
+        if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+      }
+    }
+    APD_HIP(hipEventSynchronize(ev_poll));
+    return 0;
+  }
+
   int ensure_alt_slot() {
     if (alt.h_poll) return 0;
     APD_HIP(hipHostMalloc((void**)&alt.h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
@@ -959,6 +982,7 @@ class Engine {
     nn_events.swap(alt.nn_events);
     std::swap(nn_events_used, alt.nn_events_used), std::swap(nn_pairs_acc, alt.nn_pairs_acc);
     std::swap(pending, alt.pending), std::swap(pending_npairs, alt.pending_npairs), std::swap(pending_ticks, alt.pending_ticks);
+    std::swap(poll_seq, alt.poll_seq), std::swap(pending_spin, alt.pending_spin);
   }
   // waits for the deferred final poll of the CURRENT slot's align and reports its device error flag
   int finish_align() {
@@ -966,7 +990,7 @@ class Engine {
     pending = false;
     {
       roctx_range rr("apdgicp:poll");
-      APD_HIP(hipEventSynchronize(ev_poll));
+      APD_TRY(wait_poll());
     }
     last_ticks = pending_ticks;
     if (profile_nn) APD_TRY(collect_nn_profile());
@@ -1060,10 +1084,15 @@ class Engine {
       // k_finalize writes the host's copy itself (pinned, device-visible memory): no copy kernel behind it
       results_on_host = npairs <= kHostResults;
       h_status = results_on_host ? (int*)(h_poll + (size_t)npairs * sizeof(ResultRec)) : (int*)h_poll;
+      // one block of pairs: the poll also posts a sequence number behind its records, and the host spins on that word
+      const bool spin = npairs <= 64 && results_on_host;
+      int* h_seq = (int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65538;
+      poll_seq = spin ? poll_seq + 1 : poll_seq;
       hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), d_stat, npairs,
                          d_errflag.as<int>(), results_on_host ? (ResultRec*)h_poll_dev : (ResultRec*)nullptr,
-                         (int*)(h_poll_dev + ((char*)h_status - h_poll)));
+                         (int*)(h_poll_dev + ((char*)h_status - h_poll)), spin ? (int*)(h_poll_dev + ((char*)h_seq - h_poll)) : (int*)nullptr, poll_seq);
       APD_HIP(hipEventRecord(ev_poll, stream));
+      pending_spin = spin;
       if (defer_poll && ticks == tick_cap && ticks == todo) {  // the only chunk: nothing on the host depends on its outcome
         pending = true, pending_npairs = npairs, pending_ticks = (int)ticks;
         work.active = nullptr;
@@ -1073,7 +1102,7 @@ class Engine {
       const auto t_enq = std::chrono::steady_clock::now();
       {
         roctx_range rr("apdgicp:poll");
-        APD_HIP(hipEventSynchronize(ev_poll));
+        APD_TRY(wait_poll());
       }
       if (dbg_t)
         fprintf(stderr, "[apdgicp] %d ticks: enqueue %.3f ms, wait %.3f ms\n", todo, std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),

@@ -2451,15 +2451,29 @@ __global__ __launch_bounds__(64) void k_probe_reduce(const CloudDesc* clouds, co
 // also the poll: status_out (optional) receives every pair's status and, behind them, the device error flag
 // host_out / host_status (optional): the same records / status words + error flag written straight into pinned host memory,
 // so the poll needs no copy behind this kernel
+__device__ __forceinline__ void finalize_pair(const PairState* st, ResultRec* out, int* status_out, ResultRec* host_out, int* host_status, int p);
+// host_seq (optional; one-block launches only): after every record and status word of this poll has been written through to
+// host memory the word receives `seq` -- the host spins on it instead of sleeping on an event (a few microseconds per poll,
+// which is most of what a one-iteration LM registration has left to give)
 __global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out, int npairs, const int* err_flag, ResultRec* host_out,
-                           int* host_status) {
+                           int* host_status, int* host_seq = nullptr, int seq = 0) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0) {
     const int flag = err_flag ? *err_flag : 0;
     if (status_out) status_out[npairs] = flag;
     if (host_status) host_status[npairs] = flag;
   }
+  if (host_seq) {  // (gridDim.x == 1)
+    if (p < npairs) finalize_pair(st, out, status_out, host_out, host_status, p);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   if (p >= npairs) return;
+  finalize_pair(st, out, status_out, host_out, host_status, p);
+}
+__device__ __forceinline__ void finalize_pair(const PairState* st, ResultRec* out, int* status_out, ResultRec* host_out, int* host_status, int p) {
   const PairState& s = st[p];
   ResultRec r;
   for (int i = 0; i < 3; i++)
