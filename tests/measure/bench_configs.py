@@ -85,6 +85,59 @@ for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
     out[f"C3_1x8_{tag}"] = {"ms_per_batch": round(ms, 3), "registrations_per_s": round(8e3 / ms, 1), "n_linearize": [int(x) for x in res["n_linearize"]],
                             "t_err_m": te_max, "r_err_rad": re_max}
 
+# ---- C4 as the survey specifies it (8d): loop-closure candidates -- t <= 3 m, yaw <= 20 deg, identity guess
+# (loop_detector.cpp:225), LM with the launch parameters -- 32 pairs per batch (the per-GPU shard of 256 over 8 GPUs), both
+# clouds fresh.  The first search of every pair is cold and far from the solution: the regime the warm-start pruning does not help.
+P4 = 32
+cl4, pr4, gs4, host4 = [], [], [], []
+for p in range(P4):
+    s_, t_, _, g_ = scene.make_pair(8192, 8192, scene.pair_seed(4, p), "loop")
+    host4.append((s_, t_, g_))
+    cl4 += [torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()]
+    pr4.append((2 * p, 2 * p + 1))
+    gs4.append(g_)
+for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    pairs4 = b.make_pairs(pr4, gs4)
+    packed = b.pack_clouds(cl4)
+
+    def c4():
+        b.set_clouds(0, packed)
+        return b.align(pairs4)
+    ms = timed(c4, 10)
+    res = c4()
+    # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
+    hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(3)]
+    for h_ in hs:
+        h_.set_pair_groups(1)
+
+    def c4x3():
+        tk = []
+        for h_ in hs:
+            h_.set_clouds(0, packed)
+            tk.append(h_.align_enqueue(pairs4))
+        for h_, t_k in zip(hs, tk):
+            h_.align_collect(t_k)
+    ms3 = timed(c4x3, 6) / 3
+    te_max = re_max = 0.0
+    n_checked = 0
+    counts_equal = True
+    for p in range(P4):
+        o = R.RefAPDGICP(R.default_params(**kw))
+        o.setInputSource(host4[p][0]), o.setInputTarget(host4[p][1])
+        To = o.align(host4[p][2])
+        te, re_ = scene.pose_error(To, reg.result_matrix(res[p]))
+        te_max, re_max = max(te_max, te), max(re_max, re_)
+        counts_equal &= bool(o.hasConverged()) == bool(res[p]["converged"]) and o.nr_iterations == int(res[p]["iterations"])
+        n_checked += 1
+    time.sleep(0.5)
+    its = [int(x) for x in res["n_linearize"]]
+    out[f"C4_loop_32_pairs_{tag}"] = {"ms_per_batch_one_handle": round(ms, 3), "registrations_per_s_one_handle": round(P4 * 1e3 / ms, 1),
+                                      "ms_per_batch_three_handles_in_flight": round(ms3, 3), "registrations_per_s_three_handles": round(P4 * 1e3 / ms3, 1),
+                                      "n_linearize_histogram": {str(k_): its.count(k_) for k_ in sorted(set(its))},
+                                      "converged": int(np.sum(res["converged"])), "pairs_checked_vs_cpu": n_checked,
+                                      "converged_and_iterations_equal_cpu": bool(counts_equal), "t_err_m": te_max, "r_err_rad": re_max}
+
 # ---- C5: 100k x 500k
 s5, t5, _, g5 = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
 d5s, d5t = torch.from_numpy(s5).cuda(), torch.from_numpy(t5).cuda()
