@@ -47,8 +47,7 @@ def parse_args():
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--points", type=int, default=N_PTS)
     ap.add_argument("--kind", default="odometry", choices=("odometry", "loop"), help="scene.make_pair kind of the synthetic pairs")
-    ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 3, or 4 with a process group; 1: one "
-                                                            "handle with three pair groups)")
+    ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 4; 1: one handle with three pair groups)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
@@ -168,10 +167,10 @@ def main():
 
     params = bench_params(reg)
     # Consecutive steps are independent batches, so several of them are kept in flight: step s runs on batch handle s % H
-    # (H = --handles, 3 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
-    # underfed (32 pairs: three groups of latency-bound tick kernels); with three steps at different phases one handle's
+    # (H = --handles, 4 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
+    # underfed (32 pairs: three groups of latency-bound tick kernels); with several steps at different phases one handle's
     # covariance kernels fill the gaps of the others' ticks.  Every handle registers its own copy of the step's clouds.
-    H = args.handles if args.handles > 0 else (4 if use_dist else 3)
+    H = args.handles if args.handles > 0 else 4   # r02 (lazy group streams: every handle's stream on a hardware queue of its own): 3 / 4 / 5 / 6 handles 1.00 / 0.92 / 0.99 / 0.99 ms per step; with a process group 1.00 / 0.96 / 1.14
     batches = []
     for _ in range(H):
         bh = reg.BatchAPDGICP(params, device=local_rank)

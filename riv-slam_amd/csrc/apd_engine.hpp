@@ -307,7 +307,14 @@ class Engine {
     if (nn_W != 1 && nn_W != 2 && nn_W != 4 && nn_W != 8) nn_W = 0;
     ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 3)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
-    for (int g = 1; g < ngroups_cfg; g++) {  // group 0 uses the main stream
+    return set_params(p);
+  }
+  // The streams of pair groups 1 .. n-1 (group 0 uses the main stream) are created when a batch first needs them, not with the
+  // engine: the runtime deals streams onto its hardware queues in creation order, and the never-used group streams of
+  // one-group handles pushed the main streams of four handles onto colliding queues (bench: 1.06 -> 0.93 ms per step with
+  // four handles once the main streams sat on queues of their own).
+  int ensure_group_streams(int ng) {
+    while ((int)gstreams.size() + 1 < ng) {
       hipStream_t st_;
       hipEvent_t ev_;
       APD_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
@@ -315,7 +322,7 @@ class Engine {
       gstreams.push_back(st_);
       gevents.push_back(ev_);
     }
-    return set_params(p);
+    return 0;
   }
 
   ~Engine() {
@@ -729,7 +736,7 @@ class Engine {
   // K = 8: 0.90 / 0.92 / 0.92 ms with 1 / 2 / 3 groups, K = 12: 1.12 / 0.98 / 1.02, K = 24: 1.41 / 1.23 / 1.17)
   bool keep_maha = true;  // false for batch handles: nothing reads mahalanobis_ there unless the optimiser is LM (k_error)
   int max_groups = 1 << 30;  // apdgicp_batch_set_pair_groups: a caller that keeps several batches (handles) in flight wants one group each
-  int group_count() const { return std::max(1, std::min<int>(std::min<int>((int)gstreams.size() + 1, max_groups), (npairs + 4) / 8)); }
+  int group_count() const { return std::max(1, std::min<int>(std::min<int>(ngroups_cfg, max_groups), (npairs + 4) / 8)); }
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
@@ -1053,7 +1060,8 @@ class Engine {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk_at(ticks), tick_cap - ticks);
       // pair groups on their own streams: fork after the main stream's set-up work, join before the poll
-      const int ng = ticks == 0 ? group_count() : std::max(1, std::min<int>(std::min<int>((int)gstreams.size() + 1, max_groups), n_active / 2));
+      const int ng = ticks == 0 ? group_count() : std::max(1, std::min<int>(std::min<int>(ngroups_cfg, max_groups), n_active / 2));
+      APD_TRY(ensure_group_streams(ng));
       if (ng > 1) {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < ng; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));

@@ -12,7 +12,7 @@ import numpy as np, torch
 reg = importlib.import_module("riv-slam_amd.registration")
 scene = importlib.import_module("riv-slam_amd.scene")
 import bench
-H = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 clouds, pairs, guesses = [], [], []
