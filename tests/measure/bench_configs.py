@@ -107,18 +107,36 @@ for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
     ms = timed(c4, 10)
     res = c4()
     # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
-    hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(3)]
+    hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(4)]
     for h_ in hs:
         h_.set_pair_groups(1)
 
     def c4x3():
         tk = []
-        for h_ in hs:
+        for h_ in hs[:3]:
             h_.set_clouds(0, packed)
             tk.append(h_.align_enqueue(pairs4))
-        for h_, t_k in zip(hs, tk):
+        for h_, t_k in zip(hs[:3], tk):
             h_.align_collect(t_k)
     ms3 = timed(c4x3, 6) / 3
+    # an LM batch polls as it goes, so enqueue blocks; one host thread per handle keeps several of them in flight
+    import threading
+
+    def c4_threads(nthreads=4, reps=4):
+        def work(h_):
+            for _ in range(reps):
+                h_.set_clouds(0, packed)
+                h_.align(pairs4)
+        ths = [threading.Thread(target=work, args=(h_,)) for h_ in hs[:nthreads]]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+    c4_threads()
+    torch.cuda.synchronize()
+    t0_ = time.perf_counter()
+    c4_threads()
+    ms_thr = (time.perf_counter() - t0_) * 1e3 / (4 * 4)
     te_max = re_max = 0.0
     n_checked = 0
     counts_equal = True
@@ -134,6 +152,7 @@ for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
     its = [int(x) for x in res["n_linearize"]]
     out[f"C4_loop_32_pairs_{tag}"] = {"ms_per_batch_one_handle": round(ms, 3), "registrations_per_s_one_handle": round(P4 * 1e3 / ms, 1),
                                       "ms_per_batch_three_handles_in_flight": round(ms3, 3), "registrations_per_s_three_handles": round(P4 * 1e3 / ms3, 1),
+                                      "ms_per_batch_four_host_threads": round(ms_thr, 3), "registrations_per_s_four_host_threads": round(P4 * 1e3 / ms_thr, 1),
                                       "n_linearize_histogram": {str(k_): its.count(k_) for k_ in sorted(set(its))},
                                       "converged": int(np.sum(res["converged"])), "pairs_checked_vs_cpu": n_checked,
                                       "converged_and_iterations_equal_cpu": bool(counts_equal), "t_err_m": te_max, "r_err_rad": re_max}

@@ -11,7 +11,11 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ev=gpurun_out/ev; mkdir -p $ev
 DRV="python3 bench.py --gpus 1 --steps 20 --warmup 5"
 PMC="python3 bench.py --gpus 1 --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-diagnostics"
+# (APDGICP_PROFILE_STRIDE=1: bench.py's own timing brackets EVERY search launch in this run, like the trace does, so the two
+# averages cover the same launches; the default run samples one tick in ten)
+export APDGICP_PROFILE_STRIDE=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks -o k -- $DRV --no-cpu-baseline > $ev/bench_profiled.json 2> $ev/ks.err
+unset APDGICP_PROFILE_STRIDE
 python3 tools/rocpd_summary.py $(find $ev/ks -name "*.db" | head -1) "$tag: '$DRV --no-cpu-baseline' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats.md
 pass() {  # name, counters...
   name=$1; shift
