@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--points", type=int, default=N_PTS)
     ap.add_argument("--kind", default="odometry", choices=("odometry", "loop"), help="scene.make_pair kind of the synthetic pairs")
     ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 4; 1: one handle with three pair groups)")
+    ap.add_argument("--groups", type=int, default=1, help="pair groups (HIP streams) per handle when several handles are in flight")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
@@ -176,7 +177,7 @@ def main():
         bh = reg.BatchAPDGICP(params, device=local_rank)
         bh.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
         if H > 1:
-            bh.set_pair_groups(1)
+            bh.set_pair_groups(max(1, args.groups))
         batches.append(bh)
     batch = batches[0]
     pairs_arr = batch.make_pairs(pair_idx, guesses)

@@ -45,6 +45,28 @@ for tag, kw in CONFIGS.items():
                                 [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error])
         st["pairs"] += 1
     out[tag] = st
+# the throughput regime: one-group batch handles (k_nn_compact, neighbour keeping) on full-size pairs, GN-20 and LM
+for tag, kw in (("batch_8k_gn20", dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0,
+                                       azimuth_variance_deg=1.0)),
+                ("batch_8k_lm_launch", dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0))):
+    PB = max(8, NP // 4)
+    clouds, pairs, guesses, host = [], [], [], []
+    for i in range(PB):
+        src, tgt, _, guess = scene.make_pair(8192, 8192, scene.pair_seed(60, i), "odometry" if i % 2 else "loop")
+        clouds += [src, tgt]; pairs.append((2 * i, 2 * i + 1)); guesses.append(guess); host.append((src, tgt, guess))
+    b = reg.BatchAPDGICP(reg.default_params(**kw)); b.set_pair_groups(1)
+    b.set_clouds(0, clouds)
+    res = b.align(pairs, guesses)
+    st = dict(pairs=0, max_t_err_m=0.0, max_r_err_rad=0.0, info_equal=0, kernel=b.last_nn_kernel())
+    for i in range(PB):
+        o = R.RefAPDGICP(R.default_params(**kw)); o.setInputSource(host[i][0]); o.setInputTarget(host[i][1])
+        To = o.align(host[i][2])
+        te, re_ = scene.pose_error(To, reg.result_matrix(res[i]))
+        st["max_t_err_m"] = max(st["max_t_err_m"], te); st["max_r_err_rad"] = max(st["max_r_err_rad"], re_)
+        st["info_equal"] += int([int(res[i]["converged"]), int(res[i]["iterations"]), int(res[i]["n_linearize"]), int(res[i]["n_compute_error"])] ==
+                                [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error])
+        st["pairs"] += 1
+    out[tag] = st
 out["seconds"] = round(time.time() - t0, 1)
 out["note"] = ("GPU (libapdgicp_hip.so through the C ABI) vs oracle/apdgicp_ref.cpp; info = (converged, iterations, n_linearize, n_compute_error); "
                "a differing iteration count on an ill-conditioned LM run is possible (fp32 atan2f ulp, summation order) and is not a parity failure "
