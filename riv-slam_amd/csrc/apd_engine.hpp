@@ -249,6 +249,7 @@ class Engine {
   // `profile_stride`-th tick are timed, with a phase that rotates from align to align (unbiased over ticks)
   int profile_stride = 10, profile_phase = 0, cur_tick = 0;
   int last_ticks = 0;
+  int cur_active = 0;  // pairs still running in the tick being launched (0: all of them, e.g. the probes)
   const char* last_nn_kernel = "";  // the search kernel of the last launch (bench.py names it in its roofline object)
 
   // The opt-in for more than 64 KB of dynamic LDS is a property of the (function, device) pair, so every engine sets it
@@ -876,7 +877,8 @@ class Engine {
     // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) (last_nn_kernel = #KERNEL, hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w))
-    const long long tick_blocks = (long long)npairs * src_blocks;  // the whole batch: all groups tick together
+    // all groups tick together; an LM batch shrinks to its slow pairs, and those few get the wave split of a small batch
+    const long long tick_blocks = (long long)(cur_active > 0 ? cur_active : npairs) * src_blocks;
     // large (dense) targets: a wave's 64 points touch many more groups (10.8 instead of 1.7 per wave for 100k x 500k), so
     // splitting the scans over 4 waves still pays with a few thousand blocks (r01: 0.170 -> 0.143 ms per iteration)
     const bool big_target = nmax_tgt > SORT_LDS_MAX_N;
@@ -1073,6 +1075,7 @@ class Engine {
         }
         cov_group_off.clear();
       }
+      cur_active = n_active;
       {
         roctx_range rr("apdgicp:ticks");
         for (int t = 0; t < todo; t++, cur_tick++)
@@ -1081,6 +1084,7 @@ class Engine {
             APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
           }
       }
+      cur_active = 0;
       for (int g = 1; g < ng; g++) {
         APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
         APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
