@@ -745,6 +745,19 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
                 assert st[6] == 0
             elif kw is gn and "APDGICP_NN_SKIN_REL" not in env:
                 assert st[6] > 0.3 * 18 * sum(len(clouds[2 * i]) for i in range(6)), st   # most points, most iterations
+    # large targets (> 16384 points: the super-box level) through the one-group path: k_nn_compact's waves walk the batches of
+    # group boxes on their own, without block barriers -- same records as the multi-wave k_nn_pruned blocks and as no keeping
+    s_, t_, _, g_ = scene.make_pair(6000, 40_000, scene.pair_seed(21, 60), kind)
+    s2, t2, _, g2 = scene.make_pair(20_000, 30_000, scene.pair_seed(21, 61), kind)
+    want = None
+    for env, one_group in (({}, False), ({}, True), ({"APDGICP_NN_SKIN": "0"}, True), ({"APDGICP_NN_COMPACT": "0"}, True)):
+        b = _handle_with_env(reg, reg.BatchAPDGICP, env, **dict(gn, max_iterations=8))
+        if one_group:
+            b.set_pair_groups(1)
+        b.set_clouds(0, [s_, t_, s2, t2])
+        got = b.align([(0, 1), (2, 3)], [g_, g2]).tobytes()
+        want = want or got
+        assert got == want, (env, one_group)
     # a single handle: correspondences, distances and H, b after the last linearize of an align are those of a cold search
     s_, t_, _, g_ = scene.make_pair(8192, 8192, scene.pair_seed(21, 50), kind)
     a = _handle_with_env(reg, reg.FastAPDGICP, {}, **gn)
