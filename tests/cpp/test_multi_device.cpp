@@ -10,6 +10,7 @@
 #include <cstring>
 #include <vector>
 
+#include "information_matrix_hip.hpp"
 #include "loop_verifier_hip.hpp"
 #include "sharded_batch_hip.hpp"
 
@@ -111,7 +112,15 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "verifier: %s\n", apdgicp_last_error());
     return 6;
   }
-  std::printf("world %d pairs %d sharded_equals_single %d gathered_on_all_ranks %d loop_best %d loop_score %.17g candidates %zu\n", D, np, same, all_ranks,
-              match.best, match.best_score, cand.size());
+  // ---- edge information of pair 0 at its registered pose (InformationMatrixCalculator::calc_information_matrix: cloud1 = target)
+  fast_gicp::InformationMatrixCalculatorHip infcalc;
+  double relpose[16], inf[36];
+  for (int q = 0; q < 16; q++) relpose[q] = (double)single[0].T[q];
+  const auto& c1 = clouds[(size_t)pairs[0].target_cloud];
+  const auto& c2 = clouds[(size_t)pairs[0].source_cloud];
+  const double fs = infcalc.calc_fitness_score(c1.xyz, c1.n, c2.xyz, c2.n, 12, relpose);
+  infcalc.calc_information_matrix(c1.xyz, c1.n, c2.xyz, c2.n, 12, relpose, inf);
+  std::printf("world %d pairs %d sharded_equals_single %d gathered_on_all_ranks %d loop_best %d loop_score %.17g candidates %zu fitness %.17g inf00 %.17g inf33 %.17g\n", D,
+              np, same, all_ranks, match.best, match.best_score, cand.size(), fs, inf[0], inf[3 + 6 * 3]);
   return same && all_ranks ? 0 : 1;
 }

@@ -78,3 +78,12 @@ def test_sharded_cpp_equals_single_handle_and_python_verifier(scene, pkg, tmp_pa
     assert int(vals["loop_best"]) == (loop.candidate if loop else -1)
     if loop:
         assert float(vals["loop_score"]) == loop.fitness_score
+    # InformationMatrixCalculatorHip (C++) == the Python mirror on pair 0 at the registered pose
+    im = importlib.import_module("riv-slam_amd.information_matrix")
+    single = reg.BatchAPDGICP(reg.default_params(**kw))
+    single.set_clouds(0, clouds)
+    T0 = reg.result_matrix(single.align(pairs, guesses)[0])
+    calc = im.InformationMatrixCalculator()
+    fs = calc.calc_fitness_score(clouds[pairs[0][1]], clouds[pairs[0][0]], T0)
+    inf = im.information_from_fitness(calc.params, fs)
+    assert float(vals["fitness"]) == fs and float(vals["inf00"]) == inf[0, 0] and float(vals["inf33"]) == inf[3, 3]
