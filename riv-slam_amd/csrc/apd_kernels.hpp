@@ -1048,7 +1048,10 @@ __global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, 
     cci[pos] = make_int2((int)s0.bestc, i | (s0.hinted ? 0 : 1 << 30));
   }
   __syncthreads();
-  if (w.stats && lane == 0) atomicAdd(w.stats + 6, (unsigned long long)__popcll(__ballot(valid && s0.kept)));
+  {
+    const unsigned long long nkept = (unsigned long long)__popcll(__ballot(valid && s0.kept));  // (the ballot needs every lane)
+    if (w.stats && lane == 0) atomicAdd(w.stats + 6, nkept);
+  }
   if (wid * 64 >= total) {  // nothing left for this wave
     if (w.stats && lane == 0) atomicAdd(w.stats + 3, 1ull);
     return;

@@ -7,6 +7,7 @@ last ulp and the APD model amplifies it near the +x axis); final transforms <= 1
 (north_star) -- asserted much tighter where the run is well conditioned.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -725,8 +726,10 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
             {"APDGICP_NN_W": "4"}, {"APDGICP_NN_MODE": "brute"},
             # one pair group per handle = the throughput regime of bench.py: k_nn_compact (blocks of 256 points that pack the
             # points still searching into fewer waves), and the same regime with one-wave blocks of k_nn_pruned
-            {"ONE_GROUP": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_COMPACT": "0"}, {"ONE_GROUP": "1", "APDGICP_NN_SKIN": "0"},
-            {"ONE_GROUP": "1", "APDGICP_NN_SKIN_REL": "0.3", "APDGICP_NN_SKIN_ABS": "0.03"})
+            # (APDGICP_NN_W=1: six pairs are too few for the engine to choose that regime by itself)
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"},
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"},
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN_REL": "0.3", "APDGICP_NN_SKIN_ABS": "0.03"}, {"APDGICP_NN_W": "1"})
     for kw in (gn, lm):
         want = None
         for env in envs:
@@ -743,14 +746,16 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
             assert got == want, (env, kw is gn)
             if env.get("APDGICP_NN_SKIN") == "0" or env.get("APDGICP_NN_MODE") == "brute":
                 assert st[6] == 0
-            elif kw is gn and "APDGICP_NN_SKIN_REL" not in env:
+            elif kw is gn and "APDGICP_NN_SKIN_REL" not in env and not any(os.environ.get(v) for v in (   # (tools/knob_matrix.sh switches that turn keeping off)
+                    "APDGICP_NN_SKIN", "APDGICP_NN_SKIN_REL", "APDGICP_NN_GATE_CAP", "APDGICP_NN_MODE")):
                 assert st[6] > 0.3 * 18 * sum(len(clouds[2 * i]) for i in range(6)), st   # most points, most iterations
     # large targets (> 16384 points: the super-box level) through the one-group path: k_nn_compact's waves walk the batches of
     # group boxes on their own, without block barriers -- same records as the multi-wave k_nn_pruned blocks and as no keeping
     s_, t_, _, g_ = scene.make_pair(6000, 40_000, scene.pair_seed(21, 60), kind)
     s2, t2, _, g2 = scene.make_pair(20_000, 30_000, scene.pair_seed(21, 61), kind)
     want = None
-    for env, one_group in (({}, False), ({}, True), ({"APDGICP_NN_SKIN": "0"}, True), ({"APDGICP_NN_COMPACT": "0"}, True)):
+    for env, one_group in (({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True),
+                           ({"APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"}, True)):
         b = _handle_with_env(reg, reg.BatchAPDGICP, env, **dict(gn, max_iterations=8))
         if one_group:
             b.set_pair_groups(1)
