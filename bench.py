@@ -355,6 +355,8 @@ def main():
                         else:
                             os.environ[k_] = v_
                 bb.set_profiling(True)
+                if H > 1 and "APDGICP_NN_MODE" not in env:
+                    bb.set_pair_groups(1)      # the timed handles' regime (k_nn_compact)
                 for _ in range(2):
                     bb.set_clouds(0, d_clouds)
                     bb.align_async(pairs_arr)
