@@ -201,6 +201,7 @@ class Engine {
   bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
+  bool fold_init_cfg = true, fold_init = false, tickets_dirty = true;  // APDGICP_FOLD_INIT=0: k_init_state in front of every align
   bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
   DevBuf b_ticket;
   // pair groups: the tick kernels of each group run on their own stream so that one group's short serial
@@ -295,6 +296,7 @@ class Engine {
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
+    fold_init_cfg = env_int("APDGICP_FOLD_INIT", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
     nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
@@ -795,7 +797,7 @@ class Engine {
     APD_TRY(d_results.ensure(n * sizeof(ResultRec) + (n + 1) * sizeof(int)));  // records, then the status words of the poll
     APD_TRY(d_pairs.upload(h_pairs.data(), n * sizeof(PairDesc), stream));
     (void)with_guess;
-    APD_TRY(d_guess.upload(guesses.data(), guesses.size() * sizeof(float), stream));
+    APD_TRY(upload_guesses(guesses.data(), n));
 
     // launch shape of the NN kernel: S sources per lane, T target splits (tunable for experiments)
     const int nchunks_min = 1;
@@ -839,13 +841,25 @@ class Engine {
     work.errpart = b_errpart.as<double>();
     work.stats = d_stats.as<unsigned long long>();
     APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
+    if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
+    work.init = nullptr;
     work.pair0 = 0;
     work.npairs = npairs;
     return 0;
   }
 
   // A launch covers the pairs [p0, p0 + np) on stream `st`.
+  // L:56 x0 = guess.cast<double>(): widened here, so that the kernels read the pose through scalar loads
+  std::vector<Rigid> h_guess;
+  int upload_guesses(const float* g /* n x 16, column-major */, int64_t n) {
+    h_guess.resize((size_t)n);
+    for (int64_t p = 0; p < n; p++)
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) h_guess[p].m[4 * i + j] = (double)g[16 * p + i + 4 * j];
+    return d_guess.upload(h_guess.data(), h_guess.size() * sizeof(Rigid), stream);
+  }
+
   struct Span {
     int p0, np;
     hipStream_t st;
@@ -874,6 +888,7 @@ class Engine {
     Work w = work;
     w.pair0 = sp.p0;
     w.cap = nn_cap;
+    w.init = fold_init && cur_tick == 0 ? d_guess.as<Rigid>() : nullptr;
     // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) (last_nn_kernel = #KERNEL, hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w))
@@ -911,6 +926,7 @@ class Engine {
     const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
+    w.init = fold_init && cur_tick == 0 && mode == 2 ? d_guess.as<Rigid>() : nullptr;
     if (mode == 2)
       hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
                          consts(), mode);
@@ -1007,6 +1023,7 @@ class Engine {
     if (profile_nn) APD_TRY(collect_nn_profile());
     if (h_status[pending_npairs]) {
       const int flag = h_status[pending_npairs];
+      tickets_dirty = true;
       APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
       if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
     }
@@ -1040,10 +1057,16 @@ class Engine {
     // every align starts cold: k_init_state zeroes n_lin, and the search ignores the hint array until the first linearize of
     // this align has rewritten it (hints of an earlier run would still be valid bounds, but nothing observable -- timing
     // included -- may depend on call history)
-    hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<float>(), npairs,
-                       params.max_iterations, b_ticket.as<int>());
     const bool lm = params.optimizer == APDGICP_OPT_LM;
     const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
+    // the fused optimiser builds the state in the last block of the first k_linearize (Work::init): one launch less per
+    // align.  The arrival counters reset themselves; only a run that ended in an error may have left them mid-count
+    fold_init = fold_init_cfg && fuse_lm && nn_pruned && tick_cap > 0 && !tickets_dirty;
+    if (!fold_init) {
+      hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<Rigid>(), npairs,
+                         params.max_iterations, b_ticket.as<int>());
+      tickets_dirty = false;
+    }
     // LM: the loop length is data dependent, poll every few ticks.  GN runs max_iterations ticks unless a
     // pair hits an exactly-zero step, so one poll at the end is enough.
     // LM polls after 1, then 2, then every 4 ticks: with the shipped parameters most registrations converge in 1-3
@@ -1132,6 +1155,7 @@ class Engine {
       }
       if (h_status[npairs]) {
         const int flag = h_status[npairs];
+        tickets_dirty = true;
         APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
         work.active = nullptr;
         if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));

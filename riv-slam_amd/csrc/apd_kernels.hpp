@@ -101,7 +101,25 @@ struct Work {
                                // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
+  const Rigid* init;           // non-null in the FIRST tick of an align (fused optimiser): the guesses, one pose per pair.  The
+                               // search and the per-point pass take their pose from there and run cold, and the last block of
+                               // k_linearize builds the pair's state from scratch (L:56-59) instead of loading it: no k_init_state launch
 };
+
+// L:56-59: x0 = guess.cast<double>() (the host widens it: a pose read through a uniform pointer stays in scalar registers),
+// lm_lambda_ = -1, converged_ = false
+__device__ __forceinline__ void init_pair_state(PairState& s, const Rigid* g /* or null: identity */, int max_iterations) {
+  s.x0 = g ? *g : rigid_identity();
+  s.xi = s.x0;
+  s.delta = rigid_identity();
+  for (int q = 0; q < 36; q++) s.H[q] = 0.0, s.final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
+  for (int q = 0; q < 6; q++) s.b[q] = 0.0, s.d[q] = 0.0;
+  s.y0 = s.yi = 0.0;
+  s.lambda = -1.0;
+  s.nu = 2.0;
+  s.status = max_iterations > 0 ? ST_NEED_LIN : ST_DONE;
+  s.converged = 0, s.iter = 0, s.inner = 0, s.n_lin = 0, s.n_err = 0, s.failed = 0, s.n_matched = 0;
+}
 
 __device__ __forceinline__ int pair_of(const Work& w, unsigned block) { return w.active ? w.active[w.pair0 + block] : w.pair0 + (int)block; }
 
@@ -974,10 +992,10 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
-  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
-  const bool cold = st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
+  const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
+  const bool cold = w.init || st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
   const PairDesc pd = pairs[pair];
-  const Rigid T0 = st[pair].x0;
+  const Rigid T0 = *(w.init ? w.init + pair : &st[pair].x0);
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1014,10 +1032,10 @@ __global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, 
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
-  const int status = st[pair].status;
-  const bool cold = st[pair].n_lin == 0;
+  const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;
+  const bool cold = w.init || st[pair].n_lin == 0;
   const PairDesc pd = pairs[pair];
-  const Rigid T0 = st[pair].x0;
+  const Rigid T0 = *(w.init ? w.init + pair : &st[pair].x0);
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, M = tgt.n, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -2038,9 +2056,9 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
-  const int status = st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
+  const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
-  const Rigid T = st[pair].x0;
+  const Rigid T = *(w.init ? w.init + pair : &st[pair].x0);
   if (status != ST_NEED_LIN) return;
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
@@ -2093,7 +2111,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
     if (last_block_of_pair(w.ticket + pair, nblk, tid)) {
       static_assert(sizeof(PairState) / 8 <= LIN_BLK, "one state word per thread");
-      const double word = tid < (int)(sizeof(PairState) / 8) ? ((const double*)&st[pair])[tid] : 0.0;  // in flight with the rows
+      const double word = (!w.init && tid < (int)(sizeof(PairState) / 8)) ? ((const double*)&st[pair])[tid] : 0.0;  // in flight with the rows
       const double* rows = w.blkpart + (size_t)pair * w.nblk_max * kRed;
       if (nblk <= kSerialRows) {
         if (tid < 29) red[tid] = sum_rows_coh(rows + tid, nblk, kRed);
@@ -2112,9 +2130,10 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
           red[tid] = v;
         }
       }
-      if (tid < (int)(sizeof(PairState) / 8)) ((double*)&ls)[tid] = word;
+      if (!w.init && tid < (int)(sizeof(PairState) / 8)) ((double*)&ls)[tid] = word;
       __syncthreads();
       if (tid == 0) {
+        if (w.init) init_pair_state(ls, w.init + pair, cst.max_iterations);  // first tick: the state starts here
         fill_from_sums(ls, red);
         lm_after_gather(ls, cst);
       }
@@ -2375,28 +2394,12 @@ __global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false
-__global__ void k_init_state(PairState* st, const float* guesses /* n x 16 column-major, or null */, int npairs, int max_iterations,
+__global__ void k_init_state(PairState* st, const Rigid* guesses /* one per pair, or null */, int npairs, int max_iterations,
                              int* ticket /* [2][npairs] arrival counters of the fused optimiser step */) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
   ticket[p] = 0, ticket[npairs + p] = 0;  // (a run that ended in an error may have left them mid-count)
-  PairState& s = st[p];
-  if (guesses) {
-    const float* g = guesses + 16 * p;
-    for (int r = 0; r < 3; r++)
-      for (int c2 = 0; c2 < 4; c2++) s.x0.m[4 * r + c2] = (double)g[r + 4 * c2];
-  } else {
-    s.x0 = rigid_identity();
-  }
-  s.xi = s.x0;
-  s.delta = rigid_identity();
-  for (int q = 0; q < 36; q++) s.H[q] = 0.0, s.final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
-  for (int q = 0; q < 6; q++) s.b[q] = 0.0, s.d[q] = 0.0;
-  s.y0 = s.yi = 0.0;
-  s.lambda = -1.0;
-  s.nu = 2.0;
-  s.status = max_iterations > 0 ? ST_NEED_LIN : ST_DONE;
-  s.converged = 0, s.iter = 0, s.inner = 0, s.n_lin = 0, s.n_err = 0, s.failed = 0, s.n_matched = 0;
+  init_pair_state(st[p], guesses ? guesses + p : nullptr, max_iterations);
 }
 
 // batch probe support: x0 of every pair := T[pair] (column-major float 4x4), status := NEED_LIN

@@ -300,7 +300,7 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
     else identity16(g);
     APD_TRY(ensure_pair(h, g));
     Engine& e = h->eng;
-    APD_TRY(e.d_guess.upload(g, sizeof(g), e.stream));  // no-op when ensure_pair has just uploaded it
+    APD_TRY(e.upload_guesses(g, 1));  // no-op when ensure_pair has just uploaded it
     APD_TRY(e.run_align());
     if (const ResultRec* r = e.host_results()) {  // came home with the last poll
       memcpy(out, r, sizeof(apdgicp_result));
