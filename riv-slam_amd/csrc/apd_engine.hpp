@@ -165,7 +165,20 @@ class Engine {
     bool sorted = false;
     bool cov_valid = false;
     uint64_t token = 0;
-    void release_all() { opts.release(), pts.release(), perm.release(), cbox.release(), gbox.release(), cov.release(); }
+    // a host cloud of the tiled-sort size class stays in this pinned buffer until the sort has read it (TileJob::staged)
+    char* stage_p = nullptr;
+    char* stage_dev = nullptr;
+    size_t stage_cap = 0;
+    bool staged = false;            // set_cloud left the points there, the next sort reads them
+    bool stage_pending = false;     // a sort that reads the buffer has been enqueued ...
+    hipEvent_t stage_wait = nullptr;  // ... in front of this event (the poll event of the align behind it; not owned)
+    void release_all() {
+      opts.release(), pts.release(), perm.release(), cbox.release(), gbox.release(), cov.release();
+      hipError_t e = hipSuccess;
+      if (stage_p) e = hipHostFree(stage_p);
+      (void)e;
+      stage_p = stage_dev = nullptr, stage_cap = 0, staged = stage_pending = false, stage_wait = nullptr;
+    }
   };
 
   int device = 0;
@@ -184,6 +197,8 @@ class Engine {
   DevBuf d_keys, d_box6, d_stats;
   CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_tilejobs[3], d_active;
   DevBuf d_tkeys;          // sorted tiles of the clouds being sorted by the tiled path
+  int n_stage_pending = 0;   // clouds whose pinned copy a sort has been enqueued for, no align behind it yet
+  bool direct_stage = true;  // host clouds of the tiled-sort sizes are read by the sort from pinned memory (APDGICP_DIRECT_STAGE=0: copied first)
   bool sort_tiled = true;  // 2048 < n <= 16384: four tile blocks + merge + boxes (APDGICP_SORT_TILED=0: one block per cloud)
   std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
   bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
@@ -304,6 +319,7 @@ class Engine {
     if (const char* v = getenv("APDGICP_NN_SKIN_ABS")) nn_skin_abs = std::max(0.f, (float)atof(v));
     sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
     sort_tiled = env_int("APDGICP_SORT_TILED", 1) != 0;
+    direct_stage = env_int("APDGICP_DIRECT_STAGE", 1) != 0;
     // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
     // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
     nn_W = env_int("APDGICP_NN_W", 0);
@@ -422,7 +438,47 @@ class Engine {
     if ((size_t)n * 16 > c.opts.cap) APD_HIP(hipStreamSynchronize(stream));
     APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
-    if (!on_device) {
+    c.staged = false;
+    if (!on_device && direct_stage && sort_in_registers && sort_tiled && n > 2048 && n <= SORT_LDS_MAX_N) {
+      // scan-sized host clouds: packed into the slot's own pinned buffer, bounding box behind the points, and the sort reads
+      // them from there (k_sort_tiles).  Nothing is enqueued here, not even an event: the buffer is rewritten after the poll
+      // of the align that followed the sort (an event between the sort's launches costs 6 us of the frame), and a cloud
+      // replaced with no align in between waits for the stream
+      if (c.stage_pending) {
+        if (c.stage_wait) APD_HIP(hipEventSynchronize(c.stage_wait));
+        else APD_HIP(hipStreamSynchronize(stream));
+        c.stage_pending = false, c.stage_wait = nullptr;
+      }
+      const size_t need = ((size_t)n + 2) * 16;
+      if (need > c.stage_cap) {
+        if (c.stage_p) APD_HIP(hipHostFree(c.stage_p));
+        c.stage_p = c.stage_dev = nullptr, c.stage_cap = 0;
+        const size_t cap = std::max<size_t>(need * 5 / 4, 1 << 16);
+        APD_HIP(hipHostMalloc((void**)&c.stage_p, cap, hipHostMallocDefault));
+        APD_HIP(hipHostGetDevicePointer((void**)&c.stage_dev, c.stage_p, 0));
+        c.stage_cap = cap;
+      }
+      float4* dst = (float4*)c.stage_p;
+      const float inf = std::numeric_limits<float>::infinity();
+      // four independent running boxes (a single one is a chain of dependent min/max, twice the time of the packing itself);
+      // `v < lo ? v : lo` leaves a NaN coordinate out, like the device's fminf
+      float lo[4][3], hi[4][3];
+      for (int u = 0; u < 4; u++)
+        for (int a = 0; a < 3; a++) lo[u][a] = inf, hi[u][a] = -inf;
+      auto put = [&](int64_t q, int u) {
+        const float* sp = (const float*)(raw + q * stride_bytes);
+        const float v[3] = {sp[0], sp[1], sp[2]};
+        dst[q] = make_float4(v[0], v[1], v[2], 1.0f);
+        for (int a = 0; a < 3; a++) lo[u][a] = v[a] < lo[u][a] ? v[a] : lo[u][a], hi[u][a] = v[a] > hi[u][a] ? v[a] : hi[u][a];
+      };
+      int64_t q = 0;
+      for (; q + 4 <= n; q += 4) put(q, 0), put(q + 1, 1), put(q + 2, 2), put(q + 3, 3);
+      for (; q < n; q++) put(q, 0);
+      for (int u = 1; u < 4; u++)
+        for (int a = 0; a < 3; a++) lo[0][a] = std::min(lo[0][a], lo[u][a]), hi[0][a] = std::max(hi[0][a], hi[u][a]);
+      dst[n] = make_float4(lo[0][0], lo[0][1], lo[0][2], 0.f), dst[n + 1] = make_float4(hi[0][0], hi[0][1], hi[0][2], 0.f);
+      c.staged = true;
+    } else if (!on_device) {
       // Host clouds (the odometry nodelet hands over pcl::PointXYZI, 32 bytes a point): the three coordinates are packed into
       // {x, y, z, 1} on the host, straight into one of two pinned staging buffers, and ONE asynchronous copy puts them where
       // the pack kernel would have.  The caller's buffer is free when this returns, and nothing waits for the GPU: a staging
@@ -535,6 +591,7 @@ class Engine {
           const int cls = c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2;
           TileJob tjb;
           tjb.job = j, tjb.keys = (unsigned long long*)tkeys_bytes /* offset, fixed up below */, tjb.nt = 1024 << cls, tjb.pad_ = 0;
+          tjb.staged = c.staged ? (const float4*)c.stage_dev : nullptr;
           tkeys_bytes += (size_t)4 * tjb.nt * 8;
           tilejobs[cls].push_back(tjb);
         } else if (c.n > 2048 && sort_in_registers) {  // k_sort_cloud_reg<E>: 1024*E/2 < n <= 1024*E
@@ -585,6 +642,8 @@ class Engine {
         if (cls == 0) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
         else if (cls == 1) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
         else hipLaunchKernelGGL(k_sort_tiles<4>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
+        for (Cloud& c : clouds)  // the pinned copies are free again behind this launch
+          if (c.staged && c.sorted && c.n > (nt << 1) && c.n <= (nt << 2)) c.staged = false, c.stage_pending = true, c.stage_wait = nullptr, n_stage_pending++;
         hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned)(4 * nt / SORT_BLK), cnt), dim3(SORT_BLK), (size_t)4 * nt * 8, stream, dj);
         hipLaunchKernelGGL(k_boxes_sorted, dim3((unsigned)(((nmax_c + 15) / 16 + 255) / 256), cnt), dim3(256), 0, stream, dj);
         APD_HIP(hipGetLastError());
@@ -1129,6 +1188,11 @@ class Engine {
                          d_errflag.as<int>(), results_on_host ? (ResultRec*)h_poll_dev : (ResultRec*)nullptr,
                          (int*)(h_poll_dev + ((char*)h_status - h_poll)), spin ? (int*)(h_poll_dev + ((char*)h_seq - h_poll)) : (int*)nullptr, poll_seq);
       APD_HIP(hipEventRecord(ev_poll, stream));
+      if (n_stage_pending) {  // pinned clouds read by a sort in front of this event
+        for (Cloud& c : clouds)
+          if (c.stage_pending && !c.stage_wait) c.stage_wait = ev_poll;
+        n_stage_pending = 0;
+      }
       pending_spin = spin;
       if (defer_poll && ticks == tick_cap && ticks == todo) {  // the only chunk: nothing on the host depends on its outcome
         pending = true, pending_npairs = npairs, pending_ticks = (int)ticks;

@@ -333,6 +333,10 @@ struct TileJob {
   unsigned long long* keys;  // [4][NT] sorted tiles
   int nt;                    // tile size = padded size / 4 (1024, 2048 or 4096)
   int pad_;
+  const float4* staged;      // null, or the cloud as the HOST packed it, in pinned memory: n points, then the bounding box
+                             // (low corner, high corner).  The tile blocks read it from there -- each its own quarter -- and
+                             // write the device copy job.pts themselves: no copy in front of the sort (8.6 us on the copy
+                             // engine + 12.7 us until the first kernel starts behind it, measured on the odometry frame)
 };
 
 template <int E>
@@ -346,29 +350,45 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_tiles(const TileJob* jobs) {
   const int n = job.n, tid = threadIdx.x, tile = blockIdx.x;
   const float inf = __builtin_inff();
   float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
-  for (int i = tid; i < n; i += SORT_BLK) {
-    const float4 q = job.pts[i];
-    lx = fminf(lx, q.x), ly = fminf(ly, q.y), lz = fminf(lz, q.z);
-    hx = fmaxf(hx, q.x), hy = fmaxf(hy, q.y), hz = fmaxf(hz, q.z);
+  float4 mine[E];
+  if (tj.staged) {  // the host reduced the box while it packed the points (min and max are exact: the same box)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = tile * NT + tid * E + e;
+      if (i < n) mine[e] = tj.staged[i];
+    }
+    const float4 lo = tj.staged[n], hi = tj.staged[n + 1];
+    lx = lo.x, ly = lo.y, lz = lo.z, hx = hi.x, hy = hi.y, hz = hi.z;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = tile * NT + tid * E + e;
+      if (i < n) const_cast<float4*>(job.pts)[i] = mine[e];
+    }
+  } else {
+    for (int i = tid; i < n; i += SORT_BLK) {
+      const float4 q = job.pts[i];
+      lx = fminf(lx, q.x), ly = fminf(ly, q.y), lz = fminf(lz, q.z);
+      hx = fmaxf(hx, q.x), hy = fmaxf(hy, q.y), hz = fmaxf(hz, q.z);
+    }
+    lx = block_reduce_minmax(lx, false, red, tid, SORT_BLK);
+    ly = block_reduce_minmax(ly, false, red, tid, SORT_BLK);
+    lz = block_reduce_minmax(lz, false, red, tid, SORT_BLK);
+    hx = block_reduce_minmax(hx, true, red, tid, SORT_BLK);
+    hy = block_reduce_minmax(hy, true, red, tid, SORT_BLK);
+    hz = block_reduce_minmax(hz, true, red, tid, SORT_BLK);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = tile * NT + tid * E + e;
+      if (i < n) mine[e] = job.pts[i];
+    }
   }
-  lx = block_reduce_minmax(lx, false, red, tid, SORT_BLK);
-  ly = block_reduce_minmax(ly, false, red, tid, SORT_BLK);
-  lz = block_reduce_minmax(lz, false, red, tid, SORT_BLK);
-  hx = block_reduce_minmax(hx, true, red, tid, SORT_BLK);
-  hy = block_reduce_minmax(hy, true, red, tid, SORT_BLK);
-  hz = block_reduce_minmax(hz, true, red, tid, SORT_BLK);
   const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
   const float scale = 1023.f / ext;
   unsigned long long key[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const int i = tile * NT + tid * E + e;
-    if (i < n) {
-      const float4 q = job.pts[i];
-      key[e] = ((unsigned long long)morton30(q.x, q.y, q.z, lx, ly, lz, scale) << 32) | (unsigned)i;
-    } else {
-      key[e] = ~0ull;
-    }
+    key[e] = i < n ? ((unsigned long long)morton30(mine[e].x, mine[e].y, mine[e].z, lx, ly, lz, scale) << 32) | (unsigned)i : ~0ull;
   }
 #pragma unroll
   for (int k = 2; k <= NT; k <<= 1) {

@@ -66,7 +66,7 @@ static int run_protocols(const float* s, int ns, const float* t, int nt, const f
   }
   std::printf("{\"points\": [%d, %d], \"iterations\": %d, ", ns, nt, reg.lastResult().iterations + 1);
   // ---- align.cpp: single
-  std::vector<double> single, multi, reuse, odom;
+  std::vector<double> single, multi, reuse, odom, odom_src;
   for (int r = 0; r < 30; r++) {
     const double t1 = now_ms();
     reg.clearTarget(), reg.clearSource();
@@ -102,10 +102,11 @@ static int run_protocols(const float* s, int ns, const float* t, int nt, const f
     const double t1 = now_ms();
     reg.setInputTarget(target);             // matching() sets the keyframe on every frame: pointer-equal, cached
     reg.setInputSource(frames[i & 1]);
+    const double t2 = now_ms();
     reg.align(*aligned, g);
     const auto T = reg.getFinalTransformation();
     (void)T;
-    if (i >= 20) odom.push_back(now_ms() - t1);
+    if (i >= 20) odom.push_back(now_ms() - t1), odom_src.push_back(t2 - t1);
   }
   stats(single, "align_cpp_single_ms", false);
   stats(multi, "align_cpp_100_times_per_call_ms", false);
@@ -113,6 +114,7 @@ static int run_protocols(const float* s, int ns, const float* t, int nt, const f
   stats(reuse, "align_cpp_100_times_reuse_per_call_ms", false);
   std::printf("\"align_cpp_100_times_reuse_total_ms\": %.3f, ", reuse_total);
   stats(odom, "odometry_frame_ms", false);
+  stats(odom_src, "odometry_set_source_ms", false);  // of the frame: handing over the new scan (returns before the device has it)
   std::printf("\"converged\": %d, \"inlier_fraction\": %.6f}\n", reg.hasConverged() ? 1 : 0, reg.inlierFraction(0.5));
   return 0;
 }

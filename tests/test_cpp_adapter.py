@@ -16,7 +16,7 @@ def build_exe():
     g.build()
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     lib_dir = os.path.join(ROOT, "riv-slam_amd")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "pcl_shim"), "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "tests", "pcl_shim"), "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "riv-slam_amd", "cpp"), os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp"),
            "-L", lib_dir, "-lapdgicp_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", EXE]
     subprocess.check_call(cmd)
