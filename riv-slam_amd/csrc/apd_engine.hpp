@@ -172,12 +172,14 @@ class Engine {
     bool staged = false;            // set_cloud left the points there, the next sort reads them
     bool stage_pending = false;     // a sort that reads the buffer has been enqueued ...
     hipEvent_t stage_wait = nullptr;  // ... in front of this event (the poll event of the align behind it; not owned)
+    volatile int* stage_seq_word = nullptr;  // ... and of the poll that posts stage_seq_val (or a later number) here
+    int stage_seq_val = 0;
     void release_all() {
       opts.release(), pts.release(), perm.release(), cbox.release(), gbox.release(), cov.release();
       hipError_t e = hipSuccess;
       if (stage_p) e = hipHostFree(stage_p);
       (void)e;
-      stage_p = stage_dev = nullptr, stage_cap = 0, staged = stage_pending = false, stage_wait = nullptr;
+      stage_p = stage_dev = nullptr, stage_cap = 0, staged = stage_pending = false, stage_wait = nullptr, stage_seq_word = nullptr;
     }
   };
 
@@ -216,6 +218,8 @@ class Engine {
   bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
+  bool fold_poll_cfg = true, post_tick = false;  // APDGICP_FOLD_POLL=0: k_finalize behind every chunk of ticks
+  CachedTable d_post;
   bool fold_init_cfg = true, fold_init = false, tickets_dirty = true;  // APDGICP_FOLD_INIT=0: k_init_state in front of every align
   bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
   DevBuf b_ticket;
@@ -312,6 +316,7 @@ class Engine {
     knn_pruned = !(m && std::string(m) == "brute");
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     fold_init_cfg = env_int("APDGICP_FOLD_INIT", 1) != 0;
+    fold_poll_cfg = env_int("APDGICP_FOLD_POLL", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
     nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
@@ -349,7 +354,7 @@ class Engine {
     e = hipSetDevice(device);
     if (stream) e = hipStreamSynchronize(stream);
     for (auto& c : clouds) c.release_all();
-    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_tilejobs[0], &d_tilejobs[1], &d_tilejobs[2], &d_active}) t->dev.release();
+    for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_tilejobs[0], &d_tilejobs[1], &d_tilejobs[2], &d_active, &d_post}) t->dev.release();
     d_tkeys.release();
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
@@ -445,9 +450,13 @@ class Engine {
       // of the align that followed the sort (an event between the sort's launches costs 6 us of the frame), and a cloud
       // replaced with no align in between waits for the stream
       if (c.stage_pending) {
-        if (c.stage_wait) APD_HIP(hipEventSynchronize(c.stage_wait));
+        // (the host has usually SEEN that poll already -- it spun on the word; asking the event costs 6 us when the kernel
+        // that posted the word has not retired yet)
+        const bool seen = c.stage_seq_word && (int)(*c.stage_seq_word - c.stage_seq_val) >= 0;
+        if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+        else if (c.stage_wait) APD_HIP(hipEventSynchronize(c.stage_wait));
         else APD_HIP(hipStreamSynchronize(stream));
-        c.stage_pending = false, c.stage_wait = nullptr;
+        c.stage_pending = false, c.stage_wait = nullptr, c.stage_seq_word = nullptr;
       }
       const size_t need = ((size_t)n + 2) * 16;
       if (need > c.stage_cap) {
@@ -643,7 +652,8 @@ class Engine {
         else if (cls == 1) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
         else hipLaunchKernelGGL(k_sort_tiles<4>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
         for (Cloud& c : clouds)  // the pinned copies are free again behind this launch
-          if (c.staged && c.sorted && c.n > (nt << 1) && c.n <= (nt << 2)) c.staged = false, c.stage_pending = true, c.stage_wait = nullptr, n_stage_pending++;
+          if (c.staged && c.sorted && c.n > (nt << 1) && c.n <= (nt << 2))
+            c.staged = false, c.stage_pending = true, c.stage_wait = nullptr, c.stage_seq_word = nullptr, n_stage_pending++;
         hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned)(4 * nt / SORT_BLK), cnt), dim3(SORT_BLK), (size_t)4 * nt * 8, stream, dj);
         hipLaunchKernelGGL(k_boxes_sorted, dim3((unsigned)(((nmax_c + 15) / 16 + 255) / 256), cnt), dim3(256), 0, stream, dj);
         APD_HIP(hipGetLastError());
@@ -903,6 +913,7 @@ class Engine {
     if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
     work.init = nullptr;
+    work.post = nullptr, work.post_seq = 0;
     work.pair0 = 0;
     work.npairs = npairs;
     return 0;
@@ -999,6 +1010,7 @@ class Engine {
     const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
+    if (fuse && post_tick) w.post = d_post.as<PollPost>(), w.post_seq = poll_seq;
     hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
                        consts(), fuse ? 1 : 0);
     return 0;
@@ -1160,20 +1172,6 @@ class Engine {
         cov_group_off.clear();
       }
       cur_active = n_active;
-      {
-        roctx_range rr("apdgicp:ticks");
-        for (int t = 0; t < todo; t++, cur_tick++)
-          for (int g = 0; g < ng; g++) {
-            const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
-            APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
-          }
-      }
-      cur_active = 0;
-      for (int g = 1; g < ng; g++) {
-        APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
-        APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
-      }
-      ticks += todo;
       // poll = finalize: the result records and, right behind them in the same buffer, the status words and the error
       // flag; small batches bring the records home in the same copy, so align() needs no second round trip
       int* d_stat = (int*)(d_results.as<char>() + (size_t)npairs * sizeof(ResultRec));
@@ -1184,13 +1182,42 @@ class Engine {
       const bool spin = npairs <= 64 && results_on_host;
       int* h_seq = (int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65538;
       poll_seq = spin ? poll_seq + 1 : poll_seq;
+      // a single registration: the last kernel of the chunk's last tick writes the poll itself (post_result), no k_finalize
+      // (Levenberg-Marquardt: k_error ends the tick)
+      const bool fold_poll = fold_poll_cfg && fuse_lm && lm && npairs == 1 && spin && ng == 1;
+      if (fold_poll) {  // where the record goes: the same for every poll of this handle (uploaded when it changes)
+        const PollPost post{d_results.as<ResultRec>(), d_stat, (ResultRec*)h_poll_dev, (int*)(h_poll_dev + ((char*)h_status - h_poll)),
+                            (int*)(h_poll_dev + ((char*)h_seq - h_poll)), d_errflag.as<int>()};
+        APD_TRY(d_post.upload(&post, sizeof(post), stream));
+      }
+      {
+        roctx_range rr("apdgicp:ticks");
+        for (int t = 0; t < todo; t++, cur_tick++) {
+          post_tick = fold_poll && t == todo - 1;
+          for (int g = 0; g < ng; g++) {
+            const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
+            APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+          }
+        }
+        post_tick = false;
+      }
+      cur_active = 0;
+      for (int g = 1; g < ng; g++) {
+        APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
+        APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
+      }
+      ticks += todo;
+      if (!fold_poll)
       hipLaunchKernelGGL(k_finalize, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_results.as<ResultRec>(), d_stat, npairs,
                          d_errflag.as<int>(), results_on_host ? (ResultRec*)h_poll_dev : (ResultRec*)nullptr,
                          (int*)(h_poll_dev + ((char*)h_status - h_poll)), spin ? (int*)(h_poll_dev + ((char*)h_seq - h_poll)) : (int*)nullptr, poll_seq);
       APD_HIP(hipEventRecord(ev_poll, stream));
       if (n_stage_pending) {  // pinned clouds read by a sort in front of this event
         for (Cloud& c : clouds)
-          if (c.stage_pending && !c.stage_wait) c.stage_wait = ev_poll;
+          if (c.stage_pending && !c.stage_wait) {
+            c.stage_wait = ev_poll;
+            if (spin) c.stage_seq_word = (volatile int*)h_seq, c.stage_seq_val = poll_seq;
+          }
         n_stage_pending = 0;
       }
       pending_spin = spin;

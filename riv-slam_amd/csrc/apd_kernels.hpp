@@ -76,6 +76,16 @@ constexpr unsigned kKeptBit = 0x40000000u; // set in a chunk id when the search 
                                            // unique nearest neighbour: k_linearize takes index and point from there, no re-scan of the chunk
 constexpr unsigned kChunkMask = ~(kTieBit | kKeptBit);
 
+// A one-pair poll without its own launch: the kernel that ends the tick writes what k_finalize would (see there).
+struct PollPost {
+  ResultRec* out;        // device record
+  int* status_out;       // device status word, error flag behind it
+  ResultRec* host_out;   // the same in pinned host memory
+  int* host_status;
+  int* host_seq;         // receives `seq` when everything above has been written through
+  const int* err_flag;
+};
+
 struct Work {
   unsigned long long* nnpart;  // [pair][split][nstride]  (fp32 bits of min sqdist << 32 | chunk id)
   int* corr;                   // [pair][nstride]   correspondences_ (A:156)
@@ -101,6 +111,10 @@ struct Work {
                                // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
+  const PollPost* post;        // non-null (k_error only): this launch is the last of a one-pair poll and writes the result record itself
+                               // (post_result).  Not in k_linearize: with the record code in its last block the register allocator
+                               // moved that kernel's spills into the per-point pass (32.6 -> 45.0 us per batch launch)
+  int post_seq;
   const Rigid* init;           // non-null in the FIRST tick of an align (fused optimiser): the guesses, one pose per pair.  The
                                // search and the per-point pass take their pose from there and run cold, and the last block of
                                // k_linearize builds the pair's state from scratch (L:56-59) instead of loading it: no k_init_state launch
@@ -119,6 +133,31 @@ __device__ __forceinline__ void init_pair_state(PairState& s, const Rigid* g /* 
   s.nu = 2.0;
   s.status = max_iterations > 0 ? ST_NEED_LIN : ST_DONE;
   s.converged = 0, s.iter = 0, s.inner = 0, s.n_lin = 0, s.n_err = 0, s.failed = 0, s.n_matched = 0;
+}
+
+__device__ __forceinline__ ResultRec result_record(const PairState& s) {
+  ResultRec r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) r.T[i + 4 * j] = (float)s.x0.m[4 * i + j];  // x0.cast<float>(), L:78
+  r.T[3] = 0.f, r.T[7] = 0.f, r.T[11] = 0.f, r.T[15] = 1.f;
+  r.final_cost = s.y0;
+  r.converged = s.converged;
+  r.iterations = s.iter;
+  r.n_linearize = s.n_lin;
+  r.n_compute_error = s.n_err;
+  r.lm_failed = s.failed;
+  r.n_matched = s.n_matched;
+  return r;
+}
+// one thread, pair 0 of a one-pair handle; every block of this align that could have raised the error flag has passed the
+// arrival counter (or finished with an earlier launch) before this runs
+__device__ __forceinline__ void post_result(const PollPost& pp, int seq, const PairState& s) {
+  const ResultRec r = result_record(s);
+  const int flag = __hip_atomic_load(pp.err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  pp.out[0] = r, pp.status_out[0] = s.status, pp.status_out[1] = flag;
+  pp.host_out[0] = r, pp.host_status[0] = s.status, pp.host_status[1] = flag;
+  __threadfence_system();
+  __hip_atomic_store(pp.host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ int pair_of(const Work& w, unsigned block) { return w.active ? w.active[w.pair0 + block] : w.pair0 + (int)block; }
@@ -2151,7 +2190,10 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
-  if (st[pair].status != ST_NEED_ERR) return;
+  if (st[pair].status != ST_NEED_ERR) {
+    if (w.post && bx == 0 && threadIdx.x == 0) post_result(*w.post, w.post_seq, st[pair]);  // (the step ended in k_linearize)
+    return;
+  }
   const PairDesc pd = pairs[pair];
   const CloudDesc src = pd.s, tgt = pd.t;
   const int N = src.n, tid = threadIdx.x;
@@ -2204,7 +2246,10 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
       }
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
       __syncthreads();
-      if (tid == 0) lm_decide_after_sum(ls, s_yi, cst);
+      if (tid == 0) {
+        lm_decide_after_sum(ls, s_yi, cst);
+        if (w.post) post_result(*w.post, w.post_seq, ls);
+      }
       __syncthreads();
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
     }
@@ -2481,17 +2526,7 @@ __global__ void k_finalize(const PairState* st, ResultRec* out, int* status_out,
 }
 __device__ __forceinline__ void finalize_pair(const PairState* st, ResultRec* out, int* status_out, ResultRec* host_out, int* host_status, int p) {
   const PairState& s = st[p];
-  ResultRec r;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 4; j++) r.T[i + 4 * j] = (float)s.x0.m[4 * i + j];  // x0.cast<float>(), L:78
-  r.T[3] = 0.f, r.T[7] = 0.f, r.T[11] = 0.f, r.T[15] = 1.f;
-  r.final_cost = s.y0;
-  r.converged = s.converged;
-  r.iterations = s.iter;
-  r.n_linearize = s.n_lin;
-  r.n_compute_error = s.n_err;
-  r.lm_failed = s.failed;
-  r.n_matched = s.n_matched;
+  const ResultRec r = result_record(s);
   out[p] = r;
   if (host_out) host_out[p] = r;
   if (status_out) status_out[p] = s.status;

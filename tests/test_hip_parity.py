@@ -785,7 +785,8 @@ def test_register_sort_equals_lds_sort(reg, scene):
         src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(8, n), "odometry")
         out = []
         # the tiled multi-block sort (default), one register-sorting block per cloud, one LDS-sorting block per cloud
-        for env in ({}, {"APDGICP_SORT_TILED": "0"}, {"APDGICP_SORT_REG": "0"}):
+        # (the default also reads the host clouds straight from pinned memory, box reduced on the host: APDGICP_DIRECT_STAGE)
+        for env in ({}, {"APDGICP_DIRECT_STAGE": "0"}, {"APDGICP_SORT_TILED": "0"}, {"APDGICP_SORT_REG": "0"}):
             g = _handle_with_env(reg, reg.FastAPDGICP, env, max_correspondence_distance=2.0)
             g.setInputSource(src)
             g.setInputTarget(tgt)
@@ -795,6 +796,35 @@ def test_register_sort_equals_lds_sort(reg, scene):
         for other in out[1:]:
             for x, y in zip(out[0], other):
                 assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_pinned_cloud_buffers_are_reused_safely(reg, scene):
+    """Scan-sized host clouds stay in the slot's pinned buffer until the sort has read them (TileJob::staged): replacing a
+    cloud before any align, after an align, and with another size class must always register the LATEST points."""
+    kw = dict(max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    sets = [scene.make_pair(n, m, scene.pair_seed(9, n), "odometry") for n, m in ((8192, 8192), (5000, 3000), (8192, 12000), (1500, 9000))]
+
+    def fresh(src, tgt, guess):
+        g = reg.FastAPDGICP(reg.default_params(**kw))
+        g.setInputSource(src), g.setInputTarget(tgt)
+        return g.align(guess), g.getSourceCovariances()
+
+    h = reg.FastAPDGICP(reg.default_params(**kw))
+    for rnd in range(2):
+        for k, (src, tgt, _, guess) in enumerate(sets):
+            other = sets[(k + 1) % len(sets)]
+            h.setInputSource(other[0])          # replaced before it is ever used
+            h.setInputSource(src)
+            h.setInputTarget(tgt)
+            T = h.align(guess)
+            Tw, cw = fresh(src, tgt, guess)
+            assert np.array_equal(T, Tw), (rnd, k)
+            assert np.array_equal(h.getSourceCovariances(), cw), (rnd, k)
+            # same target, new scan (the odometry loop): only the source buffer is rewritten
+            src2 = (src + np.float32(0.01)).astype(np.float32)
+            h.setInputSource(src2)
+            T2 = h.align(guess)
+            assert np.array_equal(T2, fresh(src2, tgt, guess)[0]), (rnd, k)
 
 
 def test_exact_ties_resolve_to_the_lowest_original_index(reg):
