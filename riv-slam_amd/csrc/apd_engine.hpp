@@ -481,6 +481,20 @@ class Engine {
         for (int a = 0; a < 3; a++) lo[u][a] = v[a] < lo[u][a] ? v[a] : lo[u][a], hi[u][a] = v[a] > hi[u][a] ? v[a] : hi[u][a];
       };
       int64_t q = 0;
+      if (stride_bytes >= 16) {  // the fourth float read with the point belongs to the point: one 16-byte load, blend, store
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f vlo[2] = {v4f(inf), v4f(inf)}, vhi[2] = {v4f(-inf), v4f(-inf)};
+        for (; q + 2 <= n; q += 2)
+          for (int u = 0; u < 2; u++) {
+            v4f v;
+            memcpy(&v, raw + (q + u) * stride_bytes, 16);
+            vlo[u] = v < vlo[u] ? v : vlo[u], vhi[u] = v > vhi[u] ? v : vhi[u];
+            v.w = 1.0f;
+            memcpy(&dst[q + u], &v, 16);
+          }
+        for (int u = 0; u < 2; u++)
+          for (int a = 0; a < 3; a++) lo[u][a] = vlo[u][a], hi[u][a] = vhi[u][a];
+      }
       for (; q + 4 <= n; q += 4) put(q, 0), put(q + 1, 1), put(q + 2, 2), put(q + 3, 3);
       for (; q < n; q++) put(q, 0);
       for (int u = 1; u < 4; u++)
