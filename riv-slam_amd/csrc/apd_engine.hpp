@@ -218,6 +218,7 @@ class Engine {
   bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
+  bool split_regularize = true;  // APDGICP_SPLIT_REG=0: the covariance kernel regularises in its own epilogue in every regime
   bool fold_poll_cfg = true, post_tick = false;  // APDGICP_FOLD_POLL=0: k_finalize behind every chunk of ticks
   CachedTable d_post;
   bool fold_init_cfg = true, fold_init = false, tickets_dirty = true;  // APDGICP_FOLD_INIT=0: k_init_state in front of every align
@@ -317,6 +318,7 @@ class Engine {
     fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
     fold_init_cfg = env_int("APDGICP_FOLD_INIT", 1) != 0;
     fold_poll_cfg = env_int("APDGICP_FOLD_POLL", 1) != 0;
+    split_regularize = env_int("APDGICP_SPLIT_REG", 1) != 0;
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
     nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
@@ -791,16 +793,21 @@ class Engine {
       if (qpw != 4 && qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;  // measured (r01): 2 clouds of 8k 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
       const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
+      // throughput launches regularise in a second launch with every lane busy; a single cloud (latency) keeps it fused
+      const int raw = coop && qpw != 4 && params.regularization != APDGICP_REG_NONE && split_regularize ? 1 : 0;
       if (coop && qpw == 16)
         hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
-                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
       else if (coop && qpw == 4)
         hipLaunchKernelGGL(k_knn_cov_coop<16>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
-                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
       else if (coop && qpw == 8)
         hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
-                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>());
-      else
+                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
+      if (raw)
+        hipLaunchKernelGGL(k_regularize_covs, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, st, d_desc.as<CloudDesc>(), d_list,
+                           params.regularization, d_errflag.as<int>());
+      if (!(coop && (qpw == 16 || qpw == 4 || qpw == 8)))
         hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {

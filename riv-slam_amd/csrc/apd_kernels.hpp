@@ -1457,7 +1457,7 @@ __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v)
 
 template <int L>
 __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
-                                                     unsigned long long* stats) {
+                                                     unsigned long long* stats, int raw /* 1: store the population covariance, k_regularize_covs follows */) {
   constexpr int QPW = 64 / L, NCL = KNN_NC / L, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
   static_assert(L == 4 || L == 8 || L == 16, "L lanes per query");
   static_assert(KQ_CAP % L == 0 && KQ_WIN % KNN_NC == 0, "layout");
@@ -1803,10 +1803,25 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   Sym3 pc;
   pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
   pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
-  Sym3 out;
-  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+  // Throughput launches (L lanes per query, so only one lane in L would work here -- and the Jacobi sweeps are a quarter of
+  // this kernel's fp64-weighted instructions) leave the regularisation to k_regularize_covs, one lane per point.
+  Sym3 out = pc;
+  if (!raw && !regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
   if (stats && lane == 0) atomicAdd(stats + 15, (unsigned long long)(clock64() - tm));  // rounds + regularisation
   double* cov = c.cov;
+  cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
+}
+
+// fast_apdgicp_impl.hpp:326-357 for covariances stored raw by k_knn_cov_coop: one lane per point, in place (the same function
+// on the same numbers as the fused path: bitwise the same result).  grid (ceil(nmax / 256), clouds)
+__global__ __launch_bounds__(256) void k_regularize_covs(const CloudDesc* clouds, const int* cloud_ids, int reg, int* err_flag) {
+  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  const int n = c.n, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double* cov = c.cov;
+  const Sym3 pc{cov[i], cov[n + i], cov[2 * n + i], cov[3 * n + i], cov[4 * n + i], cov[5 * n + i]};
+  Sym3 out;
+  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
   cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
 }
 
