@@ -76,6 +76,37 @@ constexpr unsigned kKeptBit = 0x40000000u; // set in a chunk id when the search 
                                            // unique nearest neighbour: k_linearize takes index and point from there, no re-scan of the chunk
 constexpr unsigned kChunkMask = ~(kTieBit | kKeptBit);
 
+// Second moments of the k neighbours about the query point, summed in ONE order by every covariance kernel: four partial
+// sums -- partial j takes the ranks j, j + 4, j + 8, ... in increasing order -- combined as (p0 + p1) + (p2 + p3).  The
+// 4-lanes-per-query kernel gives each lane one partial (a quarter of the fp64 work the shared rank-order sum cost every lane);
+// the one-lane-per-query kernels keep four accumulators.  A:323-324 sums in Eigen's order; parity with it is by tolerance.
+struct Mom9 {
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  __device__ __forceinline__ void add(double x, double y, double z) {
+    s1x += x, s1y += y, s1z += z;
+    sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+  }
+  __device__ __forceinline__ void merge(const Mom9& o) {
+    s1x += o.s1x, s1y += o.s1y, s1z += o.s1z;
+    sxx += o.sxx, sxy += o.sxy, sxz += o.sxz, syy += o.syy, syz += o.syz, szz += o.szz;
+  }
+};
+struct Mom9x4 {  // one lane per query
+  Mom9 p0, p1, p2, p3;
+  __device__ __forceinline__ void add(int rank, double x, double y, double z) {
+    switch (rank & 3) {
+      case 0: p0.add(x, y, z); break;
+      case 1: p1.add(x, y, z); break;
+      case 2: p2.add(x, y, z); break;
+      default: p3.add(x, y, z); break;
+    }
+  }
+  __device__ __forceinline__ Mom9 total() {
+    p0.merge(p1), p2.merge(p3), p0.merge(p2);
+    return p0;
+  }
+};
+
 // A one-pair poll without its own launch: the kernel that ends the tick writes what k_finalize would (see there).
 struct PollPost {
   ResultRec* out;        // device record
@@ -378,7 +409,7 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
 
   // ---- select the k nearest, accumulate in fp64 relative to the query point (differences of
   // fp32 numbers are exact in fp64); cov = S2/k - mean*mean^T  ==  A:323-324
-  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  Mom9x4 acc;
   {
     float last_d = -1.f;
     int last_i = -1;
@@ -398,11 +429,11 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
         break;
       }
       const float4 p = c.opts[bi];
-      const double x = (double)p.x - (double)q.x, y = (double)p.y - (double)q.y, z = (double)p.z - (double)q.z;
-      s1x += x, s1y += y, s1z += z;
-      sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+      acc.add(r, (double)p.x - (double)q.x, (double)p.y - (double)q.y, (double)p.z - (double)q.z);
     }
   }
+  const Mom9 mt = acc.total();
+  const double s1x = mt.s1x, s1y = mt.s1y, s1z = mt.s1z, sxx = mt.sxx, sxy = mt.sxy, sxz = mt.sxz, syy = mt.syy, syz = mt.syz, szz = mt.szz;
   const double ik = 1.0 / (double)k;
   const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
   Sym3 pc;
@@ -1370,7 +1401,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
 
   // ---- C
   const unsigned long long* row = lst + lane * KQ_STRIDE;
-  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  Mom9x4 acc;
   {
     unsigned long long last = 0;
     bool first = true;
@@ -1390,14 +1421,12 @@ __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, 
         last = bk, first = false;
       }
       const float4 nxt = r < k ? c.opts[(unsigned)bk] : q;
-      if (have) {
-        const double x = (double)pend.x - (double)q.x, y = (double)pend.y - (double)q.y, z = (double)pend.z - (double)q.z;
-        s1x += x, s1y += y, s1z += z;
-        sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
-      }
+      if (have) acc.add(r - 1, (double)pend.x - (double)q.x, (double)pend.y - (double)q.y, (double)pend.z - (double)q.z);
       pend = nxt, have = true;
     }
   }
+  const Mom9 mt = acc.total();
+  const double s1x = mt.s1x, s1y = mt.s1y, s1z = mt.s1z, sxx = mt.sxx, sxy = mt.sxy, sxz = mt.sxz, syy = mt.syy, syz = mt.syz, szz = mt.szz;
   const double ik = 1.0 / (double)k;
   const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
   Sym3 pc;
@@ -1445,6 +1474,13 @@ __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v
     v = o < v ? o : v;
   }
   return v;
+}
+template <int CTRL>
+__device__ __forceinline__ Mom9 mom_dpp(const Mom9& m) {  // the partner lane's sums
+  auto f = [](double v) { return __longlong_as_double((long long)dpp_u64<CTRL>((unsigned long long)__double_as_longlong(v))); };
+  Mom9 o;
+  o.s1x = f(m.s1x), o.s1y = f(m.s1y), o.s1z = f(m.s1z), o.sxx = f(m.sxx), o.sxy = f(m.sxy), o.sxz = f(m.sxz), o.syy = f(m.syy), o.syz = f(m.syz), o.szz = f(m.szz);
+  return o;
 }
 template <int L>
 __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v) {
@@ -1789,13 +1825,14 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     if (r < k) nbl[3 * r] = nbv[t].x, nbl[3 * r + 1] = nbv[t].y, nbl[3 * r + 2] = nbv[t].z;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // moments in rank order (every lane of the query computes the same sums)
-  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-  for (int r = 0; r < k; r++) {
-    const double x = (double)nbl[3 * r] - (double)q.x, y = (double)nbl[3 * r + 1] - (double)q.y, z = (double)nbl[3 * r + 2] - (double)q.z;
-    s1x += x, s1y += y, s1z += z;
-    sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
-  }
+  // moments (Mom9): lanes 0..3 of the query take one partial sum each, two quad butterflies add them up in the common order
+  // (the operands of an addition swap between partner lanes: the same bits)
+  Mom9 mp;
+  if (sub < 4)
+    for (int r = sub; r < k; r += 4) mp.add((double)nbl[3 * r] - (double)q.x, (double)nbl[3 * r + 1] - (double)q.y, (double)nbl[3 * r + 2] - (double)q.z);
+  mp.merge(mom_dpp<0xB1>(mp));  // quad_perm [1,0,3,2]: p0 + p1 | p2 + p3
+  mp.merge(mom_dpp<0x4E>(mp));  // quad_perm [2,3,0,1]: (p0 + p1) + (p2 + p3)
+  const double s1x = mp.s1x, s1y = mp.s1y, s1z = mp.s1z, sxx = mp.sxx, sxy = mp.sxy, sxz = mp.sxz, syy = mp.syy, syz = mp.syz, szz = mp.szz;
   if (stats && lane == 0) { tC = clock64() - tm; atomicAdd(stats + 10, (unsigned long long)tA), atomicAdd(stats + 11, (unsigned long long)tG), atomicAdd(stats + 12, (unsigned long long)tB), atomicAdd(stats + 13, (unsigned long long)tC); }
   if (sub != 0) return;
   const double ik = 1.0 / (double)k;
