@@ -997,6 +997,8 @@ class Engine {
     // (not for dense targets beyond 16384 points when the engine chose the regime itself: a wave there walks many batches of
     // group boxes, and 100k x 500k measured 0.232 ms per iteration against 0.170 with one-wave blocks, 0.103 with W = 4)
     if (nn_pruned && nn_S == 1 && W == 1 && work.nnaux && nn_compact && (!big_target || nn_W == 1)) {
+      // (blocks of 512 points waste half as many tail waves -- 29.5 instead of 36 search waves per 256 points over the 20
+      // ticks of the bench -- but hold twice the LDS until their slowest wave is done: measured 34.7 k vs 37.0 k registrations/s)
       grid.x = (unsigned)((nmax_src + 255) / 256);
       APD_NN_LAUNCH(k_nn_compact<4>, 256);
     } else if (nn_pruned) {

@@ -1529,14 +1529,26 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     float cmp[NCL];  // minima of the classes sub + L*m
 #pragma unroll
     for (int m = 0; m < NCL; m++) cmp[m] = inf;
-    for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
+    // straight from global memory: the L lanes of a query read L consecutive points, the queries of a wave the same
+    // window, so the lines stay in L1; no LDS copy of the window (3 KB per wave more for resident waves).
+    // The whole window lies inside the cloud unless the cloud is smaller than the window: a per-element bound check made
+    // the compiler branch around every load and wait for each one on its own (32 dependent round trips to memory per wave)
+    if (n >= KQ_WIN) {
+      for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
+        float4 t[NCL];
 #pragma unroll
-      for (int m = 0; m < NCL; m++) {
-        // straight from global memory: the L lanes of a query read L consecutive points, the queries of a wave the same
-        // window, so the lines stay in L1; no LDS copy of the window (3 KB per wave more for resident waves)
-        const int j = w0 + sub + L * (t0 + m);
-        const float4 t = c.pts[min(j, n - 1)];
-        cmp[m] = fminf(cmp[m], j < n ? sqdist1(t.x, t.y, t.z, q.x, q.y, q.z) : inf);
+        for (int m = 0; m < NCL; m++) t[m] = c.pts[w0 + sub + L * (t0 + m)];
+#pragma unroll
+        for (int m = 0; m < NCL; m++) cmp[m] = fminf(cmp[m], sqdist1(t[m].x, t[m].y, t[m].z, q.x, q.y, q.z));
+      }
+    } else {
+      for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
+#pragma unroll
+        for (int m = 0; m < NCL; m++) {
+          const int j = w0 + sub + L * (t0 + m);
+          const float4 t = c.pts[min(j, n - 1)];
+          cmp[m] = fminf(cmp[m], j < n ? sqdist1(t.x, t.y, t.z, q.x, q.y, q.z) : inf);
+        }
       }
     }
     if constexpr (L == 4) {
