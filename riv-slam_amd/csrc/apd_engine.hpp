@@ -221,6 +221,7 @@ class Engine {
   bool split_regularize = true;  // APDGICP_SPLIT_REG=0: the covariance kernel regularises in its own epilogue in every regime
   bool fold_poll_cfg = true, post_tick = false;  // APDGICP_FOLD_POLL=0: k_finalize behind every chunk of ticks
   CachedTable d_post;
+  bool init_tick = false;
   bool fold_init_cfg = true, fold_init = false, tickets_dirty = true;  // APDGICP_FOLD_INIT=0: k_init_state in front of every align
   bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
   DevBuf b_ticket;
@@ -979,7 +980,7 @@ class Engine {
     Work w = work;
     w.pair0 = sp.p0;
     w.cap = nn_cap;
-    w.init = fold_init && cur_tick == 0 ? d_guess.as<Rigid>() : nullptr;
+    w.init = init_tick ? d_guess.as<Rigid>() : nullptr;
     // a timed launch carries its own start/stop events (hipExtLaunchKernelGGL): the kernel's begin and end timestamps, as
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) (last_nn_kernel = #KERNEL, hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w))
@@ -1019,7 +1020,7 @@ class Engine {
     const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
     Work w = work;
     w.pair0 = sp.p0;
-    w.init = fold_init && cur_tick == 0 && mode == 2 ? d_guess.as<Rigid>() : nullptr;
+    w.init = init_tick && mode == 2 ? d_guess.as<Rigid>() : nullptr;
     if (mode == 2)
       hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
                          consts(), mode);
@@ -1215,14 +1216,18 @@ class Engine {
       }
       {
         roctx_range rr("apdgicp:ticks");
+        struct FlagReset {  // also on the error returns inside the loop
+          bool &a, &b;
+          ~FlagReset() { a = b = false; }
+        } flag_reset{post_tick, init_tick};
         for (int t = 0; t < todo; t++, cur_tick++) {
           post_tick = fold_poll && t == todo - 1;
+          init_tick = fold_init && cur_tick == 0;  // (only here: the probe entry points launch the same kernels)
           for (int g = 0; g < ng; g++) {
             const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
             APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
           }
         }
-        post_tick = false;
       }
       cur_active = 0;
       for (int g = 1; g < ng; g++) {

@@ -35,4 +35,4 @@ for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ; do rm -rf $d;
 find $ev/ks -type f ! -name "*.db" -delete
 head -c 1500 $ev/bench.json; echo
 head -14 $ev/kernel_stats.md
-for n in fetch write insts busy occ; do echo "== $n"; grep "k_nn_pruned\|knn_cov_coop\|k_linearize\|^| kernel" $ev/pmc_$n.md | head -8; done
+for n in fetch write insts busy occ; do echo "== $n"; grep "k_nn_\|knn_cov_coop\|k_linearize\|k_regularize\|^| kernel" $ev/pmc_$n.md | head -8; done
