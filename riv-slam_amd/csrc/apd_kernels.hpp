@@ -38,6 +38,22 @@ struct CloudDesc {
   int n;
   int pad_;
 };
+// A pointer a kernel finds in a table in memory (CloudDesc) is generic to the compiler, and every access through it a
+// flat_load -- which counts on the LDS counter as well: each LDS access behind it waits for all of them
+// (`s_waitcnt vmcnt(0) lgkmcnt(0)`), so no load overlaps with a scan out of LDS.  G(p) says what the pointer is.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define APD_AS1 __attribute__((address_space(1)))
+#else
+#define APD_AS1  // (the host pass only parses the kernels)
+#endif
+template <typename T>
+__device__ __forceinline__ const APD_AS1 T* G(const T* p) {
+  return (const APD_AS1 T*)p;
+}
+template <typename T>
+__device__ __forceinline__ APD_AS1 T* GW(T* p) {
+  return (APD_AS1 T*)p;
+}
 
 struct PairDesc {
   int src, tgt;
@@ -684,7 +700,7 @@ struct NNStart {
 __device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, const float* Tf, const Work& w, int pair, int ii, bool cold, bool skin_on) {
   const float inf = __builtin_inff();
   NNStart o;
-  const float4 p = src.pts[ii];
+  const float4 p = G(src.pts)[ii];
   o.px = xf_row(Tf + 0, p.x, p.y, p.z), o.py = xf_row(Tf + 4, p.x, p.y, p.z), o.pz = xf_row(Tf + 8, p.x, p.y, p.z);
   o.best = w.cap, o.bestc = kNoChunk, o.kept = false;
   const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
@@ -741,7 +757,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
 #pragma unroll
   for (int u = 0; u < NPRE; u++) {
     const int e = u * 64 * W + tid;
-    gpre[u] = e < 6 * min(64, ngroups) ? ((const float*)tgt.gbox)[e] : 0.f;
+    gpre[u] = G((const float*)tgt.gbox)[min(e, 6 * ngroups - 1)];
   }
   const float inf = __builtin_inff();
 
@@ -800,20 +816,22 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   // registers of the group in flight: loaded from L2 while the previous group is scanned out of LDS
   float4 pa = make_float4(inf, inf, inf, 0.f), pb = pa;
   float pc = inf;
+  // The three loads of a group are UNCONDITIONAL (clamped addresses; what lies beyond the cloud is replaced when the group
+  // is committed): written as `j < M ? load : inf` each one sat in a branch of its own with an `s_waitcnt vmcnt(0)` right
+  // behind it -- three dependent trips to memory per group, none of them under the scan of the previous group.
   auto fetch_group = [&](int g) {
     const int j = g * kGroupPts + 2 * lane;
-    pa = j < M ? tgt.pts[j] : make_float4(inf, inf, inf, 0.f);
-    pb = j + 1 < M ? tgt.pts[j + 1] : make_float4(inf, inf, inf, 0.f);
-    if (lane < 6 * kGroupChunks) {
-      const int c = g * kGroupChunks + lane / 6;
-      pc = c < nchunks ? ((const float*)tgt.cbox)[(size_t)g * kGroupChunks * 6 + lane] : inf;
-    }
+    pa = G(tgt.pts)[min(j, M - 1)];
+    pb = G(tgt.pts)[min(j + 1, M - 1)];
+    pc = G((const float*)tgt.cbox)[min(g * kGroupChunks * 6 + min(lane, 6 * kGroupChunks - 1), nchunks * 6 - 1)];
   };
-  auto commit_group = [&]() {  // registers -> the wave's LDS tile ({x0,x1,y0,y1} + {z0,z1} pairs, 8 chunk boxes)
+  auto commit_group = [&](int g) {  // registers -> the wave's LDS tile ({x0,x1,y0,y1} + {z0,z1} pairs, 8 chunk boxes)
+    const int j = g * kGroupPts + 2 * lane;
+    const bool va = j < M, vb = j + 1 < M, vc = g * kGroupChunks + lane / 6 < nchunks;
     wave_lds_fence();          // the tile belongs to this wave alone: its previous scan is done with it
-    txy[lane] = make_float4(pa.x, pb.x, pa.y, pb.y);
-    tz[lane] = make_float2(pa.z, pb.z);
-    if (lane < 6 * kGroupChunks) cbl[lane] = pc;
+    txy[lane] = make_float4(va ? pa.x : inf, vb ? pb.x : inf, va ? pa.y : inf, vb ? pb.y : inf);
+    tz[lane] = make_float2(va ? pa.z : inf, vb ? pb.z : inf);
+    if (lane < 6 * kGroupChunks) cbl[lane] = vc ? pc : inf;
     wave_lds_fence();
   };
   auto lane_needs = [&](const Box& bx) {
@@ -875,7 +893,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
   unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
   if (use_super && rad0 < inf) {
-    const Box sbx = tgt.gbox[ngroups + min(sb0 + lane, nsuper - 1)];
+    const Box sbx = G(tgt.gbox)[ngroups + min(sb0 + lane, nsuper - 1)];
     smask &= __ballot(lb_box_box(wbox, sbx) <= rad0);
   }
   while (smask) {
@@ -889,7 +907,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       for (int u = 0; u < NPRE; u++)
         if (u * 64 * W + tid < 6 * 64) gbl[u * 64 * W + tid] = gpre[u];
     }
-    for (int e = (gb0 == 0 ? 6 * 64 : 0) + tid; e < 6 * nbb; e += 64 * W) gbl[e] = ((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
+    for (int e = (gb0 == 0 ? 6 * 64 : 0) + tid; e < 6 * nbb; e += 64 * W) gbl[e] = G((const float*)tgt.gbox)[(size_t)gb0 * 6 + e];
     block_sync();
     for (int sb = 0; sb < nbb; sb += 64) {  // 64 groups at a time: their need bits fit one mask
       const int nb = min(64, nbb - sb);
@@ -909,7 +927,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         }
         if (seed >= 0) {
           fetch_group(g0 + seed);
-          commit_group();
+          commit_group(g0 + seed);
           scan_tile(g0 + seed);
         }
       }
@@ -951,7 +969,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         fetch_group(g0 + cur);
       }
       while (cur >= 0) {
-        commit_group();
+        commit_group(g0 + cur);
         const int nxt = cand ? __builtin_ctzll(cand) : -1;
         if (nxt >= 0) {
           cand &= cand - 1;
@@ -1011,7 +1029,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
         for (int h = 0; h < kChunk; h += 8) {  // eight loads in flight at a time: 32 registers, not 64
           float4 t[8];
 #pragma unroll
-          for (int jj = 0; jj < 8; jj++) t[jj] = tgt.pts[min(c0 + h + jj, M - 1)];
+          for (int jj = 0; jj < 8; jj++) t[jj] = G(tgt.pts)[min(c0 + h + jj, M - 1)];
 #pragma unroll
           for (int jj = 0; jj < 8; jj++) {
             const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
@@ -1510,7 +1528,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   const int slot = lane / L, sub = lane % L, owner = lane - sub;
   const int i = base + slot;
   const bool valid = i < n;
-  const float4 q = c.pts[valid ? i : n - 1];
+  const float4 q = G(c.pts)[valid ? i : n - 1];
   const int ngroups = (n + kGroupPts - 1) / kGroupPts;
   unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
   if ((bx & 63) != 0) stats = nullptr;  // diagnostics sample every 64th wave (the atomics would dominate otherwise)
@@ -1519,7 +1537,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   // ---- A: bound from the sorted neighbourhood
   const int w0 = min(max(base - (KQ_WIN - QPW) / 2, 0), max(n - KQ_WIN, 0));
   const Box nobox{inf, inf, inf, inf, inf, inf};
-  Box mybox = lane < ngroups ? c.gbox[lane] : nobox;  // lane g keeps the box of group gb0 + g in registers: no LDS copy
+  Box mybox = G(c.gbox)[min(lane, ngroups - 1)];
+  if (lane >= ngroups) mybox = nobox;  // lane g keeps the box of group gb0 + g in registers: no LDS copy
   int cnt = 0;  // entries in this query's list (same value in its L lanes)
   int idx_bits = 1;
   while ((1 << idx_bits) < n) idx_bits++;
@@ -1537,7 +1556,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
       for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
         float4 t[NCL];
 #pragma unroll
-        for (int m = 0; m < NCL; m++) t[m] = c.pts[w0 + sub + L * (t0 + m)];
+        for (int m = 0; m < NCL; m++) t[m] = G(c.pts)[w0 + sub + L * (t0 + m)];
 #pragma unroll
         for (int m = 0; m < NCL; m++) cmp[m] = fminf(cmp[m], sqdist1(t[m].x, t[m].y, t[m].z, q.x, q.y, q.z));
       }
@@ -1546,7 +1565,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
 #pragma unroll
         for (int m = 0; m < NCL; m++) {
           const int j = w0 + sub + L * (t0 + m);
-          const float4 t = c.pts[min(j, n - 1)];
+          const float4 t = G(c.pts)[min(j, n - 1)];
           cmp[m] = fminf(cmp[m], j < n ? sqdist1(t.x, t.y, t.z, q.x, q.y, q.z) : inf);
         }
       }
@@ -1651,7 +1670,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
   unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
   if (use_super) {
-    const Box sbx = sb0 + lane < nsuper ? c.gbox[ngroups + sb0 + lane] : nobox;
+    Box sbx = G(c.gbox)[ngroups + min(sb0 + lane, nsuper - 1)];
+    if (sb0 + lane >= nsuper) sbx = nobox;
     unsigned long long sany = 0;
 #pragma unroll
     for (int qi = 0; qi < QPW; qi++) {
@@ -1665,7 +1685,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     const int gb0 = (sb0 + __builtin_ctzll(smask)) * kSuperGroups;
     smask &= smask - 1;
     const int nb = min(64, ngroups - gb0);
-    if (gb0 > 0) mybox = gb0 + lane < ngroups ? c.gbox[gb0 + lane] : nobox;
+    if (gb0 > 0) {
+      mybox = G(c.gbox)[min(gb0 + lane, ngroups - 1)];
+      if (gb0 + lane >= ngroups) mybox = nobox;
+    }
     // group masks, one query per trip: lane g tests ITS box against the query broadcast through SGPRs, the ballot IS the
     // query's mask (a finished or padding query has tau = -1 and gets none); gany = groups some query of this wave needs
     unsigned long long gneed = 0, gany = 0;
@@ -1683,8 +1706,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     auto fetch = [&](int g, float4& a0, float4& a1, unsigned& b0, unsigned& b1) {
       const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
       a0 = make_float4(inf, inf, inf, 0.f), a1 = a0, b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
-      if (j0 < n) a0 = c.pts[j0], b0 = __float_as_uint(a0.w);  // (the sorted points carry their original index in .w)
-      if (j1 < n) a1 = c.pts[j1], b1 = __float_as_uint(a1.w);
+      { const float4 v0 = G(c.pts)[min(j0, n - 1)]; if (j0 < n) a0 = v0, b0 = __float_as_uint(v0.w); }  // (the sorted points carry their original index in .w)
+      { const float4 v1 = G(c.pts)[min(j1, n - 1)]; if (j1 < n) a1 = v1, b1 = __float_as_uint(v1.w); }
     };
         // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
     // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
@@ -1827,7 +1850,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   for (int t = 0; t < KNN_NC / L; t++) {
     const int r = sub + L * t;
     nbv[t] = q;
-    if (r < k) nbv[t] = c.opts[mysel[t]];
+    if (r < k) nbv[t] = G(c.opts)[mysel[t]];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   float* nbl = (float*)row;  // [rank][xyz], overwrites the sorted lists (already consumed)
@@ -1857,7 +1880,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
   Sym3 out = pc;
   if (!raw && !regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
   if (stats && lane == 0) atomicAdd(stats + 15, (unsigned long long)(clock64() - tm));  // rounds + regularisation
-  double* cov = c.cov;
+  auto cov = GW(c.cov);
   cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
 }
 
@@ -1867,7 +1890,7 @@ __global__ __launch_bounds__(256) void k_regularize_covs(const CloudDesc* clouds
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double* cov = c.cov;
+  auto cov = GW(c.cov);
   const Sym3 pc{cov[i], cov[n + i], cov[2 * n + i], cov[3 * n + i], cov[4 * n + i], cov[5 * n + i]};
   Sym3 out;
   if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
@@ -1994,8 +2017,8 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
   const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
   if (w.corr) w.corr[(size_t)pair * w.nstride + i] = corr;
   if (corr >= 0) {
-    const double* ca = src.cov;
-    const double* cb = tgt.cov;
+    const auto ca = G((const double*)src.cov);
+    const auto cb = G((const double*)tgt.cov);
     const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
     const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
     // APD sensor-noise covariance from the transformed point (A:167-184)
@@ -2194,7 +2217,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     }
     float Tf[12];
     load_Tf(T, Tf);
-    const float4 p = src.pts[i];
+    const float4 p = G(src.pts)[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
     linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, lp);
   }
@@ -2268,7 +2291,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   if (i < N) {
     const int corr = w.corr[(size_t)pair * w.nstride + i];
     if (corr >= 0) {
-      const float4 p = src.pts[i], q = tgt.pts[corr];
+      const float4 p = G(src.pts)[i], q = G(tgt.pts)[corr];
       const double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
       const size_t ns = w.nstride;
       const double mxx = mo[0], mxy = mo[ns], mxz = mo[2 * ns], myy = mo[3 * ns], myz = mo[4 * ns], mzz = mo[5 * ns];

@@ -20,6 +20,9 @@ b = reg.BatchAPDGICP(bench.bench_params(reg))
 b.set_pair_groups(1)
 for _ in range(reps):
     b.set_clouds(0, clouds)
+    if os.environ.get("APDGICP_STATS"):
+        b.compute_covariances()
+        b.debug_stats()   # (reading resets: the counters below are the ticks' alone)
     r = b.align(pairs, guesses)
 print("done", int(r["n_linearize"].min()))
 if os.environ.get("APDGICP_STATS"):
@@ -27,3 +30,6 @@ if os.environ.get("APDGICP_STATS"):
     w = max(st[3], 1.0)
     print("stats per wave (all ticks of the last align%s): groups %.2f chunk tests %.2f chunk scans %.2f batches %.2f kept %.1f%% waves %d" %
           (" + covariances" if reps == 1 else "s", st[0] / w, st[1] / w, st[2] / w, st[5] / w, 100 * st[6] / (w * 64), int(w)))
+    if st[14] > 0:   # sampled search waves (nn_search): cycles up to the wave box / up to the candidate groups / scans + index + record
+        print("search wave, cycles: warm start %.0f  group boxes %.0f  scans, index, record %.0f  (%d sampled waves)" %
+              (st[10] / st[14], st[11] / st[14], st[12] / st[14], int(st[14])))
