@@ -215,6 +215,7 @@ class Engine {
   // the margin (APDGICP_NN_SKIN=0 disables; APDGICP_NN_SKIN_REL / _ABS in metres override)
   bool nn_skin = true;
   float nn_skin_rel = 0.25f, nn_skin_abs = 0.02f;
+  bool nn_coop_tail = true;  // APDGICP_NN_COOP_TAIL=0: a k_nn_compact block with one wave's worth of points left searches them with that one wave
   bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
@@ -323,6 +324,7 @@ class Engine {
     nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
     nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
+    nn_coop_tail = env_int("APDGICP_NN_COOP_TAIL", 1) != 0;
     if (const char* v = getenv("APDGICP_NN_SKIN_REL")) nn_skin_rel = std::max(0.f, (float)atof(v));
     if (const char* v = getenv("APDGICP_NN_SKIN_ABS")) nn_skin_abs = std::max(0.f, (float)atof(v));
     sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
@@ -935,6 +937,7 @@ class Engine {
     if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
     work.init = nullptr;
+    work.coop_search = nn_coop_tail ? 1 : 0;
     work.post = nullptr, work.post_seq = 0;
     work.pair0 = 0;
     work.npairs = npairs;

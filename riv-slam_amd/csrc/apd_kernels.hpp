@@ -158,6 +158,7 @@ struct Work {
                                // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
+  int coop_search;             // k_nn_compact: a block with at most 64 points left searches them with all of its waves
   const PollPost* post;        // non-null (k_error only): this launch is the last of a one-pair poll and writes the result record itself
                                // (post_result).  Not in k_linearize: with the record code in its last block the register allocator
                                // moved that kernel's spills into the per-point pass (32.6 -> 45.0 us per batch launch)
@@ -729,16 +730,17 @@ __device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, co
   return o;
 }
 
-// OWN = false: the classic form -- the W waves of the block share the points [base, base + 64 S) and warm-start them here.
-// OWN = true (k_nn_compact, W == 1): the wave was handed its points by the caller -- px/py/pz/best/bestc/kept/hinted_in are
-// inputs, pidx[s] is the index of the point a lane works for (-1: none; such a lane must come in with kept = true) -- and owns
-// ALL of its LDS (gbl included), so nothing here synchronises with the other waves of the block.
-template <int S, int W, bool OWN = false>
+// GIVEN = false: the classic form -- the W waves of the block share the points [base, base + 64 S) and warm-start them here.
+// GIVEN = true (k_nn_compact): the caller hands the points over -- px/py/pz/best/bestc/kept/hinted_in are inputs, pidx[s] is
+// the index of the point a lane works for (-1: none; such a lane must come in with kept = true).  With W == 1 the wave owns
+// ALL of its LDS (gbl included) and nothing here synchronises with the other waves of the block; with W > 1 the W waves of the
+// block came in with the SAME points and split the groups between them like the classic form (block barriers, shared gbl).
+template <int S, int W, bool GIVEN = false>
 __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T0, const Work& w, int pair, int base, int lane,
                                           int wid, bool cold, float4* txy, float2* tz, float* cbl, float* gbl, unsigned long long* mrg /* [W][64*S] */,
                                           float2* mrg2 /* [W][64*S] */, float (&px)[S], float (&py)[S], float (&pz)[S], float (&best)[S],
                                           unsigned (&bestc)[S], int (&pidx)[S], bool (&kept)[S], bool hinted_in = true) {
-  static_assert(!OWN || W == 1, "a wave that owns its points shares nothing with the block");
+  constexpr bool OWN = GIVEN && W == 1;
   const int N = src.n, M = tgt.n;
   const int tid = wid * 64 + lane;
   auto block_sync = [&]() {
@@ -768,7 +770,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   const float k_mul = skin_on ? w.skin_mul : 1.f, k_add = skin_on ? w.skin_add : 0.f;
 #pragma unroll
   for (int s = 0; s < S; s++) {
-    if (!OWN) {
+    if (!GIVEN) {
       const int i = base + s * 64 + lane;
       pidx[s] = i < N ? i : -1;
       const NNStart st = nn_warm_start(src, M, Tf, w, pair, i < N ? i : N - 1, cold, skin_on);
@@ -779,7 +781,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     sk_mul[s] = kept[s] ? 0.f : k_mul, sk_add[s] = kept[s] ? -1.f : k_add;
     bestR[s] = kept[s] ? -1.f : fmaf(best[s], sk_mul[s], sk_add[s]);
   }
-  if (!OWN) {
+  if (!GIVEN) {
     bool allk = true;
 #pragma unroll
     for (int s = 0; s < S; s++) allk &= kept[s];
@@ -1157,6 +1159,23 @@ __global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, 
   {
     const unsigned long long nkept = (unsigned long long)__popcll(__ballot(valid && s0.kept));  // (the ballot needs every lane)
     if (w.stats && lane == 0) atomicAdd(w.stats + 6, nkept);
+  }
+  if (W > 1 && w.coop_search && total > 0 && total <= 64) {
+    // One wave's worth of points left in this block (the usual case from the middle of a Gauss-Newton run on: 63 of 256
+    // points search at tick 10, 9 at tick 20): the waves that would leave now split the target groups of that ONE wave between
+    // them instead -- a lone search wave is a serial chain of about 19 us, 12 of them in fetching and scanning its groups.
+    const bool has = lane < total;
+    const float4 cp = cpt[has ? lane : total - 1];
+    const int2 ci = cci[has ? lane : total - 1];
+    __syncthreads();  // (cpt / cci become the scratch of the merge)
+    float px[1] = {cp.x}, py[1] = {cp.y}, pz[1] = {cp.z}, best[1] = {cp.w};
+    unsigned bestc[1] = {(unsigned)ci.x};
+    int pidx[1] = {has ? (ci.y & ~(1 << 30)) : -1};
+    bool kept[1] = {!has};
+    nn_search<1, W, true>(src, tgt, T0, w, pair, 0, lane, wid, cold, txy[wid], tz[wid], cbl[wid], gbl[0], (unsigned long long*)cpt, (float2*)cci, px, py, pz,
+                          best, bestc, pidx, kept, !has || (ci.y & (1 << 30)) == 0);
+    if (wid == 0 && has) out[pidx[0]] = ((unsigned long long)__float_as_uint(best[0]) << 32) | bestc[0];
+    return;
   }
   if (wid * 64 >= total) {  // nothing left for this wave
     if (w.stats && lane == 0) atomicAdd(w.stats + 3, 1ull);

@@ -727,7 +727,9 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
             # one pair group per handle = the throughput regime of bench.py: k_nn_compact (blocks of 256 points that pack the
             # points still searching into fewer waves), and the same regime with one-wave blocks of k_nn_pruned
             # (APDGICP_NN_W=1: six pairs are too few for the engine to choose that regime by itself)
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"},
+            # (in k_nn_compact a block with one wave's worth of points left searches them with all four waves: NN_COOP_TAIL)
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COOP_TAIL": "0"},
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"},
             {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"},
             {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN_REL": "0.3", "APDGICP_NN_SKIN_ABS": "0.03"}, {"APDGICP_NN_W": "1"})
     for kw in (gn, lm):
@@ -754,7 +756,8 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
     s_, t_, _, g_ = scene.make_pair(6000, 40_000, scene.pair_seed(21, 60), kind)
     s2, t2, _, g2 = scene.make_pair(20_000, 30_000, scene.pair_seed(21, 61), kind)
     want = None
-    for env, one_group in (({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True),
+    for env, one_group in (({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_COOP_TAIL": "0"}, True),
+                           ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True),
                            ({"APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"}, True)):
         b = _handle_with_env(reg, reg.BatchAPDGICP, env, **dict(gn, max_iterations=8))
         if one_group:
