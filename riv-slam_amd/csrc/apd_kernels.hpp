@@ -1721,12 +1721,23 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
     }
     if (stats) { const long long t = clock64(); tG += t - tm, tm = t; }
     float4 c0, c1, d0, d1;
-    unsigned o0, o1, p0, p1;
-    auto fetch = [&](int g, float4& a0, float4& a1, unsigned& b0, unsigned& b1) {
+    unsigned o0, o1;
+    int gcur = -1;  // the group whose points are in d0 / d1
+    // The two loads of a group are UNCONDITIONAL (clamped addresses) and nothing looks at them here: what lies beyond the
+    // cloud is replaced when the group becomes current (`take`).  A load that sits in a branch of its own -- `if (j < n)
+    // a = pts[j]`, also when written as a select -- gets its `s_waitcnt vmcnt(0)` right behind it: the group requested "one
+    // ahead" then arrives before the scan of the current one starts, two dependent trips to memory per group.
+    auto fetch = [&](int g) {
       const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
-      a0 = make_float4(inf, inf, inf, 0.f), a1 = a0, b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
-      { const float4 v0 = G(c.pts)[min(j0, n - 1)]; if (j0 < n) a0 = v0, b0 = __float_as_uint(v0.w); }  // (the sorted points carry their original index in .w)
-      { const float4 v1 = G(c.pts)[min(j1, n - 1)]; if (j1 < n) a1 = v1, b1 = __float_as_uint(v1.w); }
+      d0 = G(c.pts)[min(j0, n - 1)];
+      d1 = G(c.pts)[min(j1, n - 1)];
+      gcur = g;
+    };
+    auto take = [&]() {  // d -> c (the sorted points carry their original index in .w)
+      const int j0 = (gb0 + gcur) * kGroupPts + lane, j1 = j0 + 64;
+      const bool v0 = j0 < n, v1 = j1 < n;
+      c0 = make_float4(v0 ? d0.x : inf, v0 ? d0.y : inf, v0 ? d0.z : inf, 0.f), o0 = v0 ? __float_as_uint(d0.w) : 0xFFFFFFFFu;
+      c1 = make_float4(v1 ? d1.x : inf, v1 ? d1.y : inf, v1 ? d1.z : inf, 0.f), o1 = v1 ? __float_as_uint(d1.w) : 0xFFFFFFFFu;
     };
         // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
     // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
@@ -1748,12 +1759,12 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
       return gsel;
     };
     int g = next_group();
-    if (g >= 0) fetch(g, d0, d1, p0, p1);
+    if (g >= 0) fetch(g);
     while (g >= 0) {
-      c0 = d0, c1 = d1, o0 = p0, o1 = p1;
+      take();
       unsigned long long qm = __ballot(((gneed >> g) & 1ull) != 0 && sub == 0);
       g = next_group();
-      if (g >= 0) fetch(g, d0, d1, p0, p1);
+      if (g >= 0) fetch(g);
       n_groups++;
       while (qm) {
         const int qq = __builtin_ctzll(qm);  // owner lane of the query
