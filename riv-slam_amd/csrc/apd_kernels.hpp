@@ -2008,12 +2008,13 @@ struct LinPoint {
 // lp receives this point's quantities (left all zero when it has no correspondence); lin_term turns them into the 29 sums.
 __device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
                                                 int pair, int i, const float4 p, float ptx, float pty, float ptz, float m, unsigned chunk,
-                                                bool tie, bool kept, LinPoint& lp) {
-  const int N = src.n, M = tgt.n;
+                                                bool tie, bool kept, const float4 tq_rec /* nnpt[i], read by the caller */,
+                                                const Sym3& cov_A /* the point's covariance, read by the caller */, LinPoint& lp) {
+  const int M = tgt.n;
   int j = -1;
   float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);  // the neighbour itself
   if (kept) {  // the search proved the previous neighbour still is the nearest one (kKeptBit): index and point are on record
-    tq = w.nnpt[(size_t)pair * w.nstride + i];
+    tq = tq_rec;
     j = __float_as_int(tq.w);
   } else if (chunk != kNoChunk) {
     // exact index: among the targets at distance m, the one with the lowest ORIGINAL index
@@ -2047,9 +2048,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
   const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
   if (w.corr) w.corr[(size_t)pair * w.nstride + i] = corr;
   if (corr >= 0) {
-    const auto ca = G((const double*)src.cov);
     const auto cb = G((const double*)tgt.cov);
-    const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
     const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
     // APD sensor-noise covariance from the transformed point (A:167-184)
     const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
@@ -2226,6 +2225,13 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
   lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
 
   if (i < N) {
+    // everything that depends on the point index alone is requested FIRST -- the point, its covariance, the neighbour on
+    // record -- so that it travels together with the search result: read where they are used these were four dependent trips
+    // to memory (result -> point -> record -> covariances) in a kernel that lasts 21 us
+    const float4 p = G(src.pts)[i];
+    const float4 tq_rec = w.nnpt[(size_t)pair * w.nstride + i];
+    const auto ca = G((const double*)src.cov);
+    const Sym3 cov_A{ca[i], ca[N + i], ca[2 * N + i], ca[3 * N + i], ca[4 * N + i], ca[5 * N + i]};
     unsigned long long bestp = ~0ull;
     bool tie = false;
     const unsigned long long* part = w.nnpart + (size_t)pair * w.T * w.nstride + i;
@@ -2247,9 +2253,8 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     }
     float Tf[12];
     load_Tf(T, Tf);
-    const float4 p = G(src.pts)[i];
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
-    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, lp);
+    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
   block_reduce_lds<29, LIN_BLK>([&](int r) { return lin_term(lp, want_Hb, r); }, red, red_scratch, tid);
