@@ -67,6 +67,13 @@ def test_sharded_aligner_over_the_hip_batch_and_rccl_world_size_1(tmp_path):
     script.write_text(CHILD)
     env = dict(os.environ, APD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and "AssertionError" not in r.stderr and any(k in r.stderr for k in ("NCCL", "TCPStore", "Timeout", "timed out", "Address already in use")):
+        # a rendezvous / communicator start-up problem of the box (seen once in ~60 runs), not a result: one more try.
+        # A wrong result (AssertionError in the child) is never retried.
+        with socket.socket() as s2:
+            s2.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s2.getsockname()[1])
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "world 1 OK" in r.stdout
 
