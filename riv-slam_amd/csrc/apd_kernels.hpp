@@ -1528,8 +1528,9 @@ __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v)
   return v;
 }
 
+// (5 waves per SIMD asked for: the allocation sits at 95 .. 97 registers, and 97 would cost the fifth wave)
 template <int L>
-__global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                      unsigned long long* stats, int raw /* 1: store the population covariance, k_regularize_covs follows */) {
   constexpr int QPW = 64 / L, NCL = KNN_NC / L, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
   static_assert(L == 4 || L == 8 || L == 16, "L lanes per query");
@@ -1734,10 +1735,12 @@ __global__ __launch_bounds__(64) void k_knn_cov_coop(const CloudDesc* clouds, co
       gcur = g;
     };
     auto take = [&]() {  // d -> c (the sorted points carry their original index in .w)
-      const int j0 = (gb0 + gcur) * kGroupPts + lane, j1 = j0 + 64;
-      const bool v0 = j0 < n, v1 = j1 < n;
-      c0 = make_float4(v0 ? d0.x : inf, v0 ? d0.y : inf, v0 ? d0.z : inf, 0.f), o0 = v0 ? __float_as_uint(d0.w) : 0xFFFFFFFFu;
-      c1 = make_float4(v1 ? d1.x : inf, v1 ? d1.y : inf, v1 ? d1.z : inf, 0.f), o1 = v1 ? __float_as_uint(d1.w) : 0xFFFFFFFFu;
+      c0 = d0, c1 = d1, o0 = __float_as_uint(d0.w), o1 = __float_as_uint(d1.w);
+      if ((gb0 + gcur + 1) * kGroupPts > n) {  // (uniform) only the last group of a cloud can reach beyond it
+        const int j0 = (gb0 + gcur) * kGroupPts + lane, j1 = j0 + 64;
+        if (j0 >= n) c0 = make_float4(inf, inf, inf, 0.f), o0 = 0xFFFFFFFFu;
+        if (j1 >= n) c1 = make_float4(inf, inf, inf, 0.f), o1 = 0xFFFFFFFFu;
+      }
     };
         // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
     // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
