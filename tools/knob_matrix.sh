@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs the -m gpu suite under every A/B switch of DESIGN.md section 9 (one line per configuration).
+# Runs the -m gpu suite under every A/B switch listed at the end of docs/experiments.md (one line per configuration).
 # usage (inside gpurun): bash tools/knob_matrix.sh
 for cfg in "" "APDGICP_NN_MODE=brute" "APDGICP_KNN_MODE=brute" "APDGICP_NN_W=1" "APDGICP_NN_W=2" "APDGICP_NN_W=4" "APDGICP_NN_W=8" \
            "APDGICP_NN_S=2" "APDGICP_NN_S=4" "APDGICP_NN_GATE_CAP=0" "APDGICP_KNN_QPW=4" "APDGICP_KNN_QPW=8" "APDGICP_KNN_QPW=16" \
