@@ -199,9 +199,22 @@ def main():
         bh.set_clouds(0, clouds_arg)
         return bh.align_enqueue(pairs_arr)
 
+    # N > 1: the all-gather of a step reads that step's record buffer, which its handle overwrites two enqueues later (the
+    # handle alternates between two buffers).  So the host does not wait for the collective where it issues it, but one round
+    # later, when the same handle is collected again -- just in front of the enqueue that could reuse the buffer.  Waiting at
+    # once made every rank wait for the slowest rank's same step, every step; this way ranks may drift by a few steps.
+    gather_done = {}   # handle -> event behind its last all-gather
+
     def collect_step(bh, ticket):
+        ev = gather_done.get(id(bh))
+        if ev is not None:
+            ev.synchronize()
         local = bh.align_collect(ticket, device=True)        # zero-copy view of that step's records on the device
-        out = aligner.gather(local, total_pairs, wait=True)  # (the host has about a millisecond of slack per step)
+        out = aligner.gather(local, total_pairs, wait=False)
+        if use_dist:
+            if ev is None:
+                ev = gather_done[id(bh)] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
         ms, k, pr = bh.last_nn_profile()
         nn_acc[0] += ms
         nn_acc[1] += k
@@ -220,6 +233,8 @@ def main():
             if tickets[h] is not None:
                 out = collect_step(batches[h], tickets[h])
                 tickets[h] = None
+        for ev in gather_done.values():      # every collective of this run has read its records (and `out` is complete)
+            ev.synchronize()
         return out
 
     def sync_all():
