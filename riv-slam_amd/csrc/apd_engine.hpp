@@ -186,6 +186,10 @@ class Engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // the stream everything that prepares CLOUDS runs on (pack, sort, covariances, descriptor table): `stream` itself, except
+  // while the handle pools Levenberg-Marquardt batches (pool_enter) -- there the preparation of the next batch runs beside the
+  // optimiser ticks of the batches in flight, and a batch's first tick waits for the event behind its own preparation
+  hipStream_t cstream = nullptr;
   apdgicp_params params;
   std::vector<Cloud> clouds;
   bool desc_dirty = true;
@@ -300,7 +304,9 @@ class Engine {
       APD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       own_stream = true;
     }
+    cstream = stream;
     APD_HIP(hipHostMalloc((void**)&h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
+    memset(h_poll, 0, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec));  // the sequence word the host spins on starts at 0
     h_status = (int*)h_poll;
     APD_HIP(hipHostGetDevicePointer((void**)&h_poll_dev, h_poll, 0));
     APD_HIP(hipHostMalloc((void**)&h_probe, 64 * sizeof(double), hipHostMallocDefault));
@@ -373,6 +379,18 @@ class Engine {
     if (ev_poll) e = hipEventDestroy(ev_poll);
     if (ev_main) e = hipEventDestroy(ev_main);
     if (ev_producer) e = hipEventDestroy(ev_producer);
+    if (pool.cstream) e = hipStreamSynchronize(pool.cstream);
+    for (hipEvent_t ev_ : pool.ev)
+      if (ev_) e = hipEventDestroy(ev_);
+    for (PoolJob& j : pool.jobs) {
+      if (j.ev_pro) e = hipEventDestroy(j.ev_pro);
+      if (j.pin) e = hipHostFree(j.pin);
+    }
+    for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.active, &pool.nactive, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
+                      &pool.nnpt, &pool.nnaux, &pool.sqd, &pool.maha, &pool.blkpart, &pool.errpart})
+      b->release();
+    if (pool.host) e = hipHostFree(pool.host);
+    if (pool.cstream) e = hipStreamDestroy(pool.cstream);
     for (HostStage& hs : h_stage) {
       if (hs.ev) e = hipEventDestroy(hs.ev);
       if (hs.p) e = hipHostFree(hs.p);
@@ -390,6 +408,7 @@ class Engine {
       return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
+    if (pool.on) APD_TRY(pool_drain());  // the batches in flight finish with the parameters they were enqueued with
     const bool cov_change = clouds.size() && (p->k_correspondences != params.k_correspondences || p->regularization != params.regularization);
     params = *p;
     if (cov_change)
@@ -424,6 +443,7 @@ class Engine {
     if (!ev_producer) APD_HIP(hipEventCreateWithFlags(&ev_producer, hipEventDisableTiming));
     APD_HIP(hipEventRecord(ev_producer, (hipStream_t)producer));
     APD_HIP(hipStreamWaitEvent(stream, ev_producer, 0));
+    if (cstream != stream) APD_HIP(hipStreamWaitEvent(cstream, ev_producer, 0));
     return 0;
   }
 
@@ -441,11 +461,12 @@ class Engine {
     if (n > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud too large");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
     APD_HIP(hipSetDevice(device));
+    APD_TRY(pool_release_clouds(slot, 1));
     roctx_range rr("apdgicp:pack");
     if ((int)clouds.size() <= slot) clouds.resize(slot + 1);
     Cloud& c = clouds[slot];
     // the previous contents may still be in use by queued kernels on this stream; stream order protects us
-    if ((size_t)n * 16 > c.opts.cap) APD_HIP(hipStreamSynchronize(stream));
+    if ((size_t)n * 16 > c.opts.cap) APD_HIP(hipStreamSynchronize(cstream));
     APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
     c.staged = false;
@@ -460,7 +481,7 @@ class Engine {
         const bool seen = c.stage_seq_word && (int)(*c.stage_seq_word - c.stage_seq_val) >= 0;
         if (seen) std::atomic_thread_fence(std::memory_order_acquire);
         else if (c.stage_wait) APD_HIP(hipEventSynchronize(c.stage_wait));
-        else APD_HIP(hipStreamSynchronize(stream));
+        else APD_HIP(hipStreamSynchronize(cstream));
         c.stage_pending = false, c.stage_wait = nullptr, c.stage_seq_word = nullptr;
       }
       const size_t need = ((size_t)n + 2) * 16;
@@ -489,7 +510,7 @@ class Engine {
       if (stride_bytes >= 16) {  // the fourth float read with the point belongs to the point: one 16-byte load, blend, store
         typedef float v4f __attribute__((ext_vector_type(4)));
         v4f vlo[2] = {v4f(inf), v4f(inf)}, vhi[2] = {v4f(-inf), v4f(-inf)};
-        for (; q + 2 <= n; q += 2)
+        for (; q + 2 <= n - 1; q += 2)  // (not the last point: its fourth float may lie outside the caller's buffer)
           for (int u = 0; u < 2; u++) {
             v4f v;
             memcpy(&v, raw + (q + u) * stride_bytes, 16);
@@ -526,10 +547,10 @@ class Engine {
         const float* sp = (const float*)(raw + q * stride_bytes);
         dst[q] = make_float4(sp[0], sp[1], sp[2], 1.0f);
       }
-      APD_HIP(hipMemcpyAsync(c.opts.p, hs.p, (size_t)n * 16, hipMemcpyHostToDevice, stream));
-      APD_HIP(hipEventRecord(hs.ev, stream));
+      APD_HIP(hipMemcpyAsync(c.opts.p, hs.p, (size_t)n * 16, hipMemcpyHostToDevice, cstream));
+      APD_HIP(hipEventRecord(hs.ev, cstream));
     } else {
-      hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, raw, (long long)stride_bytes, (int)n, c.opts.as<float4>());
+      hipLaunchKernelGGL(k_pack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cstream, raw, (long long)stride_bytes, (int)n, c.opts.as<float4>());
       APD_HIP(hipGetLastError());
     }
     c.n = (int)n;
@@ -546,6 +567,7 @@ class Engine {
     if (!xyz || !ns) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
     APD_HIP(hipSetDevice(device));
+    APD_TRY(pool_release_clouds(first, count));
     roctx_range rr("apdgicp:pack");
     if ((int)clouds.size() < first + count) clouds.resize(first + count);
     bool grew = false;
@@ -555,7 +577,7 @@ class Engine {
       grew |= (size_t)ns[q] * 16 > clouds[first + q].opts.cap;
       nmax = std::max<int>(nmax, (int)ns[q]);
     }
-    if (grew) APD_HIP(hipStreamSynchronize(stream));  // a buffer about to be re-allocated may still be in use
+    if (grew) APD_HIP(hipStreamSynchronize(cstream));  // a buffer about to be re-allocated may still be in use
     std::vector<PackJob> jobs(count);
     for (int q = 0; q < count; q++) {
       Cloud& c = clouds[first + q];
@@ -565,9 +587,10 @@ class Engine {
       c.sorted = false;
       c.cov_valid = false;
       c.token = 0;
+      c.staged = false;  // (a host cloud set before and never sorted: its pinned copy is void now)
     }
-    APD_TRY(d_packjobs.upload(jobs.data(), jobs.size() * sizeof(PackJob), stream));
-    hipLaunchKernelGGL(k_pack_points_multi, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, stream, d_packjobs.as<PackJob>());
+    APD_TRY(d_packjobs.upload(jobs.data(), jobs.size() * sizeof(PackJob), cstream));
+    hipLaunchKernelGGL(k_pack_points_multi, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, cstream, d_packjobs.as<PackJob>());
     APD_HIP(hipGetLastError());
     // device-resident inputs: the caller's buffers are free again once the stream has passed this point
     // (apdgicp_batch_synchronize), no host-side wait here
@@ -578,6 +601,7 @@ class Engine {
   void clear_cloud(int slot) {
     if (slot < (int)clouds.size()) {
       clouds[slot].n = 0;
+      clouds[slot].staged = false;
       clouds[slot].sorted = false;
       clouds[slot].cov_valid = false;
       clouds[slot].token = 0;
@@ -601,7 +625,7 @@ class Engine {
       grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || (ngr + nsup) * sizeof(Box) > c.gbox.cap;
     }
     if (!any) return 0;
-    if (grew) APD_HIP(hipStreamSynchronize(stream));  // old buffers may still be read by queued kernels
+    if (grew) APD_HIP(hipStreamSynchronize(cstream));  // old buffers may still be read by queued kernels
     roctx_range rr("apdgicp:sort");
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
@@ -637,23 +661,23 @@ class Engine {
       desc_dirty = true;
     }
     if (!small.empty()) {
-      APD_TRY(d_sortjobs.upload(small.data(), small.size() * sizeof(SortJob), stream));
-      hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, stream, d_sortjobs.as<SortJob>());
+      APD_TRY(d_sortjobs.upload(small.data(), small.size() * sizeof(SortJob), cstream));
+      hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, cstream, d_sortjobs.as<SortJob>());
       APD_HIP(hipGetLastError());
     }
     for (int cls = 0; cls < 3; cls++) {
       if (regjobs[cls].empty()) continue;
-      APD_TRY(d_sortjobs_reg[cls].upload(regjobs[cls].data(), regjobs[cls].size() * sizeof(SortJob), stream));
+      APD_TRY(d_sortjobs_reg[cls].upload(regjobs[cls].data(), regjobs[cls].size() * sizeof(SortJob), cstream));
       const size_t lds = (size_t)(4 << cls) * SORT_BLK * 8;
       const SortJob* dj = d_sortjobs_reg[cls].as<SortJob>();
       const dim3 grid((unsigned)regjobs[cls].size());
-      if (cls == 0) hipLaunchKernelGGL(k_sort_cloud_reg<4>, grid, dim3(SORT_BLK), lds, stream, dj);
-      else if (cls == 1) hipLaunchKernelGGL(k_sort_cloud_reg<8>, grid, dim3(SORT_BLK), lds, stream, dj);
-      else hipLaunchKernelGGL(k_sort_cloud_reg<16>, grid, dim3(SORT_BLK), lds, stream, dj);
+      if (cls == 0) hipLaunchKernelGGL(k_sort_cloud_reg<4>, grid, dim3(SORT_BLK), lds, cstream, dj);
+      else if (cls == 1) hipLaunchKernelGGL(k_sort_cloud_reg<8>, grid, dim3(SORT_BLK), lds, cstream, dj);
+      else hipLaunchKernelGGL(k_sort_cloud_reg<16>, grid, dim3(SORT_BLK), lds, cstream, dj);
       APD_HIP(hipGetLastError());
     }
     if (tkeys_bytes) {
-      if (tkeys_bytes > d_tkeys.cap) APD_HIP(hipStreamSynchronize(stream));
+      if (tkeys_bytes > d_tkeys.cap) APD_HIP(hipStreamSynchronize(cstream));
       APD_TRY(d_tkeys.ensure(tkeys_bytes));
       for (int cls = 0; cls < 3; cls++) {
         if (tilejobs[cls].empty()) continue;
@@ -662,19 +686,19 @@ class Engine {
           tjb.keys = (unsigned long long*)(d_tkeys.as<char>() + (size_t)tjb.keys);
           nmax_c = std::max(nmax_c, tjb.job.n);
         }
-        APD_TRY(d_tilejobs[cls].upload(tilejobs[cls].data(), tilejobs[cls].size() * sizeof(TileJob), stream));
+        APD_TRY(d_tilejobs[cls].upload(tilejobs[cls].data(), tilejobs[cls].size() * sizeof(TileJob), cstream));
         const TileJob* dj = d_tilejobs[cls].as<TileJob>();
         const unsigned cnt = (unsigned)tilejobs[cls].size();
         const int nt = 1024 << cls;
         const size_t lds = (size_t)nt * 8;
-        if (cls == 0) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
-        else if (cls == 1) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
-        else hipLaunchKernelGGL(k_sort_tiles<4>, dim3(4, cnt), dim3(SORT_BLK), lds, stream, dj);
+        if (cls == 0) hipLaunchKernelGGL(k_sort_tiles<1>, dim3(4, cnt), dim3(SORT_BLK), lds, cstream, dj);
+        else if (cls == 1) hipLaunchKernelGGL(k_sort_tiles<2>, dim3(4, cnt), dim3(SORT_BLK), lds, cstream, dj);
+        else hipLaunchKernelGGL(k_sort_tiles<4>, dim3(4, cnt), dim3(SORT_BLK), lds, cstream, dj);
         for (Cloud& c : clouds)  // the pinned copies are free again behind this launch
           if (c.staged && c.sorted && c.n > (nt << 1) && c.n <= (nt << 2))
             c.staged = false, c.stage_pending = true, c.stage_wait = nullptr, c.stage_seq_word = nullptr, n_stage_pending++;
-        hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned)(4 * nt / SORT_BLK), cnt), dim3(SORT_BLK), (size_t)4 * nt * 8, stream, dj);
-        hipLaunchKernelGGL(k_boxes_sorted, dim3((unsigned)(((nmax_c + 15) / 16 + 255) / 256), cnt), dim3(256), 0, stream, dj);
+        hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned)(4 * nt / SORT_BLK), cnt), dim3(SORT_BLK), (size_t)4 * nt * 8, cstream, dj);
+        hipLaunchKernelGGL(k_boxes_sorted, dim3((unsigned)(((nmax_c + 15) / 16 + 255) / 256), cnt), dim3(256), 0, cstream, dj);
         APD_HIP(hipGetLastError());
       }
     }
@@ -683,31 +707,31 @@ class Engine {
       const int n = c.n;
       int np2 = VOX_TILE;
       while (np2 < n) np2 <<= 1;
-      APD_HIP(hipStreamSynchronize(stream));
+      APD_HIP(hipStreamSynchronize(cstream));
       APD_TRY(d_keys.ensure((size_t)np2 * 8));
       APD_TRY(d_box6.ensure(6 * sizeof(int)));
       const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff};  // +inf x3, -inf x3 (ordered-int)
-      APD_HIP(hipMemcpyAsync(d_box6.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-      APD_HIP(hipStreamSynchronize(stream));
-      hipLaunchKernelGGL(k_bbox_atomic, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, stream, c.opts.as<float4>(), n, d_box6.as<int>());
+      APD_HIP(hipMemcpyAsync(d_box6.p, init, sizeof(init), hipMemcpyHostToDevice, cstream));
+      APD_HIP(hipStreamSynchronize(cstream));
+      hipLaunchKernelGGL(k_bbox_atomic, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, cstream, c.opts.as<float4>(), n, d_box6.as<int>());
       int idx_bits = 1;
       while ((1 << idx_bits) < np2) idx_bits++;
       const int mbits = std::min(21, (64 - idx_bits) / 3);
-      hipLaunchKernelGGL(k_morton_keys, dim3((np2 + 255) / 256), dim3(256), 0, stream, c.opts.as<float4>(), n, np2, d_box6.as<int>(),
+      hipLaunchKernelGGL(k_morton_keys, dim3((np2 + 255) / 256), dim3(256), 0, cstream, c.opts.as<float4>(), n, np2, d_box6.as<int>(),
                          d_keys.as<unsigned long long>(), mbits, idx_bits);
-      hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>());
+      hipLaunchKernelGGL(k_bitonic_tile_sort, dim3(np2 / VOX_TILE), dim3(1024), 0, cstream, d_keys.as<unsigned long long>());
       for (int k = 2 * VOX_TILE; k <= np2; k <<= 1) {
         for (int j = k >> 1; j >= VOX_TILE; j >>= 1)
-          hipLaunchKernelGGL(k_bitonic_global, dim3((np2 / 2 + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), np2, k, j);
-        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(np2 / VOX_TILE), dim3(1024), 0, stream, d_keys.as<unsigned long long>(), k);
+          hipLaunchKernelGGL(k_bitonic_global, dim3((np2 / 2 + 255) / 256), dim3(256), 0, cstream, d_keys.as<unsigned long long>(), np2, k, j);
+        hipLaunchKernelGGL(k_bitonic_tile_merge, dim3(np2 / VOX_TILE), dim3(1024), 0, cstream, d_keys.as<unsigned long long>(), k);
       }
-      hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, stream, d_keys.as<unsigned long long>(), c.opts.as<float4>(), n,
+      hipLaunchKernelGGL(k_gather_sorted, dim3((n + 255) / 256), dim3(256), 0, cstream, d_keys.as<unsigned long long>(), c.opts.as<float4>(), n,
                          c.pts.as<float4>(), c.perm.as<int>(), idx_bits);
       const int nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts;
-      hipLaunchKernelGGL(k_boxes, dim3((nch + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, 16, c.cbox.as<Box>(), nch);
-      hipLaunchKernelGGL(k_boxes, dim3((ngr + 255) / 256), dim3(256), 0, stream, c.pts.as<float4>(), n, kGroupPts, c.gbox.as<Box>(), ngr);
+      hipLaunchKernelGGL(k_boxes, dim3((nch + 255) / 256), dim3(256), 0, cstream, c.pts.as<float4>(), n, 16, c.cbox.as<Box>(), nch);
+      hipLaunchKernelGGL(k_boxes, dim3((ngr + 255) / 256), dim3(256), 0, cstream, c.pts.as<float4>(), n, kGroupPts, c.gbox.as<Box>(), ngr);
       const int nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
-      hipLaunchKernelGGL(k_super_boxes, dim3((nsup + 63) / 64), dim3(64), 0, stream, c.gbox.as<Box>(), ngr, nsup);
+      hipLaunchKernelGGL(k_super_boxes, dim3((nsup + 63) / 64), dim3(64), 0, cstream, c.gbox.as<Box>(), ngr, nsup);
       APD_HIP(hipGetLastError());
     }
     return 0;
@@ -729,7 +753,7 @@ class Engine {
       h[i].n = clouds[i].n;
       h[i].pad_ = 0;
     }
-    APD_TRY(d_desc.upload(h.data(), h.size() * sizeof(CloudDesc), stream));
+    APD_TRY(d_desc.upload(h.data(), h.size() * sizeof(CloudDesc), cstream));
     desc_dirty = false;
     return 0;
   }
@@ -743,16 +767,16 @@ class Engine {
   int check_errflag(const char* what) {
     int flag = 0;
     int* h_flag = (int*)(h_poll + kHostResults * sizeof(ResultRec)) + 65539;  // last pinned word: never part of a poll
-    APD_HIP(hipMemcpyAsync(h_flag, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    APD_HIP(hipStreamSynchronize(stream));
+    APD_HIP(hipMemcpyAsync(h_flag, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, cstream));
+    APD_HIP(hipStreamSynchronize(cstream));
     flag = h_flag[0];
     if (flag && env_int("APDGICP_IGNORE_ERRFLAG", 0)) {  // debugging aid only
       fprintf(stderr, "[apdgicp] %s: device error flag %d ignored\n", what, flag);
-      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), cstream));
       return 0;
     }
     if (flag) {
-      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
+      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), cstream));
       return fail(APDGICP_ERR_INTERNAL, std::string(what) + ": " + errflag_text(flag));
     }
     return 0;
@@ -766,8 +790,8 @@ class Engine {
     if (ids.empty()) return 0;
     APD_HIP(hipSetDevice(device));
     APD_TRY(upload_desc());
-    APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), stream));
-    APD_TRY(launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), stream));
+    APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), cstream));
+    APD_TRY(launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), cstream));
     if (!defer_errflag) APD_TRY(check_errflag("k_knn_cov"));
     return 0;
   }
@@ -836,6 +860,7 @@ class Engine {
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
+    APD_TRY(pool_leave());
     h_pairs.resize(n);
     std::vector<float>& guesses = h_guesses;
     guesses.resize((size_t)n * 16);
@@ -960,12 +985,20 @@ class Engine {
     hipStream_t st;
   };
   Span whole() const { return Span{0, npairs, stream}; }
+  // what the tick launches run over: the batch set up by setup_pairs, or (inside pool_enqueue_chunk) the pair pool
+  bool in_pool = false;
+  const Work& t_work() const { return in_pool ? pool.work : work; }
+  const PairDesc* t_pairs() const { return in_pool ? pool.pairs.as<PairDesc>() : d_pairs.as<PairDesc>(); }
+  PairState* t_state() const { return in_pool ? pool.state.as<PairState>() : d_state.as<PairState>(); }
+  int t_npairs() const { return in_pool ? pool.cap : npairs; }
+  int t_nmax_src() const { return in_pool ? pool.nmax_src : nmax_src; }
+  int t_nmax_tgt() const { return in_pool ? pool.nmax_tgt : nmax_tgt; }
 
   int launch_nn(Span sp) {
-    const int src_blocks = nn_pruned ? (nmax_src + 64 * nn_S - 1) / (64 * nn_S) : (nmax_src + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
-    dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)work.T, nn_pruned ? 1u : (unsigned)sp.np);
+    const int src_blocks = nn_pruned ? (t_nmax_src() + 64 * nn_S - 1) / (64 * nn_S) : (t_nmax_src() + NN_BLK * nn_S - 1) / (NN_BLK * nn_S);
+    dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)t_work().T, nn_pruned ? 1u : (unsigned)sp.np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = profile_nn && ((cur_tick + profile_phase) % profile_stride == 0);
+    const bool timed = profile_nn && !in_pool && ((cur_tick + profile_phase) % profile_stride == 0);
     if (timed) {
       nn_pairs_acc += sp.np;
       if (nn_events_used == nn_events.size()) {
@@ -978,9 +1011,9 @@ class Engine {
       nn_events_used++;
     }
     const CloudDesc* cd = d_desc.as<CloudDesc>();
-    const PairDesc* pd = d_pairs.as<PairDesc>();
-    const PairState* st = d_state.as<PairState>();
-    Work w = work;
+    const PairDesc* pd = t_pairs();
+    const PairState* st = t_state();
+    Work w = t_work();
     w.pair0 = sp.p0;
     w.cap = nn_cap;
     w.init = init_tick ? d_guess.as<Rigid>() : nullptr;
@@ -988,22 +1021,22 @@ class Engine {
     // a profiler reports them, not the stream's idle gaps around it
 #define APD_NN_LAUNCH(KERNEL, BLOCK) (last_nn_kernel = #KERNEL, hipExtLaunchKernelGGL(KERNEL, grid, dim3(BLOCK), 0, sp.st, e0, e1, 0, cd, pd, st, w))
     // all groups tick together; an LM batch shrinks to its slow pairs, and those few get the wave split of a small batch
-    const long long tick_blocks = (long long)(cur_active > 0 ? cur_active : npairs) * src_blocks;
+    const long long tick_blocks = (long long)(cur_active > 0 ? cur_active : t_npairs()) * src_blocks;
     // large (dense) targets: a wave's 64 points touch many more groups (10.8 instead of 1.7 per wave for 100k x 500k), so
     // splitting the scans over 4 waves still pays with a few thousand blocks (r01: 0.170 -> 0.143 ms per iteration)
-    const bool big_target = nmax_tgt > SORT_LDS_MAX_N;
+    const bool big_target = t_nmax_tgt() > SORT_LDS_MAX_N;
     // a handle limited to one pair group shares the GPU with other busy handles: throughput counts there, not the latency of
     // this launch, and one wave per 64 points does no redundant bound work (three handles in flight: 1.32 -> 1.27 ms per step)
-    const int w_full = max_groups == 1 ? 1 : 2;
+    const int w_full = max_groups == 1 || in_pool ? 1 : 2;
     const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
     // throughput regime (one wave per 64 points) with neighbour keeping on: blocks of 256 points that pack the points still
     // searching into as few waves as they fill (k_nn_compact)
     // (not for dense targets beyond 16384 points when the engine chose the regime itself: a wave there walks many batches of
     // group boxes, and 100k x 500k measured 0.232 ms per iteration against 0.170 with one-wave blocks, 0.103 with W = 4)
-    if (nn_pruned && nn_S == 1 && W == 1 && work.nnaux && nn_compact && (!big_target || nn_W == 1)) {
+    if (nn_pruned && nn_S == 1 && W == 1 && t_work().nnaux && nn_compact && (!big_target || nn_W == 1)) {
       // (blocks of 512 points waste half as many tail waves -- 29.5 instead of 36 search waves per 256 points over the 20
       // ticks of the bench -- but hold twice the LDS until their slowest wave is done: measured 34.7 k vs 37.0 k registrations/s)
-      grid.x = (unsigned)((nmax_src + 255) / 256);
+      grid.x = (unsigned)((t_nmax_src() + 255) / 256);
       APD_NN_LAUNCH(k_nn_compact<4>, 256);
     } else if (nn_pruned) {
       if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
@@ -1020,25 +1053,25 @@ class Engine {
   }
 
   int launch_linearize(Span sp, int mode /* 0 cost only, 1 H/b/cost, 2 + fused GN/LM step */) {
-    const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
-    Work w = work;
+    const dim3 grid((unsigned)((t_nmax_src() + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
+    Work w = t_work();
     w.pair0 = sp.p0;
     w.init = init_tick && mode == 2 ? d_guess.as<Rigid>() : nullptr;
     if (mode == 2)
-      hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
+      hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
                          consts(), mode);
     else
-      hipLaunchKernelGGL(k_linearize<false>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
+      hipLaunchKernelGGL(k_linearize<false>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
                          consts(), mode);
     return 0;
   }
 
   int launch_error(Span sp, bool fuse) {
-    const dim3 grid((unsigned)((nmax_src + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
-    Work w = work;
+    const dim3 grid((unsigned)((t_nmax_src() + LIN_BLK - 1) / LIN_BLK), (unsigned)sp.np);
+    Work w = t_work();
     w.pair0 = sp.p0;
     if (fuse && post_tick) w.post = d_post.as<PollPost>(), w.post_seq = poll_seq;
-    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w,
+    hipLaunchKernelGGL(k_error, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
                        consts(), fuse ? 1 : 0);
     return 0;
   }
@@ -1054,7 +1087,7 @@ class Engine {
   // one tick of the state machines of the pairs in `sp`
   int launch_tick(Span sp) {
     const Consts c = consts();
-    Work w = work;
+    Work w = t_work();
     w.pair0 = sp.p0;
     nn_cap = gate_cap();
     const int rc_nn = launch_nn(sp);
@@ -1062,11 +1095,11 @@ class Engine {
     APD_TRY(rc_nn);
     APD_TRY(launch_linearize(sp, fuse_lm ? 2 : 1));
     if (!fuse_lm)
-      hipLaunchKernelGGL(k_lm_solve, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w, c);
+      hipLaunchKernelGGL(k_lm_solve, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, c);
     if (params.optimizer == APDGICP_OPT_LM) {
       APD_TRY(launch_error(sp, fuse_lm));
       if (!fuse_lm)
-        hipLaunchKernelGGL(k_lm_decide, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), d_pairs.as<PairDesc>(), d_state.as<PairState>(), w, c);
+        hipLaunchKernelGGL(k_lm_decide, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, c);
     }
     return 0;
   }
@@ -1094,6 +1127,7 @@ class Engine {
   int ensure_alt_slot() {
     if (alt.h_poll) return 0;
     APD_HIP(hipHostMalloc((void**)&alt.h_poll, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec), hipHostMallocDefault));
+    memset(alt.h_poll, 0, 65540 * sizeof(int) + kHostResults * sizeof(ResultRec));
     APD_HIP(hipHostGetDevicePointer((void**)&alt.h_poll_dev, alt.h_poll, 0));
     alt.h_status = (int*)alt.h_poll;
     APD_HIP(hipEventCreateWithFlags(&alt.ev_poll, hipEventDisableTiming));
@@ -1296,6 +1330,363 @@ class Engine {
       APD_HIP(hipStreamSynchronize(stream));
       APD_TRY(collect_nn_profile());
     }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ pooled Levenberg-Marquardt batches
+  // (see k_pool_poll in apd_kernels.hpp for the device side)  A batch handle whose optimiser is LM keeps the pairs of up to
+  // `lanes` batches in one pool of pair slots; enqueue prepares the batch's clouds on the cloud stream, hands its pair
+  // descriptors and guesses to the lane and returns; the ticks -- every launch over the device-side list of running pairs --
+  // are enqueued in chunks of a few, always `depth` chunks ahead of the header the host has seen, by whichever call of the
+  // handle is running (enqueue tops up, collect pumps until its batch is done).  A cloud slot referenced by a batch in flight
+  // must not be replaced: set_cloud on such a slot first waits for that batch.
+  struct PoolJob {
+    enum State { FREE, PENDING, RUNNING, DONE };
+    State state = FREE;
+    uint64_t ticket = 0, admit_seq = 0;
+    int np = 0;
+    bool collected = false;
+    int err = 0;
+    std::string errmsg;
+    std::vector<int> cloud_ids;       // (unique) clouds the batch reads
+    std::vector<std::pair<int, int>> pair_ids;
+    std::vector<ResultRec> recs;      // host copy of the records, taken when the batch completed
+    hipEvent_t ev_pro = nullptr;      // behind the preparation of its clouds (cloud stream)
+    char* pin = nullptr;              // staging of the lane's pair descriptors and guesses
+    size_t pin_cap = 0;
+  };
+  struct Pool {
+    bool on = false;
+    bool layout_valid = false;
+    int lanes = 0, segcap = 0, cap = 0, nmax_src = 0, nmax_tgt = 0;
+    hipStream_t cstream = nullptr;
+    DevBuf state, pairs, guess, active, nactive, results, ticket, nnpart, corr, nnpt, nnaux, sqd, maha, blkpart, errpart;
+    Work work{};
+    char* host = nullptr;  // pinned: ResultRec[cap], then PoolHdr[kPoolRing]
+    char* host_dev = nullptr;
+    size_t host_cap = 0;
+    hipEvent_t ev[kPoolRing] = {};
+    PoolJob jobs[kPoolLanes];
+    uint64_t seq_enq = 0, seq_seen = 0;
+    int adm[kPoolRing] = {};
+    int ub = 0;  // upper bound of the device's list length behind the last ENQUEUED poll
+    int kill_mask = 0;
+    int ticks_per_chunk = 2, depth = 2;
+    int last_lane = -1;
+    long long n_chunks = 0, n_ticks = 0, n_pair_ticks = 0;  // statistics (apdgicp_batch_last_ticks)
+    std::vector<int> cloud_busy;
+  } pool;
+
+  bool pool_eligible() const {
+    const bool enabled = env_int("APDGICP_LM_POOL", 1) != 0;  // (0: the host-polled loop of run_align, the cross-check)
+    return enabled && params.optimizer == APDGICP_OPT_LM && params.max_iterations > 0 && nn_pruned && fuse_lm;
+  }
+  PoolHdr* pool_hdr(uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing; }
+  bool pool_busy() const {
+    for (const PoolJob& j : pool.jobs)
+      if (j.state == PoolJob::PENDING || j.state == PoolJob::RUNNING) return true;
+    return false;
+  }
+
+  int pool_enter() {
+    if (pool.on) return 0;
+    APD_HIP(hipStreamSynchronize(stream));  // whatever the clouds went through on the main stream so far
+    if (!pool.cstream) {
+      APD_HIP(hipStreamCreateWithFlags(&pool.cstream, hipStreamNonBlocking));
+      for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&pool.ev[i], hipEventDisableTiming));
+      for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
+      pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 2)));
+      pool.depth = std::max(1, std::min(kPoolRing - 2, env_int("APDGICP_POOL_DEPTH", 2)));
+    }
+    cstream = pool.cstream;
+    pool.on = true;
+    return 0;
+  }
+  // back to one stream: every other entry point (Gauss-Newton batches, fitness, probes) prepares clouds and ticks in stream order
+  int pool_leave() {
+    if (!pool.on) return 0;
+    APD_TRY(pool_drain());
+    APD_HIP(hipStreamSynchronize(pool.cstream));
+    APD_HIP(hipStreamSynchronize(stream));
+    for (Cloud& c : clouds) c.stage_pending = false, c.stage_wait = nullptr, c.stage_seq_word = nullptr;  // (every sort has run)
+    n_stage_pending = 0;
+    cstream = stream;
+    pool.on = false;
+    return 0;
+  }
+
+  int pool_layout(int n, int nsrc, int ntgt) {
+    pool.nmax_tgt = std::max(pool.nmax_tgt, ntgt);
+    if (pool.layout_valid && n <= pool.segcap && nsrc <= pool.nmax_src) return 0;
+    APD_TRY(pool_drain());
+    APD_HIP(hipStreamSynchronize(stream));
+    const int segcap = std::max(pool.segcap, n);
+    const int nmax = std::max(pool.nmax_src, nsrc);
+    const size_t ns = ((size_t)nmax + 255) & ~(size_t)255, nblk = (nmax + LIN_BLK - 1) / LIN_BLK;
+    const size_t per_pair = ns * 96 + nblk * (kRed + 1) * 8 + sizeof(PairState) + sizeof(PairDesc) + sizeof(Rigid) + 2 * sizeof(ResultRec) + 16;
+    int lanes = std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 4)));
+    while (lanes > 1 && (size_t)lanes * segcap * per_pair > ((size_t)16 << 30)) lanes--;
+    const int cap = lanes * segcap;
+    APD_TRY(pool.state.ensure((size_t)cap * sizeof(PairState)));
+    APD_TRY(pool.pairs.ensure((size_t)cap * sizeof(PairDesc)));
+    APD_TRY(pool.guess.ensure((size_t)cap * sizeof(Rigid)));
+    APD_TRY(pool.active.ensure((size_t)cap * sizeof(int)));
+    APD_TRY(pool.nactive.ensure(sizeof(int)));
+    APD_TRY(pool.results.ensure((size_t)cap * sizeof(ResultRec)));
+    APD_TRY(pool.ticket.ensure((size_t)2 * cap * sizeof(int)));
+    APD_TRY(pool.nnpart.ensure((size_t)cap * ns * 8));
+    APD_TRY(pool.corr.ensure((size_t)cap * ns * 4));
+    APD_TRY(pool.nnpt.ensure((size_t)cap * ns * 16));
+    APD_TRY(pool.nnaux.ensure((size_t)cap * ns * 16));
+    APD_TRY(pool.sqd.ensure((size_t)cap * ns * 4));
+    APD_TRY(pool.maha.ensure((size_t)cap * 6 * ns * 8));
+    APD_TRY(pool.blkpart.ensure((size_t)cap * nblk * kRed * 8));
+    APD_TRY(pool.errpart.ensure((size_t)cap * nblk * 8));
+    const size_t host_bytes = (size_t)cap * sizeof(ResultRec) + kPoolRing * sizeof(PoolHdr);
+    if (host_bytes > pool.host_cap) {
+      if (pool.host) APD_HIP(hipHostFree(pool.host));
+      pool.host = pool.host_dev = nullptr, pool.host_cap = 0;
+      APD_HIP(hipHostMalloc((void**)&pool.host, host_bytes, hipHostMallocDefault));
+      APD_HIP(hipHostGetDevicePointer((void**)&pool.host_dev, pool.host, 0));
+      pool.host_cap = host_bytes;
+    }
+    memset(pool.host, 0, pool.host_cap);  // (also the sequence words: a header counts once its word equals the expected number, never 0)
+    APD_HIP(hipMemsetAsync(pool.nactive.p, 0, sizeof(int), stream));
+    APD_HIP(hipMemsetAsync(pool.active.p, 0xff, (size_t)cap * sizeof(int), stream));
+    APD_HIP(hipStreamSynchronize(stream));
+    Work& w = pool.work;
+    w = Work{};
+    w.T = 1;
+    w.nstride = (int)ns, w.nblk_max = (int)nblk;
+    w.cap = std::numeric_limits<float>::infinity();
+    w.nnpart = pool.nnpart.as<unsigned long long>();
+    w.corr = pool.corr.as<int>();
+    w.nnpt = pool.nnpt.as<float4>();
+    w.nnaux = nn_skin ? pool.nnaux.as<float4>() : nullptr;
+    w.skin_mul = (1.f + nn_skin_rel) * (1.f + nn_skin_rel);
+    w.skin_add = nn_skin_abs * nn_skin_abs;
+    w.sqd = pool.sqd.as<float>();
+    w.maha = pool.maha.as<double>();
+    w.blkpart = pool.blkpart.as<double>();
+    w.errpart = pool.errpart.as<double>();
+    w.stats = d_stats.as<unsigned long long>();
+    w.ticket = pool.ticket.as<int>();
+    w.coop_search = nn_coop_tail ? 1 : 0;
+    w.pair0 = 0, w.npairs = cap;
+    w.active = pool.active.as<int>();
+    nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)
+    pool.lanes = lanes, pool.segcap = segcap, pool.cap = cap, pool.nmax_src = nmax;
+    pool.ub = 0, pool.seq_seen = pool.seq_enq;  // (nothing is in flight; headers of older chunks were wiped)
+    for (int& a : pool.adm) a = 0;
+    pool.layout_valid = true;
+    return 0;
+  }
+
+  void pool_job_finished(PoolJob& j) {
+    j.state = PoolJob::DONE;
+    for (int id : j.cloud_ids)
+      if (id < (int)pool.cloud_busy.size() && pool.cloud_busy[id] > 0) pool.cloud_busy[id]--;
+  }
+
+  // one chunk: the poll (completions of everything enqueued before, admissions) and ticks_per_chunk ticks over the list
+  int pool_enqueue_chunk() {
+    PoolAdmit adm{};
+    int admitted = 0;
+    for (int l = 0; l < pool.lanes; l++) {
+      PoolJob& j = pool.jobs[l];
+      if (j.state != PoolJob::PENDING) continue;
+      APD_HIP(hipStreamWaitEvent(stream, j.ev_pro, 0));  // its clouds: sorted, covariances computed
+      adm.seg0[adm.count] = l * pool.segcap, adm.np[adm.count] = j.np, adm.count++;
+      j.state = PoolJob::RUNNING, j.admit_seq = pool.seq_enq + 1;
+      admitted += j.np;
+    }
+    adm.kill_mask = pool.kill_mask, pool.kill_mask = 0;
+    const uint64_t seq = ++pool.seq_enq;
+    pool.adm[seq % kPoolRing] = admitted;
+    PoolHdr* hdr_dev = (PoolHdr*)(pool.host_dev + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing;
+    hipLaunchKernelGGL(k_pool_poll, dim3(1), dim3(256), 0, stream, pool.state.as<PairState>(), pool.active.as<int>(), pool.nactive.as<int>(), pool.cap,
+                       pool.segcap, adm, pool.guess.as<Rigid>(), params.max_iterations, pool.ticket.as<int>(), pool.results.as<ResultRec>(),
+                       (ResultRec*)pool.host_dev, hdr_dev, (int)seq, d_errflag.as<int>());
+    APD_HIP(hipEventRecord(pool.ev[seq % kPoolRing], stream));
+    pool.ub += admitted;
+    pool.n_chunks++;
+    if (pool.ub > 0) {
+      roctx_range rr("apdgicp:pool_ticks");
+      struct Reset {
+        Engine& e;
+        ~Reset() { e.in_pool = false, e.cur_active = 0; }
+      } reset{*this};
+      in_pool = true, cur_active = pool.ub;
+      for (int t = 0; t < pool.ticks_per_chunk; t++) APD_TRY(launch_tick(Span{0, pool.ub, stream}));
+      pool.n_ticks += pool.ticks_per_chunk, pool.n_pair_ticks += (long long)pool.ticks_per_chunk * pool.ub;
+    }
+    APD_HIP(hipGetLastError());
+    return 0;
+  }
+
+  int pool_process(uint64_t seq) {  // header `seq` has arrived
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const PoolHdr h = *pool_hdr(seq);
+    pool.seq_seen = seq;
+    int ub = h.n_active;
+    for (uint64_t c = seq + 1; c <= pool.seq_enq; c++) ub += pool.adm[c % kPoolRing];
+    pool.ub = ub;
+    if (h.errflag) {  // raised by a covariance launch: whose, the flag does not say -- every batch in flight fails
+      for (int l = 0; l < pool.lanes; l++) {
+        PoolJob& j = pool.jobs[l];
+        if (j.state != PoolJob::PENDING && j.state != PoolJob::RUNNING) continue;
+        j.err = APDGICP_ERR_INTERNAL, j.errmsg = errflag_text(h.errflag);
+        if (j.state == PoolJob::PENDING) pool_job_finished(j);
+        else pool.kill_mask |= 1 << l;  // its pairs end with the next poll
+      }
+    }
+    for (int l = 0; l < pool.lanes; l++) {
+      PoolJob& j = pool.jobs[l];
+      if (j.state != PoolJob::RUNNING || j.admit_seq > seq || h.lane_left[l] != 0) continue;
+      j.recs.resize(j.np);
+      memcpy(j.recs.data(), (const ResultRec*)pool.host + (size_t)l * pool.segcap, (size_t)j.np * sizeof(ResultRec));
+      pool_job_finished(j);
+    }
+    return 0;
+  }
+
+  int pool_topup() {
+    for (;;) {
+      if ((int)(pool.seq_enq - pool.seq_seen) >= pool.depth) return 0;
+      bool pending = pool.kill_mask != 0;
+      for (const PoolJob& j : pool.jobs) pending |= j.state == PoolJob::PENDING;
+      if (pool.ub <= 0 && !pending) return 0;
+      APD_TRY(pool_enqueue_chunk());
+    }
+  }
+
+  // serves the pool: reads the headers that have arrived, keeps `depth` chunks enqueued; block: waits for one more header
+  int pool_pump(bool block) {
+    if (!pool.layout_valid) return block ? fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight") : 0;
+    APD_HIP(hipSetDevice(device));
+    while (pool.seq_seen < pool.seq_enq && *(volatile int*)&pool_hdr(pool.seq_seen + 1)->seq == (int)(pool.seq_seen + 1))
+      APD_TRY(pool_process(pool.seq_seen + 1));
+    APD_TRY(pool_topup());
+    if (!block) return 0;
+    if (pool.seq_seen == pool.seq_enq) return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for");
+    const uint64_t want = pool.seq_seen + 1;
+    volatile int* word = (volatile int*)&pool_hdr(want)->seq;
+    {
+      roctx_range rr("apdgicp:pool_wait");
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (unsigned it = 0; !seen; it++) {
+        seen = *word == (int)want;
+        if (!seen && (it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(600)) break;
+      }
+      if (!seen) {
+        APD_HIP(hipEventSynchronize(pool.ev[want % kPoolRing]));
+        if (*word != (int)want) return fail(APDGICP_ERR_INTERNAL, "pool: a poll finished without posting its header");
+      }
+    }
+    APD_TRY(pool_process(want));
+    return pool_topup();
+  }
+
+  int pool_drain() {
+    while (pool_busy()) APD_TRY(pool_pump(true));
+    return 0;
+  }
+  // before a cloud slot is replaced: the batches in flight that read it
+  int pool_release_clouds(int first, int count) {
+    if (!pool.on) return 0;
+    for (int q = first; q < first + count; q++)
+      while (q >= 0 && q < (int)pool.cloud_busy.size() && pool.cloud_busy[q] > 0) APD_TRY(pool_pump(true));
+    return 0;
+  }
+
+  int pool_enqueue(const apdgicp_pair* pairs, int64_t n, uint64_t* ticket) {
+    if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
+    APD_HIP(hipSetDevice(device));
+    APD_TRY(pool_enter());
+    std::vector<int> need;
+    int nsrc = 0, ntgt = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const int s = pairs[i].source_cloud, t = pairs[i].target_cloud;
+      if (s < 0 || t < 0 || s >= (int)clouds.size() || t >= (int)clouds.size() || clouds[s].n <= 0 || clouds[t].n <= 0)
+        return fail(APDGICP_ERR_NO_INPUT, "pair references a cloud that is not set");
+      need.push_back(s), need.push_back(t);
+      nsrc = std::max(nsrc, clouds[s].n), ntgt = std::max(ntgt, clouds[t].n);
+    }
+    APD_TRY(pool_layout((int)n, nsrc, ntgt));
+    APD_TRY(pool_pump(false));
+    // a lane: a free one, else that of the oldest collected batch, else that of the oldest batch (waited for if it still runs;
+    // its ticket is void from here on)
+    int lane = -1, best_rank = 3;
+    uint64_t best_ticket = ~0ull;
+    for (int l = 0; l < pool.lanes; l++) {
+      const PoolJob& c = pool.jobs[l];
+      const int rank = c.state == PoolJob::FREE ? 0 : c.state == PoolJob::DONE && c.collected ? 1 : 2;
+      if (rank < best_rank || (rank == best_rank && c.ticket < best_ticket)) lane = l, best_rank = rank, best_ticket = c.ticket;
+    }
+    while (pool.jobs[lane].state == PoolJob::PENDING || pool.jobs[lane].state == PoolJob::RUNNING) APD_TRY(pool_pump(true));  // (the oldest batch: its lane is next)
+    PoolJob& j = pool.jobs[lane];
+    // the clouds of this batch, on the cloud stream: sort, covariances of those that lack them, descriptor table
+    std::vector<int> ids;
+    APD_TRY(filter_cov_ids(need, false, ids));
+    APD_TRY(upload_desc());
+    if (!ids.empty()) {
+      APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), cstream));
+      APD_TRY(launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), cstream));
+    }
+    APD_HIP(hipEventRecord(j.ev_pro, cstream));
+    if (n_stage_pending) {  // pinned host clouds read by a sort in front of this event
+      for (Cloud& c : clouds)
+        if (c.stage_pending && !c.stage_wait) c.stage_wait = j.ev_pro, c.stage_seq_word = nullptr;
+      n_stage_pending = 0;
+    }
+    // descriptors and guesses of the lane's pairs: staged in the lane's pinned buffer (its last reader, the copy of the lane's
+    // previous batch, is long done), copied in stream order in front of the chunk that admits them
+    const size_t bytes = (size_t)n * (sizeof(PairDesc) + sizeof(Rigid));
+    if (bytes > j.pin_cap) {
+      if (j.pin) APD_HIP(hipHostFree(j.pin));
+      j.pin = nullptr, j.pin_cap = 0;
+      APD_HIP(hipHostMalloc((void**)&j.pin, bytes * 2, hipHostMallocDefault));
+      j.pin_cap = bytes * 2;
+    }
+    PairDesc* hp = (PairDesc*)j.pin;
+    Rigid* hg = (Rigid*)(j.pin + (size_t)n * sizeof(PairDesc));
+    j.pair_ids.resize(n);
+    for (int64_t i = 0; i < n; i++) {
+      const int s = pairs[i].source_cloud, t = pairs[i].target_cloud;
+      hp[i].src = s, hp[i].tgt = t, hp[i].s = h_desc[s], hp[i].t = h_desc[t];
+      j.pair_ids[i] = {s, t};
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) hg[i].m[4 * r + c] = (double)pairs[i].guess[r + 4 * c];  // L:56 x0 = guess.cast<double>()
+    }
+    APD_HIP(hipMemcpyAsync(pool.pairs.as<PairDesc>() + (size_t)lane * pool.segcap, hp, (size_t)n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
+    APD_HIP(hipMemcpyAsync(pool.guess.as<Rigid>() + (size_t)lane * pool.segcap, hg, (size_t)n * sizeof(Rigid), hipMemcpyHostToDevice, stream));
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    if (pool.cloud_busy.size() < clouds.size()) pool.cloud_busy.resize(clouds.size(), 0);
+    for (int id : need) pool.cloud_busy[id]++;
+    j.cloud_ids = need;
+    j.state = PoolJob::PENDING, j.ticket = ++align_seq, j.np = (int)n, j.collected = false, j.err = 0, j.errmsg.clear(), j.admit_seq = 0;
+    pool.last_lane = lane;
+    *ticket = j.ticket;
+    return pool_pump(false);
+  }
+
+  PoolJob* pool_find(uint64_t ticket) {
+    for (int l = 0; l < kPoolLanes; l++)
+      if (pool.jobs[l].state != PoolJob::FREE && pool.jobs[l].ticket == ticket) return &pool.jobs[l];
+    return nullptr;
+  }
+  // waits for the batch of `ticket`; d_out / host_out as apdgicp_batch_align_collect
+  int pool_collect(uint64_t ticket, void** d_out, apdgicp_result* host_out) {
+    PoolJob* j = pool_find(ticket);
+    if (!j) return fail(APDGICP_ERR_INVALID_ARG, "ticket is not one of the batches in flight (its lane has been reused)");
+    while (j->state != PoolJob::DONE) APD_TRY(pool_pump(true));
+    j->collected = true;
+    last_ticks = (int)std::min<long long>(pool.n_ticks, 1 << 30);
+    if (j->err) return fail(j->err, j->errmsg);
+    if (d_out) *d_out = pool.results.as<ResultRec>() + (size_t)(j - pool.jobs) * pool.segcap;
+    if (host_out) memcpy(host_out, j->recs.data(), (size_t)j->np * sizeof(ResultRec));
     return 0;
   }
 

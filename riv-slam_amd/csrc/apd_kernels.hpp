@@ -1082,6 +1082,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
+  if (pair < 0) return;  // (pooled batches: the launch was sized for more pairs than are still running)
   const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const bool cold = w.init || st[pair].n_lin == 0;  // no linearize yet in this align: the hint array holds leftovers, ignore it
   const PairDesc pd = pairs[pair];
@@ -1122,6 +1123,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, 
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
+  if (pair < 0) return;
   const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;
   const bool cold = w.init || st[pair].n_lin == 0;
   const PairDesc pd = pairs[pair];
@@ -2214,6 +2216,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
+  if (pair < 0) return;
   const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
   const PairDesc pd = pairs[pair];
   const Rigid T = *(w.init ? w.init + pair : &st[pair].x0);
@@ -2315,6 +2318,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   unsigned bx, by;
   xcd_remap(bx, by);
   const int pair = pair_of(w, by);
+  if (pair < 0) return;
   if (st[pair].status != ST_NEED_ERR) {
     if (w.post && bx == 0 && threadIdx.x == 0) post_result(*w.post, w.post_seq, st[pair]);  // (the step ended in k_linearize)
     return;
@@ -2656,6 +2660,90 @@ __device__ __forceinline__ void finalize_pair(const PairState* st, ResultRec* ou
   if (host_out) host_out[p] = r;
   if (status_out) status_out[p] = s.status;
   if (host_status) host_status[p] = s.status;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Pooled Levenberg-Marquardt batches (Engine::pool_*).  The run length of an LM registration is data dependent (L:64-76:
+// 2 ... 51 outer iterations over the loop-closure pairs of one batch), so the host cannot enqueue "the" ticks of a batch;
+// waiting for a status poll every few ticks left the GPU idle during every round trip and held a whole batch by its slowest
+// pair.  Instead the pairs of ALL batches in flight on a handle sit in one pool of pair slots (lane = the segment of one
+// batch) and every tick launch covers the device-side list of the pairs that still run.  This kernel is the only
+// bookkeeping between chunks of ticks, one block:
+//   * drops the pairs that reached ST_DONE from the list (stable, in place) and writes their result records -- device copy
+//     and pinned host copy (k_finalize's work, per pair, once);
+//   * admits the pairs of newly enqueued batches: state from the guess (L:56-59, k_init_state's work), arrival counters
+//     zeroed, appended to the list;
+//   * pads the list with -1 (tick launches are sized by the host's upper bound of its length) and posts a header -- length,
+//     pairs left per lane, the device error flag (taken and reset) -- behind everything else in pinned memory.
+// The host never has to answer for the GPU to keep working: it keeps two chunks enqueued and reads the headers as they arrive.
+constexpr int kPoolLanes = 8, kPoolRing = 8;
+struct PoolHdr {
+  int n_active, errflag;
+  int lane_left[kPoolLanes];
+  int pad_[5];
+  int seq;  // written last, system-scope release
+};
+struct PoolAdmit {
+  int count, kill_mask;  // kill_mask: lanes whose pairs end now (their batch failed: device error flag)
+  int seg0[kPoolLanes], np[kPoolLanes];
+};
+__global__ __launch_bounds__(256) void k_pool_poll(PairState* st, int* active, int* n_active, int cap, int segcap, PoolAdmit adm, const Rigid* guesses,
+                                                   int max_iterations, int* ticket, ResultRec* out, ResultRec* host_out, PoolHdr* hdr, int seq,
+                                                   int* err_flag) {
+  __shared__ int s_left[kPoolLanes], s_wcnt[4], s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid < kPoolLanes) s_left[tid] = 0;
+  if (tid == 0) s_base = 0;
+  const int n = *n_active;
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 256) {
+    const int i = r0 + tid;
+    const int pair = i < n ? active[i] : -1;
+    bool keep = false;
+    if (pair >= 0) {
+      const int ln = pair / segcap;
+      if ((adm.kill_mask >> ln) & 1) st[pair].status = ST_DONE, st[pair].failed = 1;
+      keep = st[pair].status != ST_DONE;
+      if (keep) {
+        atomicAdd(&s_left[ln], 1);
+      } else {
+        const ResultRec r = result_record(st[pair]);
+        out[pair] = r;
+        host_out[pair] = r;
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_wcnt[wid] = __popcll(m);
+    __syncthreads();  // (every read of this round is done: the in-place writes below never pass position i)
+    int off = s_base;
+    for (int o = 0; o < wid; o++) off += s_wcnt[o];
+    if (keep) active[off + __popcll(m & ((1ull << lane) - 1ull))] = pair;
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  int base = s_base;
+  for (int a = 0; a < adm.count; a++) {
+    for (int j = tid; j < adm.np[a]; j += 256) {
+      const int p = adm.seg0[a] + j;
+      init_pair_state(st[p], guesses + p, max_iterations);
+      ticket[p] = 0, ticket[cap + p] = 0;
+      active[base + j] = p;
+    }
+    if (tid == 0) s_left[adm.seg0[a] / segcap] += adm.np[a];
+    base += adm.np[a];
+  }
+  for (int i = base + tid; i < cap; i += 256) active[i] = -1;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    *n_active = base;
+    hdr->n_active = base;
+    hdr->errflag = __hip_atomic_exchange(err_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < kPoolLanes; q++) hdr->lane_left[q] = s_left[q];
+    __threadfence_system();
+    __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}

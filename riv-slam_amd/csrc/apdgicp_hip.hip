@@ -551,6 +551,7 @@ int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p) {
 
 int apdgicp_batch_clear(apdgicp_batch* b) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  APD_TRY(b->eng.pool_leave());
   APD_HIP(hipStreamSynchronize(b->eng.stream));
   for (auto& c : b->eng.clouds) c.release_all();
   b->eng.clouds.clear();
@@ -604,6 +605,11 @@ int apdgicp_batch_compute_covariances(apdgicp_batch* b) {
 int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, void** d_results) {
   return guarded([&]() -> int {
     if (!b || !pairs) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (b->eng.pool_eligible()) {  // Levenberg-Marquardt: through the pair pool (complete on return, like every LM run)
+      uint64_t ticket = 0;
+      APD_TRY(b->eng.pool_enqueue(pairs, n_pairs, &ticket));
+      return b->eng.pool_collect(ticket, d_results, nullptr);
+    }
     APD_TRY(b->eng.setup_pairs(pairs, n_pairs, true, /*pipeline_cov=*/true));
     APD_TRY(b->eng.run_align());
     if (d_results) *d_results = b->eng.d_results.p;
@@ -615,6 +621,7 @@ int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int
   return guarded([&]() -> int {
     if (!b || !pairs || !ticket) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
     Engine& e = b->eng;
+    if (e.pool_eligible()) return e.pool_enqueue(pairs, n_pairs, ticket);
     APD_TRY(e.ensure_alt_slot());
     e.swap_slots();  // the slot of the batch before the last one becomes current (run_align waits for it if nobody collected it)
     e.align_seq++;
@@ -630,6 +637,7 @@ int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_resu
   return guarded([&]() -> int {
     if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
     Engine& e = b->eng;
+    if (e.pool_find(ticket)) return e.pool_collect(ticket, d_results, host_results);
     const bool previous = ticket + 1 == e.align_seq;
     if (ticket == 0 || (ticket != e.align_seq && !previous)) return fail(APDGICP_ERR_INVALID_ARG, "ticket is not one of the last two enqueued batches");
     if (previous) e.swap_slots();
@@ -654,6 +662,11 @@ int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_resu
 int apdgicp_batch_align(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, apdgicp_result* results) {
   return guarded([&]() -> int {
     if (!results) return fail(APDGICP_ERR_INVALID_ARG, "results is null");
+    if (b && pairs && b->eng.pool_eligible()) {
+      uint64_t ticket = 0;
+      APD_TRY(b->eng.pool_enqueue(pairs, n_pairs, &ticket));
+      return b->eng.pool_collect(ticket, nullptr, results);
+    }
     APD_TRY(apdgicp_batch_align_async(b, pairs, n_pairs, nullptr));
     Engine& e = b->eng;
     if (const ResultRec* r = e.host_results()) {
@@ -675,6 +688,19 @@ int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n
     bool same_pairs = same;
     for (int64_t i = 0; same_pairs && i < n_pairs; i++)
       same_pairs = e.h_pairs[i].src == pairs[i].source_cloud && e.h_pairs[i].tgt == pairs[i].target_cloud;
+    std::vector<float> pool_T;
+    if (!T && e.pool.on && e.pool.last_lane >= 0) {  // the last align ran in the pair pool: its poses are in the batch's records
+      const Engine::PoolJob& j = e.pool.jobs[e.pool.last_lane];
+      bool match = j.state != Engine::PoolJob::FREE && (int64_t)j.pair_ids.size() == n_pairs;
+      for (int64_t i = 0; match && i < n_pairs; i++) match = j.pair_ids[i].first == pairs[i].source_cloud && j.pair_ids[i].second == pairs[i].target_cloud;
+      if (match) {
+        APD_TRY(e.pool_collect(j.ticket, nullptr, nullptr));
+        pool_T.resize((size_t)n_pairs * 16);
+        for (int64_t i = 0; i < n_pairs; i++) memcpy(&pool_T[(size_t)i * 16], j.recs[i].T, 16 * sizeof(float));
+        T = pool_T.data();
+        same_pairs = false;
+      }
+    }
     if (!T && !same_pairs) return fail(APDGICP_ERR_NO_INPUT, "T == NULL needs a previous align of the same pair list");
     if (!same_pairs) APD_TRY(e.setup_pairs(pairs, n_pairs, true));
     APD_HIP(hipStreamSynchronize(e.stream));
@@ -701,13 +727,26 @@ int apdgicp_batch_fitness(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n
 
 int apdgicp_batch_synchronize(apdgicp_batch* b) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
-  APD_HIP(hipStreamSynchronize(b->eng.stream));
-  return 0;
+  return guarded([&]() -> int {
+    if (b->eng.pool.on) APD_TRY(b->eng.pool_drain());  // (pooled LM batches: every batch in flight runs to its end)
+    if (b->eng.cstream != b->eng.stream) APD_HIP(hipStreamSynchronize(b->eng.cstream));
+    APD_HIP(hipStreamSynchronize(b->eng.stream));
+    return 0;
+  });
 }
 
 int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int dst_on_device) {
   if (!b || !dst) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
   Engine& e = b->eng;
+  if (e.pool.on && e.pool.last_lane >= 0) {  // the last align ran in the pair pool
+    Engine::PoolJob& j = e.pool.jobs[e.pool.last_lane];
+    if (n_pairs <= 0 || n_pairs > j.np) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs exceeds the last batch");
+    void* d = nullptr;
+    APD_TRY(e.pool_collect(j.ticket, &d, nullptr));
+    APD_HIP(hipMemcpyAsync(dst, d, n_pairs * sizeof(apdgicp_result), dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  }
   if (n_pairs <= 0 || n_pairs > e.npairs) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs exceeds the last batch");
   APD_HIP(hipSetDevice(e.device));
   APD_HIP(hipMemcpyAsync(dst, e.d_results.p, n_pairs * sizeof(apdgicp_result), dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e.stream));

@@ -500,11 +500,14 @@ class BatchAPDGICP:
         _check(self.L.apdgicp_batch_clear(self.b))
         self.n_clouds = 0
 
-    def _device_input(self, keep):
-        ps = _producer_stream(keep[0] if isinstance(keep, list) and keep else keep)
-        if ps is not None:
-            _check(self.L.apdgicp_batch_wait_producer(self.b, ps))
+    def _device_input(self, keep, producer_wait: bool = True):
+        if producer_wait:
+            ps = _producer_stream(keep[0] if isinstance(keep, list) and keep else keep)
+            if ps is not None:
+                _check(self.L.apdgicp_batch_wait_producer(self.b, ps))
         self._keep_new.append(keep)
+        if len(self._keep_new) > 64:   # callers that never reach a sync point (long-lived resident inputs) must not pin tensors without bound
+            del self._keep_new[:-64]
 
     def wait_producer(self, stream_ptr: int = 0):
         """Orders the batch behind everything queued so far on the given hipStream_t (0: the legacy default stream)."""
@@ -539,17 +542,20 @@ class BatchAPDGICP:
         ns = (C.c_int64 * len(args))(*[a[1] for a in args])
         return ("packed_clouds", ptrs, ns, stride, dev, len(args), [a[4] for a in args])
 
-    def set_clouds(self, first_index: int, clouds):
-        """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride -- or pack_clouds(list)"""
+    def set_clouds(self, first_index: int, clouds, producer_wait: bool = True):
+        """clouds: list of torch CUDA tensors (or numpy arrays), all with the same row stride -- or pack_clouds(list).
+        producer_wait=False: the caller guarantees that the inputs are complete (long-lived resident buffers), no wait on
+        torch's current stream is inserted -- in a multi-rank job that stream carries the RCCL all-gathers."""
         packed = clouds if isinstance(clouds, tuple) and clouds and clouds[0] == "packed_clouds" else self.pack_clouds(clouds)
         _, ptrs, ns, stride, dev, n, keep = packed
         if dev and keep:
-            self._device_input(keep)   # (one producer wait for the whole list: torch's current stream)
+            self._device_input(keep, producer_wait)   # (one producer wait for the whole list: torch's current stream)
         _check(self.L.apdgicp_batch_set_clouds(self.b, first_index, n, ptrs, ns, stride, dev))
         self.n_clouds = max(self.n_clouds, first_index + n)
 
     def compute_covariances(self):
         _check(self.L.apdgicp_batch_compute_covariances(self.b))
+        self._keep_new.clear()   # the call waits for the stream (error flag): every queued pack has run
 
     @staticmethod
     def make_pairs(pairs, guesses=None):
@@ -574,6 +580,7 @@ class BatchAPDGICP:
         arr = pairs if isinstance(pairs, C.Array) else self.make_pairs(pairs, guesses)
         dptr = C.c_void_p()
         _check(self.L.apdgicp_batch_align_async(self.b, arr, len(arr), C.byref(dptr)))
+        self._keep_new.clear()   # returns behind its last status poll: every queued pack has run
         return dptr.value, len(arr) * RESULT_DTYPE.itemsize
 
     def set_pair_groups(self, max_groups: int):
@@ -587,7 +594,8 @@ class BatchAPDGICP:
         ticket = C.c_uint64()
         _check(self.L.apdgicp_batch_align_enqueue(self.b, arr, len(arr), C.byref(ticket)))
         self._keep_ticket[ticket.value], self._keep_new = self._keep_new, []
-        self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 1 >= ticket.value}, ticket.value: len(arr)}
+        # (Gauss-Newton: the last two tickets are collectable; pooled LM batches: as many as the pool has lanes -- the library decides)
+        self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 8 >= ticket.value}, ticket.value: len(arr)}
         return ticket.value
 
     def align_collect(self, ticket: int, device: bool = False):
@@ -595,7 +603,7 @@ class BatchAPDGICP:
         with device=True as a zero-copy torch uint8 CUDA tensor [n, 96] (valid until the second enqueue after its own)."""
         n = getattr(self, "_ticket_pairs", {}).get(ticket)
         if n is None:
-            raise ValueError(f"ticket {ticket} is not one of the last two enqueued batches")
+            raise ValueError(f"ticket {ticket} is not one of the batches in flight")
         for t in [t for t in self._keep_ticket if t <= ticket]:   # stream order: everything up to this batch has run
             del self._keep_ticket[t]
         if device:

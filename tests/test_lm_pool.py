@@ -1,0 +1,190 @@
+"""GPU tests (-m gpu) of the pooled Levenberg-Marquardt batches (Engine::pool_*, k_pool_poll): LM is the reference's only
+reachable optimiser (lsq_registration_impl.hpp:17) and loop-closure candidates are aligned from the identity
+(loop_detector.cpp:222-225), so their run lengths differ widely inside one batch.  The pool keeps several batches in flight
+on ONE handle and ONE host thread; every record must be byte-identical to the host-polled loop (APDGICP_LM_POOL=0) and agree
+with the CPU oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import ref as R
+
+pytestmark = pytest.mark.gpu
+
+LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+T_TOL, R_TOL = 1e-3, 1e-4
+
+
+@pytest.fixture(scope="module")
+def reg():
+    import __graft_entry__ as g
+    g.build()
+    return importlib.import_module("riv-slam_amd.registration")
+
+
+def host_polled(reg, params):
+    """a batch handle that runs LM through run_align's host-polled loop (the round-2 path): the cross-check"""
+    os.environ["APDGICP_LM_POOL"] = "0"
+    try:
+        b = reg.BatchAPDGICP(params)
+        b._polled = True
+        return b
+    finally:
+        os.environ.pop("APDGICP_LM_POOL", None)
+
+
+def polled_align(b, pairs, guesses):
+    os.environ["APDGICP_LM_POOL"] = "0"
+    try:
+        return b.align(pairs, guesses).copy()
+    finally:
+        os.environ.pop("APDGICP_LM_POOL", None)
+
+
+def loop_batches(scene, n_batches, n_pairs, n_pts, seed0):
+    data = []
+    for s in range(n_batches):
+        clouds, guesses = [], []
+        for p in range(n_pairs):
+            a, b_, _, _ = scene.make_pair(n_pts + 13 * p, n_pts, scene.pair_seed(seed0 + s, p), "loop")
+            clouds += [a, b_]
+            guesses.append(np.eye(4, dtype=np.float32))   # loop_detector.cpp:225
+        data.append((clouds, guesses))
+    return data
+
+
+def test_pool_records_equal_the_host_polled_loop_and_the_oracle(reg, scene):
+    n_pairs = 10
+    (clouds, guesses), = loop_batches(scene, 1, n_pairs, 1500, 300)
+    pair_idx = [(2 * i, 2 * i + 1) for i in range(n_pairs)]
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b.set_clouds(0, clouds)
+    got = b.align(pair_idx, guesses)
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    ref_b.set_clouds(0, clouds)
+    want = polled_align(ref_b, pair_idx, guesses)
+    assert got.tobytes() == want.tobytes()
+    assert len(set(int(x) for x in got["n_linearize"])) > 2      # the run lengths really differ inside the batch
+    for p in range(n_pairs):
+        o = R.RefAPDGICP(R.default_params(**LM))
+        o.setInputSource(clouds[2 * p]), o.setInputTarget(clouds[2 * p + 1])
+        To = o.align(guesses[p])
+        te, re_ = scene.pose_error(To, reg.result_matrix(got[p]))
+        assert te <= T_TOL and re_ <= R_TOL, (p, te, re_)
+        assert [got[p]["converged"], got[p]["iterations"], got[p]["n_linearize"], got[p]["n_compute_error"]] == \
+            [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error], p
+
+
+def test_four_batches_in_flight_on_one_handle(reg, scene):
+    """Batches of different sizes in disjoint cloud slots, enqueued back to back, collected out of order, in host and device
+    form; afterwards the slots are reused (set_clouds waits for the batch that still reads them)."""
+    sizes = (7, 12, 3, 9, 12, 5)
+    data = [loop_batches(scene, 1, n, 900 + 100 * (k % 3), 320 + k)[0] for k, n in enumerate(sizes)]
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    want = []
+    for (clouds, guesses), n in zip(data, sizes):
+        ref_b.set_clouds(0, clouds)
+        want.append(polled_align(ref_b, [(2 * i, 2 * i + 1) for i in range(n)], guesses))
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    base, tickets = 0, []
+    for k in range(4):
+        clouds, guesses = data[k]
+        b.set_clouds(base, clouds)
+        tickets.append(b.align_enqueue([(base + 2 * i, base + 2 * i + 1) for i in range(sizes[k])], guesses))
+        base += len(clouds)
+    for k in (2, 0, 3, 1):
+        if k == 3:
+            assert b.align_collect(tickets[k], device=True).cpu().numpy().tobytes() == want[k].tobytes()
+        assert b.align_collect(tickets[k]).tobytes() == want[k].tobytes(), k
+    # slots 0.. are free again; batch 4 goes there while batch 5 reuses them at once: set_clouds waits for batch 4
+    b.set_clouds(0, data[4][0])
+    t4 = b.align_enqueue([(2 * i, 2 * i + 1) for i in range(sizes[4])], data[4][1])
+    b.set_clouds(0, data[5][0])
+    t5 = b.align_enqueue([(2 * i, 2 * i + 1) for i in range(sizes[5])], data[5][1])
+    assert b.align_collect(t5).tobytes() == want[5].tobytes()
+    assert b.align_collect(t4).tobytes() == want[4].tobytes()
+    assert b.align([(2 * i, 2 * i + 1) for i in range(sizes[5])], data[5][1]).tobytes() == want[5].tobytes()
+
+
+def test_more_batches_than_lanes_and_a_growing_pool(reg, scene):
+    """Six enqueues without a collect on four lanes: the oldest finished batches give their lanes up (their tickets are void),
+    the newest four stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
+    data = loop_batches(scene, 6, 4, 800, 340)
+    pair_idx = [(2 * i, 2 * i + 1) for i in range(4)]
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    want = []
+    for clouds, guesses in data:
+        ref_b.set_clouds(0, clouds)
+        want.append(polled_align(ref_b, pair_idx, guesses))
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    tickets = []
+    for s, (clouds, guesses) in enumerate(data):
+        b.set_clouds(8 * s, clouds)
+        tickets.append(b.align_enqueue([(8 * s + 2 * i, 8 * s + 2 * i + 1) for i in range(4)], guesses))
+    for s in (5, 4, 3, 2):
+        assert b.align_collect(tickets[s]).tobytes() == want[s].tobytes(), s
+    for s in (0, 1):
+        with pytest.raises(Exception, match="ticket"):
+            b.align_collect(tickets[s])
+    (clouds, guesses), = loop_batches(scene, 1, 9, 2600, 350)
+    b.set_clouds(0, clouds)
+    got = b.align([(2 * i, 2 * i + 1) for i in range(9)], guesses)
+    ref_b.set_clouds(0, clouds)
+    assert got.tobytes() == polled_align(ref_b, [(2 * i, 2 * i + 1) for i in range(9)], guesses).tobytes()
+
+
+def test_a_failing_batch_fails_alone_and_the_handle_stays_usable(reg, scene):
+    data = loop_batches(scene, 3, 5, 1000, 360)
+    pair_idx = lambda base: [(base + 2 * i, base + 2 * i + 1) for i in range(5)]  # noqa: E731
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b.set_clouds(0, data[0][0])
+    want0 = b.align(pair_idx(0), data[0][1]).copy()
+    bad = [c.copy() for c in data[1][0]]
+    bad[4][17] = np.nan
+    b.set_clouds(10, bad)
+    t_bad = b.align_enqueue(pair_idx(10), data[1][1])
+    with pytest.raises(Exception, match="non-finite"):
+        b.align_collect(t_bad)
+    b.set_clouds(10, data[1][0])                      # the same slots, healthy clouds
+    t1 = b.align_enqueue(pair_idx(10), data[1][1])
+    t0 = b.align_enqueue(pair_idx(0), data[0][1])   # clouds cached since the first align
+    assert b.align_collect(t0).tobytes() == want0.tobytes()
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    ref_b.set_clouds(0, data[1][0])
+    assert b.align_collect(t1).tobytes() == polled_align(ref_b, pair_idx(0), data[1][1]).tobytes()
+    # parameters change between batches: the pool drains, the next batch runs with the new ones; GN leaves the pool
+    b.set_params(reg.default_params(optimizer=1, max_iterations=3, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0))
+    gn = b.align(pair_idx(0), data[0][1])
+    assert int(gn["n_linearize"].min()) == 3
+    b.set_params(reg.default_params(**LM))
+    assert b.align(pair_idx(0), data[0][1]).tobytes() == want0.tobytes()
+
+
+def test_c4_shard_at_full_size(reg, scene):
+    """BASELINE configs[3], one GPU's shard as SURVEY 8d specifies it: 32 loop-closure candidates at 8192 points, identity
+    guess, LM with the launch parameters.  Flags and iteration counts exact against the oracle, poses inside north_star's
+    tolerance; run with two batches in flight (the same pairs in two slot ranges)."""
+    P, n = 32, 8192
+    clouds, guesses = [], []
+    for p in range(P):
+        s, t, _, _ = scene.make_pair(n, n, scene.pair_seed(4, p), "loop")
+        clouds += [s, t]
+        guesses.append(np.eye(4, dtype=np.float32))
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b.set_clouds(0, clouds)
+    t0 = b.align_enqueue([(2 * i, 2 * i + 1) for i in range(P)], guesses)
+    b.set_clouds(2 * P, clouds)
+    t1 = b.align_enqueue([(2 * P + 2 * i, 2 * P + 2 * i + 1) for i in range(P)], guesses)
+    r0, r1 = b.align_collect(t0), b.align_collect(t1)
+    assert r0.tobytes() == r1.tobytes()
+    assert int(r0["n_linearize"].max()) >= 20 and int(r0["n_linearize"].min()) <= 5
+    for p in range(P):
+        o = R.RefAPDGICP(R.default_params(**LM))
+        o.setInputSource(clouds[2 * p]), o.setInputTarget(clouds[2 * p + 1])
+        To = o.align(guesses[p])
+        te, re_ = scene.pose_error(To, reg.result_matrix(r0[p]))
+        assert te <= T_TOL and re_ <= R_TOL, (p, te, re_)
+        assert [r0[p]["converged"], r0[p]["iterations"], r0[p]["n_linearize"], r0[p]["n_compute_error"]] == \
+            [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error], p

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""C4 shard: 32 loop-closure pairs at 8192 points, identity guess, LM with the launch parameters, both clouds fresh
+every batch -- ONE handle, ONE host thread, F batches in flight (disjoint cloud-slot ranges).  Prints ms per batch for the
+pooled path (F = 1 .. 4) and for the host-polled loop of round 2 (APDGICP_LM_POOL=0), and checks that the records agree."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+import __graft_entry__ as _ge  # noqa
+_ge.build()
+reg = importlib.import_module("riv-slam_amd.registration")
+scene = importlib.import_module("riv-slam_amd.scene")
+
+LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+P, N = int(os.environ.get("PAIRS", 32)), int(os.environ.get("POINTS", 8192))
+REPS = int(os.environ.get("REPS", 24))
+clouds, guesses = [], []
+for p in range(P):
+    s, t, _, _ = scene.make_pair(N, N, scene.pair_seed(4, p), "loop")
+    clouds += [torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()]
+    guesses.append(np.eye(4, dtype=np.float32))
+torch.cuda.synchronize()
+out = {"pairs": P, "points": N}
+
+
+def run(F, reps):
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    packed = b.pack_clouds(clouds)
+    pairs = [b.make_pairs([(2 * P * f + 2 * i, 2 * P * f + 2 * i + 1) for i in range(P)], guesses) for f in range(F)]
+
+    def steps(count):
+        tickets, res = [None] * F, None
+        for s in range(count):
+            f = s % F
+            if tickets[f] is not None:
+                res = b.align_collect(tickets[f])
+            b.set_clouds(2 * P * f, packed, producer_wait=False)
+            tickets[f] = b.align_enqueue(pairs[f])
+        for s in range(count, count + F):
+            f = s % F
+            if tickets[f] is not None:
+                res = b.align_collect(tickets[f])
+                tickets[f] = None
+        return res
+    steps(2 * F)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = steps(reps)
+    b.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    return ms, res, b.last_ticks()[0]
+
+
+want = None
+for F in [int(x) for x in os.environ.get("F_LIST", "1,2,3,4").split(",")]:
+    ms, res, ticks = run(F, REPS)
+    if want is None:
+        want = res.tobytes()
+        its = [int(x) for x in res["n_linearize"]]
+        out["n_linearize"] = {"min": min(its), "median": float(np.median(its)), "max": max(its), "sum": sum(its)}
+        out["n_compute_error_sum"] = int(res["n_compute_error"].sum())
+    assert res.tobytes() == want
+    out[f"pool_{F}_in_flight_ms_per_batch"] = round(ms, 3)
+if os.environ.get("NO_POLLED", "0") != "1":
+    os.environ["APDGICP_LM_POOL"] = "0"
+    ms, res, _ = run(1, max(4, REPS // 4))
+    out["host_polled_ms_per_batch"] = round(ms, 3)
+    out["records_equal_host_polled"] = res.tobytes() == want
+print(json.dumps(out))
