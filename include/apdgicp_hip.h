@@ -211,14 +211,22 @@ int apdgicp_batch_align_async(apdgicp_batch* b, const apdgicp_pair* pairs, int64
 int apdgicp_batch_synchronize(apdgicp_batch* b);
 int apdgicp_batch_wait_producer(apdgicp_batch* b, void* producer_stream);   /* see apdgicp_wait_producer */
 int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream);              /* see apdgicp_get_stream */
-/* A stream of batches (one per keyframe, loop_detector.cpp:222-236) with two of them in flight: enqueue launches everything
- * batch s needs -- packing and sorting of clouds set since the last call, covariances, every optimiser tick, the final
- * poll -- and returns without waiting when the run length is known up front (Gauss-Newton; a Levenberg-Marquardt run polls
- * as it goes and is complete on return).  The caller may then set the clouds of batch s+1 (stream-ordered behind batch s,
- * the same cloud slots can be reused) and enqueue it before collecting batch s, so the GPU never waits for the host.
- * collect(ticket) waits for that batch, reports its error if it had one, and hands out its records: *d_results (device,
- * n_pairs x sizeof(apdgicp_result)) and/or host_results (may be NULL).  A ticket stays collectable until the SECOND enqueue
- * after its own; collecting is optional (an uncollected batch is waited for when its slot is reused). */
+/* A stream of batches (one per keyframe, loop_detector.cpp:222-236) with several of them in flight on ONE handle and ONE host
+ * thread: enqueue prepares the clouds set since the last call (packing, sorting, covariances), hands the batch to the device and
+ * returns without waiting; collect(ticket) waits for that batch, reports its error if it had one, and hands out its records:
+ * *d_results (device, n_pairs x sizeof(apdgicp_result)) and/or host_results (either may be NULL).  Collecting is optional.
+ *   Gauss-Newton (the run length is known): every tick and the final poll are enqueued at once; TWO batches may be in flight, the
+ *   next batch may reuse the same cloud slots (stream order), and a ticket stays collectable until the SECOND enqueue after its own.
+ *   Levenberg-Marquardt (the reference's default, L:17; the run length is data dependent, L:64-76): the pairs of up to EIGHT
+ *   batches share one pool of pair slots on the device; every optimiser tick is one launch over the pairs of all batches that
+ *   still run, pairs leave as they converge and the pairs of the next batch join between two ticks, so a batch is never held
+ *   by the slowest pair of another one and the GPU never waits for the host (ticks are enqueued two chunks ahead by whichever
+ *   call of the handle is running; collect pumps until its batch is done).  A ticket stays collectable until its lane is
+ *   needed again: the eighth enqueue after its own at the latest.  A cloud slot referenced by a batch in flight must not be
+ *   replaced -- set_cloud(s) on such a slot first waits for that batch -- so callers that want overlap give consecutive batches
+ *   disjoint slot ranges (keyframe clouds that stay registered are shared freely).  If a covariance launch raises the device
+ *   error flag, every batch in flight at that moment fails at its collect; the handle stays usable.
+ *   APDGICP_LM_POOL=0 in the environment selects the round-2 host-polled loop instead (the cross-check of tests/test_lm_pool.py). */
 int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, uint64_t* ticket);
 /* A batch runs as up to three pair groups on three HIP streams (about 8 pairs per group), which is the best a single handle
  * can do.  A caller that keeps several HANDLES busy at once -- batch s on handle s % 3, each enqueued before the previous

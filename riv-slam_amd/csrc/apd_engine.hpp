@@ -1028,7 +1028,8 @@ class Engine {
     // a handle limited to one pair group shares the GPU with other busy handles: throughput counts there, not the latency of
     // this launch, and one wave per 64 points does no redundant bound work (three handles in flight: 1.32 -> 1.27 ms per step)
     const int w_full = max_groups == 1 || in_pool ? 1 : 2;
-    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
+    const long long w4_blocks = in_pool ? pool.w4_blocks : 1024;
+    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= w4_blocks || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
     // throughput regime (one wave per 64 points) with neighbour keeping on: blocks of 256 points that pack the points still
     // searching into as few waves as they fill (k_nn_compact)
     // (not for dense targets beyond 16384 points when the engine chose the regime itself: a wave there walks many batches of
@@ -1372,6 +1373,9 @@ class Engine {
     int ub = 0;  // upper bound of the device's list length behind the last ENQUEUED poll
     int kill_mask = 0;
     int ticks_per_chunk = 2, depth = 2;
+    int groups = 2, group_min = 24, head_ticks = 1;  // see pool_enqueue_chunk
+    float head_frac = 0.5f;
+    int w4_blocks = 1024;  // tick launches of up to this many 64-point blocks search with four waves per block
     int last_lane = -1;
     long long n_chunks = 0, n_ticks = 0, n_pair_ticks = 0;  // statistics (apdgicp_batch_last_ticks)
     std::vector<int> cloud_busy;
@@ -1397,6 +1401,11 @@ class Engine {
       for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
       pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 2)));
       pool.depth = std::max(1, std::min(kPoolRing - 2, env_int("APDGICP_POOL_DEPTH", 2)));
+      pool.groups = std::max(1, std::min(8, env_int("APDGICP_POOL_GROUPS", 2)));
+      pool.group_min = std::max(2, env_int("APDGICP_POOL_GROUP_MIN", 24));
+      pool.w4_blocks = std::max(256, env_int("APDGICP_POOL_W4_BLOCKS", 1024));
+      pool.head_ticks = std::max(1, std::min(8, env_int("APDGICP_POOL_HEAD_TICKS", 1)));
+      if (const char* v = getenv("APDGICP_POOL_HEAD_FRAC")) pool.head_frac = std::max(0.05f, std::min(0.95f, (float)atof(v)));
     }
     cstream = pool.cstream;
     pool.on = true;
@@ -1424,7 +1433,7 @@ class Engine {
     const int nmax = std::max(pool.nmax_src, nsrc);
     const size_t ns = ((size_t)nmax + 255) & ~(size_t)255, nblk = (nmax + LIN_BLK - 1) / LIN_BLK;
     const size_t per_pair = ns * 96 + nblk * (kRed + 1) * 8 + sizeof(PairState) + sizeof(PairDesc) + sizeof(Rigid) + 2 * sizeof(ResultRec) + 16;
-    int lanes = std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 4)));
+    int lanes = std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 8)));
     while (lanes > 1 && (size_t)lanes * segcap * per_pair > ((size_t)16 << 30)) lanes--;
     const int cap = lanes * segcap;
     APD_TRY(pool.state.ensure((size_t)cap * sizeof(PairState)));
@@ -1516,9 +1525,33 @@ class Engine {
         Engine& e;
         ~Reset() { e.in_pool = false, e.cur_active = 0; }
       } reset{*this};
-      in_pool = true, cur_active = pool.ub;
-      for (int t = 0; t < pool.ticks_per_chunk; t++) APD_TRY(launch_tick(Span{0, pool.ub, stream}));
-      pool.n_ticks += pool.ticks_per_chunk, pool.n_pair_ticks += (long long)pool.ticks_per_chunk * pool.ub;
+      in_pool = true;
+      // The list is in admission order: its head holds what is left of the oldest batches -- few pairs, each with many iterations
+      // to go, a latency-bound chain of small launches -- its tail the young batches whose launches are wide.  In one stream
+      // every pair advances at the pace of the widest launch, so the list is cut into `groups` slices that tick on streams of
+      // their own between two polls; the head slice gets `head_ticks` times the ticks of the others (a pair that is done, or a
+      // slot behind the end of the list, leaves its launches at once).
+      const int G = pool.ub >= pool.group_min ? pool.groups : 1;
+      APD_TRY(ensure_group_streams(G));
+      if (G > 1) {
+        APD_HIP(hipEventRecord(ev_main, stream));
+        for (int g = 1; g < G; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
+      }
+      const int head = G > 1 ? std::max(1, std::min(pool.ub - (G - 1), (int)(pool.ub * pool.head_frac))) : pool.ub;
+      for (int g = 0; g < G; g++) {
+        const int p0 = g == 0 ? 0 : head + (int)((long long)(pool.ub - head) * (g - 1) / (G - 1));
+        const int p1 = g == 0 ? head : head + (int)((long long)(pool.ub - head) * g / (G - 1));
+        if (p1 <= p0) continue;
+        const int nt = pool.ticks_per_chunk * (g == 0 && G > 1 ? pool.head_ticks : 1);
+        cur_active = p1 - p0;
+        for (int t = 0; t < nt; t++) APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+        pool.n_pair_ticks += (long long)nt * (p1 - p0);
+      }
+      for (int g = 1; g < G; g++) {
+        APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
+        APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
+      }
+      pool.n_ticks += pool.ticks_per_chunk;
     }
     APD_HIP(hipGetLastError());
     return 0;

@@ -562,8 +562,11 @@ def test_two_batches_in_flight(reg, scene, optimizer):
                 dev = b.align_collect(tickets[s - 1], device=True)  # collecting twice is allowed; device form
                 assert dev.cpu().numpy().tobytes() == want[s - 1].tobytes()
     assert b.align_collect(tickets[-1]).tobytes() == want[-1].tobytes()
-    with pytest.raises(Exception, match="ticket"):
-        b.align_collect(tickets[0])
+    if optimizer == "gn":     # two record buffers: the ticket is void after the second enqueue behind its own
+        with pytest.raises(Exception, match="ticket"):
+            b.align_collect(tickets[0])
+    else:                     # pooled LM batches: a lane per batch, eight of them
+        assert b.align_collect(tickets[0]).tobytes() == want[0].tobytes()
     # a batch with non-finite points fails at ITS collect; the batches around it are unaffected
     bad = [c.copy() for c in data[0][0]]
     bad[3][5] = np.nan

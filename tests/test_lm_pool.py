@@ -109,9 +109,9 @@ def test_four_batches_in_flight_on_one_handle(reg, scene):
 
 
 def test_more_batches_than_lanes_and_a_growing_pool(reg, scene):
-    """Six enqueues without a collect on four lanes: the oldest finished batches give their lanes up (their tickets are void),
-    the newest four stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
-    data = loop_batches(scene, 6, 4, 800, 340)
+    """Ten enqueues without a collect on eight lanes: the oldest batches give their lanes up (their tickets are void), the
+    newest eight stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
+    data = loop_batches(scene, 10, 4, 800, 340)
     pair_idx = [(2 * i, 2 * i + 1) for i in range(4)]
     ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
     want = []
@@ -123,7 +123,7 @@ def test_more_batches_than_lanes_and_a_growing_pool(reg, scene):
     for s, (clouds, guesses) in enumerate(data):
         b.set_clouds(8 * s, clouds)
         tickets.append(b.align_enqueue([(8 * s + 2 * i, 8 * s + 2 * i + 1) for i in range(4)], guesses))
-    for s in (5, 4, 3, 2):
+    for s in (9, 4, 7, 2, 3, 5, 6, 8):
         assert b.align_collect(tickets[s]).tobytes() == want[s].tobytes(), s
     for s in (0, 1):
         with pytest.raises(Exception, match="ticket"):
