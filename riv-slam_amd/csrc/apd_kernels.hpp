@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "apd_math.hpp"
 #include "apd_sort.hpp"
 
@@ -1263,6 +1265,18 @@ __device__ __forceinline__ unsigned long long wave_kth_smallest3(unsigned long l
   }
   return ((unsigned long long)pre_hi << 32) | pre_lo;
 }
+// v_writelane_b32 with a constant lane (this toolchain has no builtin for it; one scalar source at most besides the lane)
+template <int LANE>
+__device__ __forceinline__ void writelane_const(int& v, int val) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 __device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 
 __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)orig; }
@@ -1290,7 +1304,14 @@ constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 
 // qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
 // smaller lists (more waves per CU); lanes >= qpw only help in the lane = candidate phase.
 __host__ __device__ constexpr int knn_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4; }
-__host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8; }  // k_knn_cov_coop: lists only (boxes in registers, window from L1)
+// k_knn_cov_coop: list entries per query -- 60 with 4 lanes per query (16 queries per wave: 7.8 KB of lists, what five resident
+// waves per SIMD leave of the LDS; 48 overflowed 3.8 times per wave, and every overflow is a radix select of 300 scalar
+// instructions on the one scalar unit the four SIMDs share), 48 otherwise
+#ifndef APD_KNN_CAP4
+#define APD_KNN_CAP4 60
+#endif
+__host__ __device__ constexpr int knn_coop_cap(int lanes_per_query) { return lanes_per_query == 4 ? APD_KNN_CAP4 : 48; }
+__host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * (knn_coop_cap(64 / qpw) + 1) * 8; }  // lists only (boxes in registers, window from L1)
 
 __global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                        unsigned long long* stats, int qpw) {
@@ -1531,12 +1552,15 @@ __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v)
 }
 
 // (5 waves per SIMD asked for: the allocation sits at 95 .. 97 registers, and 97 would cost the fifth wave)
+#ifndef APD_KNN_WPE
+#define APD_KNN_WPE 5
+#endif
 template <int L>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE, 8))) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
                                                      unsigned long long* stats, int raw /* 1: store the population covariance, k_regularize_covs follows */) {
-  constexpr int QPW = 64 / L, NCL = KNN_NC / L, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
+  constexpr int QPW = 64 / L, NCL = KNN_NC / L, KQ_CAP = knn_coop_cap(L), KQ_STRIDE = KQ_CAP + 1, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
   static_assert(L == 4 || L == 8 || L == 16, "L lanes per query");
-  static_assert(KQ_CAP % L == 0 && KQ_WIN % KNN_NC == 0, "layout");
+  static_assert(KQ_CAP % L == 0 && KQ_CAP <= 64 && KQ_WIN % KNN_NC == 0, "layout");
   extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
   float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
@@ -1713,15 +1737,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     }
     // group masks, one query per trip: lane g tests ITS box against the query broadcast through SGPRs, the ballot IS the
     // query's mask (a finished or padding query has tau = -1 and gets none); gany = groups some query of this wave needs
-    unsigned long long gneed = 0, gany = 0;
-#pragma unroll
-    for (int qi = 0; qi < QPW; qi++) {
+    unsigned long long gany = 0;
+    int gneed_lo = 0, gneed_hi = 0;
+    static_for<0, QPW>([&](auto qi_) {
+      constexpr int qi = decltype(qi_)::value;
       const float qx = readlane_f(q.x, qi * L), qy = readlane_f(q.y, qi * L), qz = readlane_f(q.z, qi * L);
       const float td = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tau_hi, qi * L));
-      const unsigned long long mq = __ballot(lane < nb && lb_point_box(mybox, qx, qy, qz) <= td);
+      // (a lane without a group holds the all-infinite box: its bound is +inf, no `lane < nb` needed -- as a condition it became
+      // a branch around the bound in every one of the QPW trips)
+      const unsigned long long mq = __ballot(lb_point_box(mybox, qx, qy, qz) <= td);
       gany |= mq;
-      if (slot == qi) gneed = mq;
-    }
+      // only the query's owner lane reads its mask (qm below): two v_writelane instead of a select per lane and trip, whose QPW
+      // lane masks the compiler kept in 2 QPW scalar registers for the whole kernel
+      writelane_const<qi * L>(gneed_lo, (int)(unsigned)mq);
+      writelane_const<qi * L>(gneed_hi, (int)(unsigned)(mq >> 32));
+    });
+    const unsigned long long gneed = ((unsigned long long)(unsigned)gneed_hi << 32) | (unsigned)gneed_lo;
     if (stats) { const long long t = clock64(); tG += t - tm, tm = t; }
     float4 c0, c1, d0, d1;
     unsigned o0, o1;
@@ -1841,8 +1872,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
       cx(0, 2), cx(0, 1), cx(1, 2);
     } else if constexpr (EPL == 6) {
       cx(0, 5), cx(1, 3), cx(2, 4), cx(1, 2), cx(3, 4), cx(0, 3), cx(2, 5), cx(0, 1), cx(2, 3), cx(4, 5), cx(1, 2), cx(3, 4);
+    } else if constexpr (EPL != 12) {
+      // any other length: Batcher's merge-exchange network for the next power of two, the comparators that would touch an
+      // element >= EPL left out (those elements are +infinity and stay where they are); 15 keys: 59 compare-exchanges
+      constexpr int P = EPL <= 4 ? 4 : EPL <= 8 ? 8 : EPL <= 16 ? 16 : 32;
+#pragma unroll
+      for (int p_ = 1; p_ < P; p_ <<= 1)
+#pragma unroll
+        for (int k_ = p_; k_ >= 1; k_ >>= 1)
+#pragma unroll
+          for (int j_ = k_ % p_; j_ + k_ < P; j_ += 2 * k_)
+#pragma unroll
+            for (int i_ = 0; i_ < k_; i_++)
+              if ((i_ + j_) / (2 * p_) == (i_ + j_ + k_) / (2 * p_) && i_ + j_ + k_ < EPL) cx(i_ + j_, i_ + j_ + k_);
     } else {
-      static_assert(EPL == 12, "sorting networks for 3, 6 and 12 entries per lane");
       cx(0, 8), cx(1, 7), cx(2, 6), cx(3, 11), cx(4, 10), cx(5, 9), cx(0, 1), cx(2, 5), cx(3, 4), cx(6, 9), cx(7, 8), cx(10, 11), cx(0, 2);
       cx(1, 6), cx(5, 10), cx(9, 11), cx(0, 3), cx(1, 2), cx(4, 6), cx(5, 7), cx(8, 11), cx(9, 10), cx(1, 4), cx(3, 5), cx(6, 8), cx(7, 10);
       cx(1, 3), cx(2, 5), cx(6, 9), cx(8, 10), cx(2, 3), cx(4, 5), cx(6, 7), cx(8, 9), cx(4, 6), cx(5, 7), cx(3, 4), cx(5, 6), cx(7, 8);

@@ -1,7 +1,7 @@
 """Times calculate_covariances alone (k_knn_cov_*): 64 clouds of 8192 points by default.
 usage: python tools/knn_time.py [n_clouds] [n_points]; env APDGICP_KNN_QPW / APDGICP_KNN_COOP / APDGICP_STATS"""
 import importlib, os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
 import bench
