@@ -204,38 +204,30 @@ class Engine {
   CachedTable d_desc, d_pairs, d_guess, d_ids, d_packjobs, d_sortjobs, d_sortjobs_reg[3], d_tilejobs[3], d_active;
   DevBuf d_tkeys;          // sorted tiles of the clouds being sorted by the tiled path
   int n_stage_pending = 0;   // clouds whose pinned copy a sort has been enqueued for, no align behind it yet
-  bool direct_stage = true;  // host clouds of the tiled-sort sizes are read by the sort from pinned memory (APDGICP_DIRECT_STAGE=0: copied first)
-  bool sort_tiled = true;  // 2048 < n <= 16384: four tile blocks + merge + boxes (APDGICP_SORT_TILED=0: one block per cloud)
   std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
-  bool sort_in_registers = true;  // k_sort_cloud_reg for 2048 < n <= 16384 (APDGICP_SORT_REG=0: k_sort_cloud_lds)
   DevBuf b_nnpart, b_corr, b_nnpt, b_nnaux, b_sqd, b_maha, b_blkpart, b_errpart;
   Work work{};
-  int nn_S = 2;
+  int nn_S = 1;
   int nn_W = 0;  // waves per block of k_nn_pruned<1, W> sharing the same 64 points (APDGICP_NN_W = 1, 2, 4; 0: by load)
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
-  bool nn_gate_cap = true; // optimiser ticks stop the search at the correspondence gate (APDGICP_NN_GATE_CAP=0: unbounded)
   // Neighbour keeping (nn_warm_start): a full search prunes with the squared radius r^2 (1 + skin_rel)^2 + skin_abs^2 instead of
   // r^2, which buys later iterations the right to keep the neighbour without searching while the point has moved by less than
-  // the margin (APDGICP_NN_SKIN=0 disables; APDGICP_NN_SKIN_REL / _ABS in metres override)
+  // the margin (APDGICP_NN_SKIN=0 disables: the cross-check of tests/test_hip_parity.py; margins measured in docs/experiments.md)
   bool nn_skin = true;
-  float nn_skin_rel = 0.25f, nn_skin_abs = 0.02f;
-  bool nn_coop_tail = true;  // APDGICP_NN_COOP_TAIL=0: a k_nn_compact block with one wave's worth of points left searches them with that one wave
-  bool nn_compact = true;  // APDGICP_NN_COMPACT=0: one-wave blocks of k_nn_pruned<1, 1> instead of k_nn_compact in the throughput regime
+  static constexpr float nn_skin_rel = 0.25f, nn_skin_abs = 0.02f;
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
-  bool split_regularize = true;  // APDGICP_SPLIT_REG=0: the covariance kernel regularises in its own epilogue in every regime
-  bool fold_poll_cfg = true, post_tick = false;  // APDGICP_FOLD_POLL=0: k_finalize behind every chunk of ticks
+  bool post_tick = false;  // this launch of k_error also writes the poll record (one-pair LM handles)
   CachedTable d_post;
   bool init_tick = false;
-  bool fold_init_cfg = true, fold_init = false, tickets_dirty = true;  // APDGICP_FOLD_INIT=0: k_init_state in front of every align
-  bool fuse_lm = true;     // GN/LM step inside the last block of k_linearize / k_error (APDGICP_FUSE=0: separate k_lm_solve / k_lm_decide launches)
+  bool fold_init = false, tickets_dirty = true;  // the first tick builds the pair state itself unless the arrival counters may be mid-count
   DevBuf b_ticket;
   // pair groups: the tick kernels of each group run on their own stream so that one group's short serial
   // kernels (k_lm_solve) and launch gaps overlap with the other group's wide ones
   std::vector<hipStream_t> gstreams;
   std::vector<hipEvent_t> gevents;
   hipEvent_t ev_main = nullptr;
-  int ngroups_cfg = 2;
+  static constexpr int ngroups_cfg = 3;  // pair groups (HIP streams) of a batch handle that runs alone (measured: docs/experiments.md)
   static constexpr int kHostResults = 256;  // batches up to this size get their records with the status poll
   char* h_poll = nullptr;    // pinned: [records][status words + error flag] of the last poll
   char* h_poll_dev = nullptr;  // the same memory as the device addresses it
@@ -283,9 +275,6 @@ class Engine {
   // for its own device when it is created -- no process-wide "done once" flag that a second device or thread could trip over.
   static int set_kernel_attributes() {
     APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
-    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SORT_BLK * 8));
-    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SORT_BLK * 8));
-    APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_reg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * SORT_BLK * 8));
     APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
     APD_HIP(hipFuncSetAttribute((const void*)k_merge_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
     return 0;
@@ -323,24 +312,11 @@ class Engine {
     nn_pruned = !(m && std::string(m) == "brute");
     m = getenv("APDGICP_KNN_MODE");
     knn_pruned = !(m && std::string(m) == "brute");
-    fuse_lm = env_int("APDGICP_FUSE", 1) != 0;
-    fold_init_cfg = env_int("APDGICP_FOLD_INIT", 1) != 0;
-    fold_poll_cfg = env_int("APDGICP_FOLD_POLL", 1) != 0;
-    split_regularize = env_int("APDGICP_SPLIT_REG", 1) != 0;
-    nn_gate_cap = env_int("APDGICP_NN_GATE_CAP", 1) != 0;
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
-    nn_compact = env_int("APDGICP_NN_COMPACT", 1) != 0;
-    nn_coop_tail = env_int("APDGICP_NN_COOP_TAIL", 1) != 0;
-    if (const char* v = getenv("APDGICP_NN_SKIN_REL")) nn_skin_rel = std::max(0.f, (float)atof(v));
-    if (const char* v = getenv("APDGICP_NN_SKIN_ABS")) nn_skin_abs = std::max(0.f, (float)atof(v));
-    sort_in_registers = env_int("APDGICP_SORT_REG", 1) != 0;
-    sort_tiled = env_int("APDGICP_SORT_TILED", 1) != 0;
-    direct_stage = env_int("APDGICP_DIRECT_STAGE", 1) != 0;
     // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
     // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
     nn_W = env_int("APDGICP_NN_W", 0);
     if (nn_W != 1 && nn_W != 2 && nn_W != 4 && nn_W != 8) nn_W = 0;
-    ngroups_cfg = std::max(1, std::min(8, env_int("APDGICP_STREAMS", 3)));
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     return set_params(p);
   }
@@ -470,7 +446,7 @@ class Engine {
     APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
     c.staged = false;
-    if (!on_device && direct_stage && sort_in_registers && sort_tiled && n > 2048 && n <= SORT_LDS_MAX_N) {
+    if (!on_device && n > 2048 && n <= SORT_LDS_MAX_N) {
       // scan-sized host clouds: packed into the slot's own pinned buffer, bounding box behind the points, and the sort reads
       // them from there (k_sort_tiles).  Nothing is enqueued here, not even an event: the buffer is rewritten after the poll
       // of the align that followed the sort (an event between the sort's launches costs 6 us of the frame), and a cloud
@@ -611,7 +587,7 @@ class Engine {
 
   // Z-curve sort + chunk/group boxes of every cloud that was (re)set since the last call
   int sort_clouds() {
-    std::vector<SortJob> small, regjobs[3];
+    std::vector<SortJob> small;
     std::vector<TileJob> tilejobs[3];
     size_t tkeys_bytes = 0;
     std::vector<int> large;
@@ -639,15 +615,13 @@ class Engine {
         SortJob j;
         j.pts = c.opts.as<float4>(), j.spts = c.pts.as<float4>(), j.perm = c.perm.as<int>();
         j.cbox = c.cbox.as<Box>(), j.gbox = c.gbox.as<Box>(), j.n = c.n, j.pad_ = 0;
-        if (c.n > 2048 && sort_in_registers && sort_tiled) {  // four tiles of 1024 / 2048 / 4096 keys
+        if (c.n > 2048) {  // four tiles of 1024 / 2048 / 4096 keys
           const int cls = c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2;
           TileJob tjb;
           tjb.job = j, tjb.keys = (unsigned long long*)tkeys_bytes /* offset, fixed up below */, tjb.nt = 1024 << cls, tjb.pad_ = 0;
           tjb.staged = c.staged ? (const float4*)c.stage_dev : nullptr;
           tkeys_bytes += (size_t)4 * tjb.nt * 8;
           tilejobs[cls].push_back(tjb);
-        } else if (c.n > 2048 && sort_in_registers) {  // k_sort_cloud_reg<E>: 1024*E/2 < n <= 1024*E
-          regjobs[c.n <= 4096 ? 0 : c.n <= 8192 ? 1 : 2].push_back(j);
         } else {
           small.push_back(j);
           int np2 = 1;
@@ -663,17 +637,6 @@ class Engine {
     if (!small.empty()) {
       APD_TRY(d_sortjobs.upload(small.data(), small.size() * sizeof(SortJob), cstream));
       hipLaunchKernelGGL(k_sort_cloud_lds, dim3((unsigned)small.size()), dim3(SORT_BLK), (size_t)np2max * 8, cstream, d_sortjobs.as<SortJob>());
-      APD_HIP(hipGetLastError());
-    }
-    for (int cls = 0; cls < 3; cls++) {
-      if (regjobs[cls].empty()) continue;
-      APD_TRY(d_sortjobs_reg[cls].upload(regjobs[cls].data(), regjobs[cls].size() * sizeof(SortJob), cstream));
-      const size_t lds = (size_t)(4 << cls) * SORT_BLK * 8;
-      const SortJob* dj = d_sortjobs_reg[cls].as<SortJob>();
-      const dim3 grid((unsigned)regjobs[cls].size());
-      if (cls == 0) hipLaunchKernelGGL(k_sort_cloud_reg<4>, grid, dim3(SORT_BLK), lds, cstream, dj);
-      else if (cls == 1) hipLaunchKernelGGL(k_sort_cloud_reg<8>, grid, dim3(SORT_BLK), lds, cstream, dj);
-      else hipLaunchKernelGGL(k_sort_cloud_reg<16>, grid, dim3(SORT_BLK), lds, cstream, dj);
       APD_HIP(hipGetLastError());
     }
     if (tkeys_bytes) {
@@ -770,11 +733,6 @@ class Engine {
     APD_HIP(hipMemcpyAsync(h_flag, d_errflag.p, sizeof(int), hipMemcpyDeviceToHost, cstream));
     APD_HIP(hipStreamSynchronize(cstream));
     flag = h_flag[0];
-    if (flag && env_int("APDGICP_IGNORE_ERRFLAG", 0)) {  // debugging aid only
-      fprintf(stderr, "[apdgicp] %s: device error flag %d ignored\n", what, flag);
-      APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), cstream));
-      return 0;
-    }
     if (flag) {
       APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), cstream));
       return fail(APDGICP_ERR_INTERNAL, std::string(what) + ": " + errflag_text(flag));
@@ -814,29 +772,24 @@ class Engine {
     long long total = 0;
     for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
     if (knn_pruned) {
-      // queries per wave: 64 amortises the group loads best; fewer queries per wave shorten the per-wave
-      // dependency chain and shrink its LDS lists, which wins whenever the GPU is not already full
-      int qpw = env_int("APDGICP_KNN_QPW", 0);
-      if (qpw != 4 && qpw != 8 && qpw != 16 && qpw != 32 && qpw != 64) qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;  // measured (r01): 2 clouds of 8k 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16
+      // queries per wave = 64 / lanes per query: fewer queries per wave shorten the per-wave dependency chain and shrink its LDS
+      // lists, which wins whenever the GPU is not already full (r01, 2 clouds of 8k: 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16)
+      const int qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;
       const dim3 grid((unsigned)((nmax + qpw - 1) / qpw), (unsigned)count);
-      const int coop = env_int("APDGICP_KNN_COOP", 1);  // 4 or 8 lanes per query in the lane = query phases
       // throughput launches regularise in a second launch with every lane busy; a single cloud (latency) keeps it fused
-      const int raw = coop && qpw != 4 && params.regularization != APDGICP_REG_NONE && split_regularize ? 1 : 0;
-      if (coop && qpw == 16)
+      const int raw = qpw != 4 && params.regularization != APDGICP_REG_NONE ? 1 : 0;
+      if (qpw == 16)
         hipLaunchKernelGGL(k_knn_cov_coop<4>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
-      else if (coop && qpw == 4)
+      else if (qpw == 4)
         hipLaunchKernelGGL(k_knn_cov_coop<16>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
-      else if (coop && qpw == 8)
+      else
         hipLaunchKernelGGL(k_knn_cov_coop<8>, grid, dim3(64), knn_coop_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
                            params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), raw);
       if (raw)
         hipLaunchKernelGGL(k_regularize_covs, dim3((unsigned)((nmax + 255) / 256), (unsigned)count), dim3(256), 0, st, d_desc.as<CloudDesc>(), d_list,
                            params.regularization, d_errflag.as<int>());
-      if (!(coop && (qpw == 16 || qpw == 4 || qpw == 8)))
-        hipLaunchKernelGGL(k_knn_cov_pruned, grid, dim3(64), knn_lds_bytes(qpw), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
-                           params.regularization, d_errflag.as<int>(), d_stats.as<unsigned long long>(), qpw);
     } else {
       const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)count);
       hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
@@ -917,19 +870,13 @@ class Engine {
     (void)with_guess;
     APD_TRY(upload_guesses(guesses.data(), n));
 
-    // launch shape of the NN kernel: S sources per lane, T target splits (tunable for experiments)
-    const int nchunks_min = 1;
-    (void)nchunks_min;
-    int S = env_int("APDGICP_NN_S", 0);
-    int T = 1;
-    if (nn_pruned) {
-      if (S != 1 && S != 2 && S != 4) S = 1;
-    } else {
-      if (S != 2 && S != 4 && S != 8) S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
+    // launch shape of the search: the pruned kernels take one source point per lane; the brute-force cross-check
+    // (APDGICP_NN_MODE=brute) S = 2 or 4 per lane and T target splits, enough blocks to fill the GPU
+    int S = 1, T = 1;
+    if (!nn_pruned) {
+      S = ((long long)npairs * ((nmax_src + 1023) / 1024) >= 256) ? 4 : 2;
       const int src_blocks = (nmax_src + NN_BLK * S - 1) / (NN_BLK * S);
-      T = env_int("APDGICP_NN_T", 0);
-      if (T <= 0) T = (512 + npairs * src_blocks - 1) / (npairs * src_blocks);
-      T = std::max(1, std::min(T, 64));
+      T = std::max(1, std::min((512 + npairs * src_blocks - 1) / (npairs * src_blocks), 64));
     }
     nn_S = S;
     work.T = T;
@@ -962,7 +909,7 @@ class Engine {
     if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
     work.init = nullptr;
-    work.coop_search = nn_coop_tail ? 1 : 0;
+    work.coop_search = 1;
     work.post = nullptr, work.post_seq = 0;
     work.pair0 = 0;
     work.npairs = npairs;
@@ -1028,27 +975,23 @@ class Engine {
     // a handle limited to one pair group shares the GPU with other busy handles: throughput counts there, not the latency of
     // this launch, and one wave per 64 points does no redundant bound work (three handles in flight: 1.32 -> 1.27 ms per step)
     const int w_full = max_groups == 1 || in_pool ? 1 : 2;
-    const long long w4_blocks = in_pool ? pool.w4_blocks : 1024;
-    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= w4_blocks || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
+    const int W = nn_W ? nn_W : tick_blocks <= 256 ? 8 : (tick_blocks <= 1024 || (big_target && tick_blocks <= 8192)) ? 4 : w_full;
     // throughput regime (one wave per 64 points) with neighbour keeping on: blocks of 256 points that pack the points still
     // searching into as few waves as they fill (k_nn_compact)
     // (not for dense targets beyond 16384 points when the engine chose the regime itself: a wave there walks many batches of
     // group boxes, and 100k x 500k measured 0.232 ms per iteration against 0.170 with one-wave blocks, 0.103 with W = 4)
-    if (nn_pruned && nn_S == 1 && W == 1 && t_work().nnaux && nn_compact && (!big_target || nn_W == 1)) {
+    if (nn_pruned && W == 1 && t_work().nnaux && (!big_target || nn_W == 1)) {
       // (blocks of 512 points waste half as many tail waves -- 29.5 instead of 36 search waves per 256 points over the 20
       // ticks of the bench -- but hold twice the LDS until their slowest wave is done: measured 34.7 k vs 37.0 k registrations/s)
       grid.x = (unsigned)((t_nmax_src() + 255) / 256);
       APD_NN_LAUNCH(k_nn_compact<4>, 256);
     } else if (nn_pruned) {
-      if (nn_S == 1 && W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
-      else if (nn_S == 1 && W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
-      else if (nn_S == 1 && W == 2) APD_NN_LAUNCH((k_nn_pruned<1, 2>), 128);
-      else if (nn_S == 1) APD_NN_LAUNCH((k_nn_pruned<1, 1>), 64);
-      else if (nn_S == 2) APD_NN_LAUNCH((k_nn_pruned<2, 1>), 64);
-      else APD_NN_LAUNCH((k_nn_pruned<4, 1>), 64);
+      if (W == 8) APD_NN_LAUNCH((k_nn_pruned<1, 8>), 512);
+      else if (W == 4) APD_NN_LAUNCH((k_nn_pruned<1, 4>), 256);
+      else if (W == 2) APD_NN_LAUNCH((k_nn_pruned<1, 2>), 128);
+      else APD_NN_LAUNCH((k_nn_pruned<1, 1>), 64);
     } else if (nn_S == 2) APD_NN_LAUNCH(k_nn_partial<2>, NN_BLK);
-    else if (nn_S == 4) APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
-    else APD_NN_LAUNCH(k_nn_partial<8>, NN_BLK);
+    else APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
 #undef APD_NN_LAUNCH
     return 0;
   }
@@ -1078,7 +1021,6 @@ class Engine {
   }
 
   float gate_cap() const {  // smallest float >= corr_dist_threshold^2 (A:156 compares the float distance with the double square)
-    if (!nn_gate_cap) return std::numeric_limits<float>::infinity();
     const double thr2 = consts().thr2;
     float capf = (float)thr2;
     if ((double)capf < thr2) capf = std::nextafterf(capf, std::numeric_limits<float>::infinity());
@@ -1087,21 +1029,12 @@ class Engine {
 
   // one tick of the state machines of the pairs in `sp`
   int launch_tick(Span sp) {
-    const Consts c = consts();
-    Work w = t_work();
-    w.pair0 = sp.p0;
     nn_cap = gate_cap();
     const int rc_nn = launch_nn(sp);
     nn_cap = std::numeric_limits<float>::infinity();
     APD_TRY(rc_nn);
-    APD_TRY(launch_linearize(sp, fuse_lm ? 2 : 1));
-    if (!fuse_lm)
-      hipLaunchKernelGGL(k_lm_solve, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, c);
-    if (params.optimizer == APDGICP_OPT_LM) {
-      APD_TRY(launch_error(sp, fuse_lm));
-      if (!fuse_lm)
-        hipLaunchKernelGGL(k_lm_decide, dim3(sp.np), dim3(64), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, c);
-    }
+    APD_TRY(launch_linearize(sp, 2));
+    if (params.optimizer == APDGICP_OPT_LM) APD_TRY(launch_error(sp, true));
     return 0;
   }
 
@@ -1158,7 +1091,7 @@ class Engine {
       const int flag = h_status[pending_npairs];
       tickets_dirty = true;
       APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
-      if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
+      return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
     }
     return 0;
   }
@@ -1194,7 +1127,7 @@ class Engine {
     const long long tick_cap = (long long)std::max(0, params.max_iterations) * (lm ? std::max(1, params.lm_max_iterations) : 1);
     // the fused optimiser builds the state in the last block of the first k_linearize (Work::init): one launch less per
     // align.  The arrival counters reset themselves; only a run that ended in an error may have left them mid-count
-    fold_init = fold_init_cfg && fuse_lm && nn_pruned && tick_cap > 0 && !tickets_dirty;
+    fold_init = nn_pruned && tick_cap > 0 && !tickets_dirty;
     if (!fold_init) {
       hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<Rigid>(), npairs,
                          params.max_iterations, b_ticket.as<int>());
@@ -1204,9 +1137,7 @@ class Engine {
     // pair hits an exactly-zero step, so one poll at the end is enough.
     // LM polls after 1, then 2, then every 4 ticks: with the shipped parameters most registrations converge in 1-3
     // iterations, and every tick enqueued past convergence is three empty launches
-    const int chunk_cfg = env_int("APDGICP_POLL_TICKS", 0);
     auto chunk_at = [&](long long done) {
-      if (chunk_cfg > 0) return chunk_cfg;
       if (!lm) return std::min(64, std::max(1, params.max_iterations));
       return done == 0 ? 1 : done < 3 ? 2 : 4;
     };
@@ -1214,8 +1145,6 @@ class Engine {
     bool all_done = params.max_iterations <= 0;
     work.active = nullptr;
     int n_active = npairs;
-    const bool dbg_t = env_int("APDGICP_DEBUG_TIMING", 0) != 0;
-    const auto t_begin = std::chrono::steady_clock::now();
     while (!all_done && ticks < tick_cap) {
       // GN needs exactly max_iterations ticks unless a pair converges early; never enqueue more than that
       const int todo = (int)std::min<long long>(chunk_at(ticks), tick_cap - ticks);
@@ -1246,7 +1175,7 @@ class Engine {
       poll_seq = spin ? poll_seq + 1 : poll_seq;
       // a single registration: the last kernel of the chunk's last tick writes the poll itself (post_result), no k_finalize
       // (Levenberg-Marquardt: k_error ends the tick)
-      const bool fold_poll = fold_poll_cfg && fuse_lm && lm && npairs == 1 && spin && ng == 1;
+      const bool fold_poll = lm && npairs == 1 && spin && ng == 1;
       if (fold_poll) {  // where the record goes: the same for every poll of this handle (uploaded when it changes)
         const PollPost post{d_results.as<ResultRec>(), d_stat, (ResultRec*)h_poll_dev, (int*)(h_poll_dev + ((char*)h_status - h_poll)),
                             (int*)(h_poll_dev + ((char*)h_seq - h_poll)), d_errflag.as<int>()};
@@ -1293,14 +1222,10 @@ class Engine {
         APD_HIP(hipGetLastError());
         return 0;
       }
-      const auto t_enq = std::chrono::steady_clock::now();
       {
         roctx_range rr("apdgicp:poll");
         APD_TRY(wait_poll());
       }
-      if (dbg_t)
-        fprintf(stderr, "[apdgicp] %d ticks: enqueue %.3f ms, wait %.3f ms\n", todo, std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
       h_active.clear();
       for (int p = 0; p < npairs; p++)
         if (h_status[p] != ST_DONE) h_active.push_back(p);
@@ -1315,7 +1240,7 @@ class Engine {
         tickets_dirty = true;
         APD_HIP(hipMemsetAsync(d_errflag.p, 0, sizeof(int), stream));
         work.active = nullptr;
-        if (!env_int("APDGICP_IGNORE_ERRFLAG", 0)) return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
+        return fail(APDGICP_ERR_INTERNAL, errflag_text(flag));
       }
     }
     work.active = nullptr;
@@ -1372,10 +1297,9 @@ class Engine {
     int adm[kPoolRing] = {};
     int ub = 0;  // upper bound of the device's list length behind the last ENQUEUED poll
     int kill_mask = 0;
-    int ticks_per_chunk = 2, depth = 2;
-    int groups = 2, group_min = 24, head_ticks = 1;  // see pool_enqueue_chunk
-    float head_frac = 0.5f;
-    int w4_blocks = 1024;  // tick launches of up to this many 64-point blocks search with four waves per block
+    int ticks_per_chunk = 2;  // APDGICP_POOL_TICKS
+    // measured (tools/pool_sweep.sh, docs/experiments.md): chunks two deep, the list cut into two slices from 24 pairs on
+    static constexpr int depth = 2, groups = 2, group_min = 24;
     int last_lane = -1;
     long long n_chunks = 0, n_ticks = 0, n_pair_ticks = 0;  // statistics (apdgicp_batch_last_ticks)
     std::vector<int> cloud_busy;
@@ -1383,7 +1307,7 @@ class Engine {
 
   bool pool_eligible() const {
     const bool enabled = env_int("APDGICP_LM_POOL", 1) != 0;  // (0: the host-polled loop of run_align, the cross-check)
-    return enabled && params.optimizer == APDGICP_OPT_LM && params.max_iterations > 0 && nn_pruned && fuse_lm;
+    return enabled && params.optimizer == APDGICP_OPT_LM && params.max_iterations > 0 && nn_pruned;
   }
   PoolHdr* pool_hdr(uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing; }
   bool pool_busy() const {
@@ -1400,12 +1324,7 @@ class Engine {
       for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&pool.ev[i], hipEventDisableTiming));
       for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
       pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 2)));
-      pool.depth = std::max(1, std::min(kPoolRing - 2, env_int("APDGICP_POOL_DEPTH", 2)));
-      pool.groups = std::max(1, std::min(8, env_int("APDGICP_POOL_GROUPS", 2)));
-      pool.group_min = std::max(2, env_int("APDGICP_POOL_GROUP_MIN", 24));
-      pool.w4_blocks = std::max(256, env_int("APDGICP_POOL_W4_BLOCKS", 1024));
-      pool.head_ticks = std::max(1, std::min(8, env_int("APDGICP_POOL_HEAD_TICKS", 1)));
-      if (const char* v = getenv("APDGICP_POOL_HEAD_FRAC")) pool.head_frac = std::max(0.05f, std::min(0.95f, (float)atof(v)));
+
     }
     cstream = pool.cstream;
     pool.on = true;
@@ -1480,7 +1399,7 @@ class Engine {
     w.errpart = pool.errpart.as<double>();
     w.stats = d_stats.as<unsigned long long>();
     w.ticket = pool.ticket.as<int>();
-    w.coop_search = nn_coop_tail ? 1 : 0;
+    w.coop_search = 1;
     w.pair0 = 0, w.npairs = cap;
     w.active = pool.active.as<int>();
     nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)
@@ -1529,20 +1448,17 @@ class Engine {
       // The list is in admission order: its head holds what is left of the oldest batches -- few pairs, each with many iterations
       // to go, a latency-bound chain of small launches -- its tail the young batches whose launches are wide.  In one stream
       // every pair advances at the pace of the widest launch, so the list is cut into `groups` slices that tick on streams of
-      // their own between two polls; the head slice gets `head_ticks` times the ticks of the others (a pair that is done, or a
-      // slot behind the end of the list, leaves its launches at once).
+      // their own between two polls (a pair that is done, or a slot behind the end of the list, leaves its launches at once).
       const int G = pool.ub >= pool.group_min ? pool.groups : 1;
       APD_TRY(ensure_group_streams(G));
       if (G > 1) {
         APD_HIP(hipEventRecord(ev_main, stream));
         for (int g = 1; g < G; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
       }
-      const int head = G > 1 ? std::max(1, std::min(pool.ub - (G - 1), (int)(pool.ub * pool.head_frac))) : pool.ub;
       for (int g = 0; g < G; g++) {
-        const int p0 = g == 0 ? 0 : head + (int)((long long)(pool.ub - head) * (g - 1) / (G - 1));
-        const int p1 = g == 0 ? head : head + (int)((long long)(pool.ub - head) * g / (G - 1));
+        const int p0 = (int)((long long)pool.ub * g / G), p1 = (int)((long long)pool.ub * (g + 1) / G);
         if (p1 <= p0) continue;
-        const int nt = pool.ticks_per_chunk * (g == 0 && G > 1 ? pool.head_ticks : 1);
+        const int nt = pool.ticks_per_chunk;
         cur_active = p1 - p0;
         for (int t = 0; t < nt; t++) APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
         pool.n_pair_ticks += (long long)nt * (p1 - p0);

@@ -8,7 +8,7 @@
 //   k_nn_partial       the 1-NN search of update_correspondences, A:149-153 (brute force, LDS tiles)
 //   k_linearize        rest of update_correspondences A:156-192 + linearize A:221-260
 //   k_error            compute_error, A:275-298
-//   k_lm_solve/decide  LsqRegistration::step_gn / step_lm, L:107-173, one lane per registration
+//   (last block of k_linearize / k_error)  LsqRegistration::step_gn / step_lm, L:107-173, one lane per registration
 //   k_finalize         final_transformation_ = x0.cast<float>(), L:78
 //
 // All kernels are batched: the registration ("pair") index is a grid dimension and every pair
@@ -1282,235 +1282,35 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_f
 __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)orig; }
 
 // ----------------------------------------------------------------------------------------------
-// k_knn_cov_pruned: calculate_covariances (A:303-363) on Z-curve-sorted clouds; exact k-NN.
-// One wave owns 64 consecutive sorted queries (spatial neighbours, so they need the same few
-// target groups) and alternates between two lane mappings:
-//   A  lane = query     : tau = k-th smallest of 32 strided class minima over the ~192 sorted
-//                         neighbours staged in LDS (k distinct points lie within tau, so it bounds the
-//                         k-th neighbour distance); then a 64-bit mask of the groups whose box is within tau
-//   B  lane = candidate : every group some query needs is loaded ONCE (2 candidates per lane,
-//                         coalesced); for each query that needs it (uniform loop, query broadcast by
-//                         readlane) the 128 keys (distance bits << 32 | original index) are compared
-//                         with the query's tau and the hits are compacted into its LDS list with
-//                         ballot/popcount -- no divergence.  A full list is tightened in place to its k
-//                         smallest keys (tau only decreases, nothing of the final answer is dropped).
-//   C  lane = query     : k rounds of min-extraction over the own list (u64 order == the reference's
-//                         (distance, index) order), gather of the k points, moments in fp64 relative
-//                         to the query (exact differences), cov = S2/k - m m^T (A:323-324), 3x3 Jacobi
-//                         eigen-decomposition and the regularisation (A:326-357).
-constexpr int KQ_CAP = 48, KQ_STRIDE = 49, KQ_WIN = 128;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.683 / 0.674 / 0.675 / 0.695 / 0.735 ms (64 clouds)
-constexpr int KQ_LDS_BYTES = 64 * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4 + 64 * 4;
-
-// qpw = queries per wave (16, 32 or 64): fewer queries per wave = shorter dependency chains and
-// smaller lists (more waves per CU); lanes >= qpw only help in the lane = candidate phase.
-__host__ __device__ constexpr int knn_lds_bytes(int qpw) { return qpw * KQ_STRIDE * 8 + KQ_WIN * 16 + 64 * 6 * 4; }
-// k_knn_cov_coop: list entries per query -- 60 with 4 lanes per query (16 queries per wave: 7.8 KB of lists, what five resident
-// waves per SIMD leave of the LDS; 48 overflowed 3.8 times per wave, and every overflow is a radix select of 300 scalar
-// instructions on the one scalar unit the four SIMDs share), 48 otherwise
+// k_knn_cov_coop<L>: calculate_covariances (A:303-363) on curve-sorted clouds; exact k-NN.  One wave owns 64 / L consecutive
+// sorted queries (spatial neighbours, so they need the same few target groups), L = 4, 8 or 16 lanes per query, and
+// alternates between two lane mappings:
+//   A  lane = (query, 1/L of the work): tau = k-th smallest of 32 strided class minima over the KQ_WIN sorted neighbours
+//      around the wave, read straight from L1 (k distinct points lie within tau, so it bounds the k-th neighbour distance);
+//      the L lanes of a query split the 32 classes (L = 4: sorted in place by a network over (lane, register)).  Group
+//      masks: lane g keeps the box of group g in registers and tests it against one query per trip, broadcast through
+//      SGPRs -- the ballot is that query's mask;
+//   B  lane = candidate: every group some query needs is loaded ONCE (2 candidates per lane, coalesced); for each query
+//      that needs it (uniform loop, query broadcast by readlane) the 128 keys (distance bits << 32 | original index) are
+//      compared with the query's tau and the hits are compacted into its LDS list with ballot / popcount -- no divergence.
+//      A full list is tightened in place to its k smallest keys (tau only decreases, nothing of the final answer is
+//      dropped); the query state (tau, count) is kept identical in the L lanes;
+//   C  lane = (query, 1/L): each lane sorts its share of the list in REGISTERS, the k neighbours come out of an L-way merge
+//      (a DPP butterfly over the heads per round, no LDS reads inside the rounds; u64 order == the reference's (distance,
+//      index) order); gather of the k points, moments in fp64 relative to the query (exact differences) as four partial
+//      sums in rank order (Mom9), cov = S2/k - m m^T (A:323-324), 3x3 Jacobi eigen-decomposition and the regularisation
+//      (A:326-357) -- in the epilogue for a single cloud, in k_regularize_covs for batches.
+// (The one-lane-per-query predecessor of this kernel, k_knn_cov_pruned, is in the history of round 2 and in docs/experiments.md.)
+constexpr int KQ_WIN = 128;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.683 / 0.674 / 0.675 / 0.695 / 0.735 ms (64 clouds)
+// list entries per query -- 60 with 4 lanes per query (16 queries per wave: 7.8 KB of lists, what five resident waves per SIMD
+// leave of the LDS; 48 overflowed 3.8 times per wave, 60 does 2.9 times, and every overflow is a radix select of about 300
+// scalar instructions on the ONE scalar unit the four SIMDs share), 48 otherwise
 #ifndef APD_KNN_CAP4
 #define APD_KNN_CAP4 60
 #endif
 __host__ __device__ constexpr int knn_coop_cap(int lanes_per_query) { return lanes_per_query == 4 ? APD_KNN_CAP4 : 48; }
 __host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * (knn_coop_cap(64 / qpw) + 1) * 8; }  // lists only (boxes in registers, window from L1)
 
-__global__ __launch_bounds__(64) void k_knn_cov_pruned(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
-                                                       unsigned long long* stats, int qpw) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
-  unsigned long long* lst = knn_smem;                            // [query][slot], padded row
-  float4* wtile = (float4*)(lst + qpw * KQ_STRIDE);              // sorted neighbourhood
-  float* gbl = (float*)(wtile + KQ_WIN);                         // 64 group boxes
-  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
-  const int n = c.n, lane = threadIdx.x;
-  const int base = blockIdx.x * qpw;
-  if (base >= n) return;
-  const float inf = __builtin_inff();
-  const int i = base + lane;
-  const bool valid = lane < qpw && i < n;
-  const float4 q = c.pts[valid ? i : n - 1];
-  const int ngroups = (n + kGroupPts - 1) / kGroupPts;
-  unsigned n_groups = 0, n_pairs = 0, n_compact = 0;
-
-  // ---- A: bound from the sorted neighbourhood
-  const int w0 = min(max(base - (KQ_WIN - qpw) / 2, 0), max(n - KQ_WIN, 0));
-  for (int e = lane; e < KQ_WIN; e += 64) {
-    const int j = w0 + e;
-    float4 t = make_float4(inf, inf, inf, 0.f);
-    if (j < n) t = c.pts[j];
-    wtile[e] = t;
-  }
-  int cnt = 0;  // entries in this lane's (= query's) list
-  int idx_bits = 1;
-  while ((1 << idx_bits) < n) idx_bits++;
-  __syncthreads();
-  float cm[KNN_NC];
-#pragma unroll
-  for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
-  for (int e0 = 0; e0 < KQ_WIN; e0 += KNN_NC) {
-#pragma unroll
-    for (int s = 0; s < KNN_NC; s++) {
-      const float4 t = wtile[e0 + s];
-      cm[s] = fminf(cm[s], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
-    }
-  }
-#pragma unroll
-  for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
-#pragma unroll
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int a = 0; a < KNN_NC; a++) {
-        const int l = a ^ j;
-        if (l > a) {
-          const bool up = (a & kk) == 0;
-          const float x = cm[a], y = cm[l];
-          const float lo = fminf(x, y), hi = fmaxf(x, y);
-          cm[a] = up ? lo : hi;
-          cm[l] = up ? hi : lo;
-        }
-      }
-    }
-  }
-  float tau_d = inf;
-#pragma unroll
-  for (int s = 0; s < KNN_NC; s++)
-    if (s == k - 1) tau_d = cm[s];
-  if (!valid) tau_d = -1.f;
-  unsigned tau_hi = __float_as_uint(tau_d), tau_lo = 0xFFFFFFFFu;  // tau key = (tau_hi << 32) | tau_lo
-
-  // ---- B
-  for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {
-    const int nb = min(64, ngroups - gb0);
-    __syncthreads();
-    for (int e = lane; e < 6 * nb; e += 64) gbl[e] = ((const float*)c.gbox)[(size_t)gb0 * 6 + e];
-    __syncthreads();
-    unsigned long long gneed = 0;
-    {
-      const float td = __uint_as_float(tau_hi);
-      for (int g = 0; g < nb; g++)
-        if (lb_point_box(lds_box(gbl, g), q.x, q.y, q.z) <= td) gneed |= 1ull << g;
-      if (!valid) gneed = 0;
-    }
-    for (int g = 0; g < nb; g++) {
-      unsigned long long qm = __ballot((gneed >> g) & 1ull);
-      if (!qm) continue;
-      n_groups++;
-      const int j0 = (gb0 + g) * kGroupPts + lane, j1 = j0 + 64;
-      float4 c0 = make_float4(inf, inf, inf, 0.f), c1 = c0;
-      unsigned o0 = 0xFFFFFFFFu, o1 = 0xFFFFFFFFu;
-      if (j0 < n) c0 = c.pts[j0], o0 = __float_as_uint(c0.w);  // (the sorted points carry their original index in .w)
-      if (j1 < n) c1 = c.pts[j1], o1 = __float_as_uint(c1.w);
-      while (qm) {
-        const int qq = __builtin_ctzll(qm);
-        qm &= qm - 1;
-        n_pairs++;
-        // broadcast of query qq through SGPRs (v_readlane), no LDS traffic
-        const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
-        unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
-                                (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
-        const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
-        const unsigned long long k1 = ((unsigned long long)__float_as_uint(sqdist1(c1.x, c1.y, c1.z, qx, qy, qz)) << 32) | o1;
-        unsigned long long* row = lst + qq * KQ_STRIDE;
-        int cntq = __builtin_amdgcn_readlane(cnt, qq);
-        unsigned long long m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
-        if (cntq + __popcll(m0) + __popcll(m1) > KQ_CAP) {
-          // List full: tau becomes the k-th smallest key of (stored keys U this group's hits); only
-          // keys <= tau survive.  tau only decreases, so nothing of the final answer is ever dropped,
-          // and exactly k keys remain afterwards (keys are unique), which always fits.
-          const unsigned long long mine = lane < cntq ? row[lane] : ~0ull;  // KQ_CAP <= 64: one entry per lane
-          const unsigned long long h0 = k0 <= tk ? k0 : ~0ull, h1 = k1 <= tk ? k1 : ~0ull;
-#ifdef APD_KNN_ROUNDS
-          {
-            unsigned long long last = 0;
-            bool first = true;
-            for (int r = 0; r < k; r++) {
-              unsigned long long cand = ~0ull;
-              if ((first || mine > last) && mine < cand) cand = mine;
-              if ((first || h0 > last) && h0 < cand) cand = h0;
-              if ((first || h1 > last) && h1 < cand) cand = h1;
-              last = wave_min_u64(cand), first = false;
-            }
-            tk = last < tk ? last : tk;
-          }
-#else
-          tk = wave_kth_smallest3(mine, h0, h1, k, idx_bits);
-#endif
-          const unsigned long long keep = __ballot(mine <= tk);
-          if (mine <= tk) row[__popcll(keep & ((1ull << lane) - 1ull))] = mine;
-          cntq = __popcll(keep);
-          if (lane == qq) tau_hi = (unsigned)(tk >> 32), tau_lo = (unsigned)tk;
-          m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
-          n_compact++;
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int total = cntq + __popcll(m0) + __popcll(m1);
-        if (total > KQ_CAP) {  // impossible by construction (total == k after a tightening); never silently wrong
-          if (lane == 0) atomicExch(err_flag, 4);
-        } else {
-          if (k0 <= tk) row[cntq + __popcll(m0 & below)] = k0;
-          if (k1 <= tk) row[cntq + __popcll(m0) + __popcll(m1 & below)] = k1;
-          if (lane == qq) cnt = total;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (stats && lane == 0) {
-    atomicAdd(stats + 4, (unsigned long long)n_groups), atomicAdd(stats + 7, 1ull);
-    atomicAdd(stats + 8, (unsigned long long)n_compact), atomicAdd(stats + 9, (unsigned long long)n_pairs);
-  }
-  if (!valid) return;
-
-  // ---- C
-  const unsigned long long* row = lst + lane * KQ_STRIDE;
-  Mom9x4 acc;
-  {
-    unsigned long long last = 0;
-    bool first = true;
-    float4 pend = q;  // software pipeline: the gather of round r is consumed in round r+1
-    bool have = false;
-    for (int r = 0; r <= k; r++) {
-      unsigned long long bk = ~0ull;
-      if (r < k) {
-        for (int a = 0; a < cnt; a++) {
-          const unsigned long long x = row[a];
-          if ((first || x > last) && x < bk) bk = x;
-        }
-        if (bk == ~0ull) {
-          atomicExch(err_flag, 2);
-          break;
-        }
-        last = bk, first = false;
-      }
-      const float4 nxt = r < k ? c.opts[(unsigned)bk] : q;
-      if (have) acc.add(r - 1, (double)pend.x - (double)q.x, (double)pend.y - (double)q.y, (double)pend.z - (double)q.z);
-      pend = nxt, have = true;
-    }
-  }
-  const Mom9 mt = acc.total();
-  const double s1x = mt.s1x, s1y = mt.s1y, s1z = mt.s1z, sxx = mt.sxx, sxy = mt.sxy, sxz = mt.sxz, syy = mt.syy, syz = mt.syz, szz = mt.szz;
-  const double ik = 1.0 / (double)k;
-  const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
-  Sym3 pc;
-  pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
-  pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
-  Sym3 out;
-  if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
-  double* cov = c.cov;
-  cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
-}
-
-// ----------------------------------------------------------------------------------------------
-// k_knn_cov_coop<L>: the same algorithm with L = 4, 8 or 16 lanes per query (64/L queries per wave) in the
-// lane = query phases, so those phases cost 1/L of the instructions and stop being one long serial
-// chain per lane:
-//   A  the L lanes of a query split the 32 distance classes of the KQ_WIN sorted neighbours around the wave, read
-//      straight from L1 (32/L class minima per lane, exchanged through LDS; every lane then runs the same 32-key
-//      sorting network).  Group masks: lane g keeps the box of group g in registers and tests it against one query
-//      per trip, broadcast through SGPRs -- the ballot is that query's mask;
-//   B  unchanged (lane = candidate); the query state (tau, count) is kept identical in the L lanes;
-//   C  each lane keeps KQ_CAP/L list entries in REGISTERS; a round is a register-only local minimum
-//      plus a DPP butterfly over the L lanes -- no LDS reads inside the k rounds.  All L lanes
-//      accumulate the moments of the same neighbours in rank order, so the result is bitwise the one of
-//      the single-lane formulation.
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
@@ -2199,9 +1999,6 @@ __device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int 
 constexpr int LIN_BLK = 256;
 constexpr int kSerialRows = 32;  // up to this many block rows (8192 points) the last block adds them one after the other
 
-__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
-                                              double* stage = nullptr, int prestaged = 0);
-__device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c);
 __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c);
 __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c);
 __device__ __forceinline__ void fill_from_sums(PairState& s, const double* v);
@@ -2209,7 +2006,7 @@ __device__ __forceinline__ void fill_from_sums(PairState& s, const double* v);
 // Cross-block traffic inside one launch (the rows of partial sums, read by the last block of a pair) goes through
 // agent-scope atomic loads and stores: they are coherent at device level by themselves (sc1), so no release/acquire
 // fence is needed.  On this multi-XCD part an agent-scope fence writes back / invalidates a whole L2, which is what made
-// the first fused version (fence pair per block) slower than a separate k_lm_solve launch.
+// the first fused version (fence pair per block) slower than a separate one-block-per-pair solve launch.
 __device__ __forceinline__ double ld_coh(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -2246,7 +2043,7 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
   return s_last != 0;
 }
 
-// want_Hb: 0 = cost only, 1 = H, b, cost, 2 = also run the GN/LM step (k_lm_solve's work) in the last block
+// want_Hb: 0 = cost only, 1 = H, b, cost, 2 = also run the GN/LM step (L:107-144) in the last block
 // FUSED = false: the per-point pass alone (want_Hb 0 or 1): without the optimiser step's register footprint (a 6x6 LDL^T, so3_exp
 // and the pose products, all in registers on one lane) the kernel fits 6 waves per SIMD instead of 4.
 #ifndef APD_LIN_WPE
@@ -2316,7 +2113,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     else *row = s;
   }
   if constexpr (FUSED)
-  if (want_Hb == 2) {  // the last block of the pair to arrive takes the GN/LM step: no k_lm_solve launch
+  if (want_Hb == 2) {  // the last block of the pair to arrive takes the GN/LM step: no launch of its own
     __shared__ PairState ls;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
     if (last_block_of_pair(w.ticket + pair, nblk, tid)) {
@@ -2396,7 +2193,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
     if (fuse) st_coh(row, s);
     else *row = s;
   }
-  if (fuse) {  // the last block of the pair to arrive decides (L:145-172): no k_lm_decide launch
+  if (fuse) {  // the last block of the pair to arrive decides (L:145-172): no launch of its own
     __shared__ PairState ls;
     __shared__ double s_yi;
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
@@ -2471,31 +2268,10 @@ __device__ __forceinline__ void fill_from_sums(PairState& s, const double* v) {
   s.y0 = v[27];
   s.n_matched = (int)v[28];
 }
-// stage (optional, kGatherRows * kRed doubles of LDS, 64-thread callers only): the rows are fetched with
-// coalesced loads that are all in flight together, kGatherRows at a time, and summed out of LDS -- the
-// same order of additions without one memory round trip per row.
-constexpr int kGatherRows = 128;
-__device__ __forceinline__ void stage_rows(double* stage, const double* p, int b0, int rows, int tid) {
-  for (int e = tid; e < rows * kRed; e += 64) stage[e] = p[(size_t)b0 * kRed + e];
-}
-// prestaged: rows [0, prestaged) are already in `stage` (the caller fetched them together with its other start-up loads)
-__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid, double* stage = nullptr,
-                                                 int prestaged = 0) {
+// the probes' reduction (k_probe_reduce): the block partials of k_linearize summed in block order, one thread per sum
+__device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, int pair, int nblk, double* lds, int tid) {
   const double* p = w.blkpart + (size_t)pair * w.nblk_max * kRed;
-  if (stage) {
-    double v = 0.0;
-    for (int b0 = 0; b0 < nblk; b0 += kGatherRows) {
-      const int rows = min(kGatherRows, nblk - b0);
-      if (b0 > 0 || prestaged < rows) {
-        __syncthreads();
-        stage_rows(stage, p, b0, rows, tid);
-      }
-      __syncthreads();
-      if (tid < 29)
-        for (int b = 0; b < rows; b++) v += stage[b * kRed + tid];
-    }
-    if (tid < 29) lds[tid] = v;
-  } else if (tid < 29) {
+  if (tid < 29) {
     double v = 0.0;
     for (int b = 0; b < nblk; b++) v += p[(size_t)b * kRed + tid];
     lds[tid] = v;
@@ -2504,15 +2280,6 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
   if (tid == 0) fill_from_sums(s, lds);
 }
 
-__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c);
-// after k_linearize: L:107-123 (GN) or L:127-144 (LM, up to the first compute_error).  Called by a whole
-// block (>= 64 threads, uniformly); lds: >= 32 doubles.
-__device__ __forceinline__ void lm_solve_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c, double* lds, int tid,
-                                              double* stage, int prestaged) {
-  gather_linearize(s, w, pair, nblk, lds, tid, stage, prestaged);
-  if (tid != 0) return;
-  lm_after_gather(s, c);
-}
 // one lane: the optimiser step once H, b and the cost are in the state
 __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
   s.n_lin += 1;
@@ -2540,11 +2307,6 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
 }
 
 // after k_error: L:145-172 (one lane)
-__device__ __forceinline__ void lm_decide_body(PairState& s, const Work& w, int pair, int nblk, const Consts& c) {
-  double yi = 0.0;
-  for (int b = 0; b < nblk; b++) yi += w.errpart[(size_t)pair * w.nblk_max + b];
-  lm_decide_after_sum(s, yi, c);
-}
 __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c) {
   s.yi = yi;
   s.n_err += 1;
@@ -2571,43 +2333,6 @@ __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, con
   s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
   for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
   step_done(s, c, true);
-}
-
-// The two steps as stand-alone kernels, one 64-lane block per pair.  The 1 KB PairState is staged in LDS
-// (one coalesced round trip in, one out) so that the serial bookkeeping of lane 0 never waits on global memory.
-static_assert(sizeof(PairState) % 8 == 0, "PairState is copied as doubles");
-__device__ __forceinline__ void state_copy(double* dst, const double* src, int tid) {
-  for (int q = tid; q < (int)(sizeof(PairState) / 8); q += 64) dst[q] = src[q];
-}
-
-__global__ __launch_bounds__(64) void k_lm_solve(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
-  __shared__ double lds[32];
-  __shared__ PairState ls;
-  __shared__ double stage[kGatherRows * kRed];
-  const int pair = pair_of(w, blockIdx.x), tid = threadIdx.x;
-  // every start-up load is issued before the first wait: status, N, the state and the first rows of partials
-  const int status = st[pair].status;
-  const int N = pairs[pair].s.n;
-  const int pre = min(kGatherRows, w.nblk_max);
-  state_copy((double*)&ls, (const double*)&st[pair], tid);
-  stage_rows(stage, w.blkpart + (size_t)pair * w.nblk_max * kRed, 0, pre, tid);
-  if (status != ST_NEED_LIN) return;
-  __syncthreads();
-  lm_solve_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c, lds, tid, stage, pre);
-  __syncthreads();
-  state_copy((double*)&st[pair], (const double*)&ls, tid);
-}
-
-__global__ __launch_bounds__(64) void k_lm_decide(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts c) {
-  __shared__ PairState ls;
-  const int pair = pair_of(w, blockIdx.x), tid = threadIdx.x;
-  if (st[pair].status != ST_NEED_ERR) return;
-  const int N = pairs[pair].s.n;
-  state_copy((double*)&ls, (const double*)&st[pair], tid);
-  __syncthreads();
-  if (tid == 0) lm_decide_body(ls, w, pair, (N + LIN_BLK - 1) / LIN_BLK, c);
-  __syncthreads();
-  state_copy((double*)&st[pair], (const double*)&ls, tid);
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false

@@ -173,13 +173,14 @@ __global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_lds(const SortJob* jobs
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_sort_cloud_reg<E>: the same job for 1024*E/2 < n <= 1024*E points (E = 4, 8, 16) with the keys in REGISTERS:
+// The register sort network of k_sort_tiles<E> (below; its one-block-per-cloud predecessor k_sort_cloud_reg<E> measured 58 us for
+// 8192 keys against the tiled 29 us and is in the history of round 2): 1024*E keys per block with the keys in REGISTERS:
 // thread t owns the E keys of positions t*E .. t*E+E-1.  A bitonic stage with stride j
 //   j < E          is a compare-exchange between two registers of the same thread,
 //   E <= j < 64*E  exchanges with lane (lane ^ j/E) of the same wave -- DPP for lane distances 1, 2, 4, 8 (pure VALU),
 //                  ds_bpermute for 16 and 32 -- no barrier,
 //   j >= 64*E      goes through LDS (slot e*1024 + t: conflict-free) with two barriers;
-// for 8192 keys that leaves 10 barrier stages out of 91 (k_sort_cloud_lds pays a barrier in every one of them).
+// for 8192 keys in one block that leaves 10 barrier stages out of 91 (k_sort_cloud_lds pays a barrier in every one of them).
 // Every stride is a compile-time constant (fully unrolled stage loops): key[] is only ever indexed statically and the
 // DPP controls are immediates.  118 us (LDS version) -> 58 us for 8192 keys, bound by the one CU a block runs on.
 // The sort is a total order of unique keys, so the permutation is the one k_sort_cloud_lds produces.
@@ -204,120 +205,6 @@ __device__ __forceinline__ unsigned lane_xor_u32(unsigned v, int m, int lane) {
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m, int lane) {
   const unsigned lo = lane_xor_u32((unsigned)v, m, lane), hi = lane_xor_u32((unsigned)(v >> 32), m, lane);
   return ((unsigned long long)hi << 32) | lo;
-}
-
-template <int E>
-__global__ __launch_bounds__(SORT_BLK) void k_sort_cloud_reg(const SortJob* jobs) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long xch[];  // [E][1024]
-  __shared__ float red[SORT_BLK / 64];
-  const SortJob job = jobs[blockIdx.x];
-  const int n = job.n, tid = threadIdx.x;
-  constexpr int NP = SORT_BLK * E;
-  const float inf = __builtin_inff();
-  // bounding box (the loads are kept: position i = tid*E + e is this thread's point e)
-  float4 p[E];
-  float lx = inf, ly = inf, lz = inf, hx = -inf, hy = -inf, hz = -inf;
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int i = tid * E + e;
-    if (i < n) {
-      p[e] = job.pts[i];
-      lx = fminf(lx, p[e].x), ly = fminf(ly, p[e].y), lz = fminf(lz, p[e].z);
-      hx = fmaxf(hx, p[e].x), hy = fmaxf(hy, p[e].y), hz = fmaxf(hz, p[e].z);
-    }
-  }
-  lx = block_reduce_minmax(lx, false, red, tid, SORT_BLK);
-  ly = block_reduce_minmax(ly, false, red, tid, SORT_BLK);
-  lz = block_reduce_minmax(lz, false, red, tid, SORT_BLK);
-  hx = block_reduce_minmax(hx, true, red, tid, SORT_BLK);
-  hy = block_reduce_minmax(hy, true, red, tid, SORT_BLK);
-  hz = block_reduce_minmax(hz, true, red, tid, SORT_BLK);
-  const float ext = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-30f));
-  const float scale = 1023.f / ext;
-  unsigned long long key[E];
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int i = tid * E + e;
-    key[e] = i < n ? ((unsigned long long)morton30(p[e].x, p[e].y, p[e].z, lx, ly, lz, scale) << 32) | (unsigned)i : ~0ull;
-  }
-#pragma unroll
-  for (int k = 2; k <= NP; k <<= 1) {
-    for (int j = k >> 1; j >= 64 * E; j >>= 1) {  // partner in another wave: through LDS
-      const int pt = tid ^ (j / E);
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < E; e++) xch[e * SORT_BLK + tid] = key[e];
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < E; e++) {
-        const int i = tid * E + e;
-        const unsigned long long o = xch[e * SORT_BLK + pt];
-        const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-        key[e] = ((o < key[e]) == take_min) ? o : key[e];
-      }
-    }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {  // partner lane (lane ^ m) of the same wave; compile-time m: DPP where it exists
-      const int j = m * E;
-      if (j < k) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          const int i = tid * E + e;
-          const unsigned long long o = shfl_xor_u64(key[e], m, tid & 63);
-          const bool take_min = ((i & j) == 0) == ((i & k) == 0);
-          key[e] = ((o < key[e]) == take_min) ? o : key[e];
-        }
-      }
-    }
-#pragma unroll
-    for (int j = E / 2; j > 0; j >>= 1) {  // strides below E: both keys in this thread, compile-time register indices
-      if (j < k) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          if ((e & j) == 0) {
-            const int i = tid * E + e;
-            const bool up = (i & k) == 0;
-            const unsigned long long a = key[e], b = key[e | j];
-            if ((a > b) == up) key[e] = b, key[e | j] = a;
-          }
-        }
-      }
-    }
-  }
-  // sorted position s = tid*E + e holds original index (unsigned)key[e]
-  Box bx{inf, inf, inf, -inf, -inf, -inf};  // of this thread's E sorted points
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int s = tid * E + e;
-    if (s < n) {
-      const int o = (int)(unsigned)key[e];
-      float4 q = job.pts[o];
-      q.w = __int_as_float(o);
-      job.perm[s] = o;
-      job.spts[s] = q;
-      bx.lx = fminf(bx.lx, q.x), bx.ly = fminf(bx.ly, q.y), bx.lz = fminf(bx.lz, q.z);
-      bx.hx = fmaxf(bx.hx, q.x), bx.hy = fmaxf(bx.hy, q.y), bx.hz = fmaxf(bx.hz, q.z);
-    }
-  }
-  auto widen = [&](int m) {  // union with the box of lane ^ m
-    bx.lx = fminf(bx.lx, __shfl_xor(bx.lx, m, 64)), bx.ly = fminf(bx.ly, __shfl_xor(bx.ly, m, 64)), bx.lz = fminf(bx.lz, __shfl_xor(bx.lz, m, 64));
-    bx.hx = fmaxf(bx.hx, __shfl_xor(bx.hx, m, 64)), bx.hy = fmaxf(bx.hy, __shfl_xor(bx.hy, m, 64)), bx.hz = fmaxf(bx.hz, __shfl_xor(bx.hz, m, 64));
-  };
-  constexpr int TPC = 16 / E > 0 ? 16 / E : 1;  // threads per 16-point chunk
-  static_assert(E <= 16 && kGroupPts / E <= 64, "a chunk and a group stay inside one wave");
-#pragma unroll
-  for (int m = 1; m < TPC; m <<= 1) widen(m);
-  if (tid % TPC == 0) {
-    const int c = tid * E / 16;
-    if (c * 16 < n) job.cbox[c] = bx;
-  }
-  constexpr int TPG = kGroupPts / E;  // threads per 128-point group
-#pragma unroll
-  for (int m = TPC; m < TPG; m <<= 1) widen(m);
-  if (tid % TPG == 0) {
-    const int g = tid * E / kGroupPts;
-    if (g * kGroupPts < n) job.gbox[g] = bx;
-  }
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -562,7 +562,8 @@ def test_two_batches_in_flight(reg, scene, optimizer):
                 dev = b.align_collect(tickets[s - 1], device=True)  # collecting twice is allowed; device form
                 assert dev.cpu().numpy().tobytes() == want[s - 1].tobytes()
     assert b.align_collect(tickets[-1]).tobytes() == want[-1].tobytes()
-    if optimizer == "gn":     # two record buffers: the ticket is void after the second enqueue behind its own
+    pooled = optimizer == "lm" and os.environ.get("APDGICP_LM_POOL", "1") != "0" and os.environ.get("APDGICP_NN_MODE") != "brute"  # (tools/knob_matrix.sh)
+    if not pooled:            # two record buffers: the ticket is void after the second enqueue behind its own
         with pytest.raises(Exception, match="ticket"):
             b.align_collect(tickets[0])
     else:                     # pooled LM batches: a lane per batch, eight of them
@@ -724,17 +725,12 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
         clouds += [s_, t_]
         pairs.append((2 * i, 2 * i + 1))
         guesses.append(g_)
-    envs = ({"APDGICP_NN_SKIN": "0"}, {}, {"APDGICP_NN_SKIN_REL": "0.5", "APDGICP_NN_SKIN_ABS": "0.05"},
-            {"APDGICP_NN_SKIN_REL": "0.0", "APDGICP_NN_SKIN_ABS": "0.0"}, {"APDGICP_NN_SKIN_REL": "0.02", "APDGICP_NN_SKIN_ABS": "0.001", "APDGICP_NN_W": "2"},
-            {"APDGICP_NN_W": "4"}, {"APDGICP_NN_MODE": "brute"},
+    envs = ({"APDGICP_NN_SKIN": "0"}, {}, {"APDGICP_NN_W": "2"}, {"APDGICP_NN_W": "4"}, {"APDGICP_NN_W": "8"}, {"APDGICP_NN_MODE": "brute"},
             # one pair group per handle = the throughput regime of bench.py: k_nn_compact (blocks of 256 points that pack the
-            # points still searching into fewer waves), and the same regime with one-wave blocks of k_nn_pruned
-            # (APDGICP_NN_W=1: six pairs are too few for the engine to choose that regime by itself)
-            # (in k_nn_compact a block with one wave's worth of points left searches them with all four waves: NN_COOP_TAIL)
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COOP_TAIL": "0"},
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"},
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"},
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN_REL": "0.3", "APDGICP_NN_SKIN_ABS": "0.03"}, {"APDGICP_NN_W": "1"})
+            # points still searching into fewer waves; a block with one wave's worth of points left searches them with all
+            # four waves) -- APDGICP_NN_W=1: six pairs are too few for the engine to choose that regime by itself -- and the
+            # same regime without keeping (one-wave blocks of k_nn_pruned)
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, {"APDGICP_NN_W": "1"})
     for kw in (gn, lm):
         want = None
         for env in envs:
@@ -751,17 +747,14 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
             assert got == want, (env, kw is gn)
             if env.get("APDGICP_NN_SKIN") == "0" or env.get("APDGICP_NN_MODE") == "brute":
                 assert st[6] == 0
-            elif kw is gn and "APDGICP_NN_SKIN_REL" not in env and not any(os.environ.get(v) for v in (   # (tools/knob_matrix.sh switches that turn keeping off)
-                    "APDGICP_NN_SKIN", "APDGICP_NN_SKIN_REL", "APDGICP_NN_GATE_CAP", "APDGICP_NN_MODE")):
+            elif kw is gn and not any(os.environ.get(v) for v in ("APDGICP_NN_SKIN", "APDGICP_NN_MODE")):   # (tools/knob_matrix.sh switches that turn keeping off)
                 assert st[6] > 0.3 * 18 * sum(len(clouds[2 * i]) for i in range(6)), st   # most points, most iterations
     # large targets (> 16384 points: the super-box level) through the one-group path: k_nn_compact's waves walk the batches of
     # group boxes on their own, without block barriers -- same records as the multi-wave k_nn_pruned blocks and as no keeping
     s_, t_, _, g_ = scene.make_pair(6000, 40_000, scene.pair_seed(21, 60), kind)
     s2, t2, _, g2 = scene.make_pair(20_000, 30_000, scene.pair_seed(21, 61), kind)
     want = None
-    for env, one_group in (({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_COOP_TAIL": "0"}, True),
-                           ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True),
-                           ({"APDGICP_NN_W": "1", "APDGICP_NN_COMPACT": "0"}, True)):
+    for env, one_group in (({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True)):
         b = _handle_with_env(reg, reg.BatchAPDGICP, env, **dict(gn, max_iterations=8))
         if one_group:
             b.set_pair_groups(1)
@@ -783,19 +776,19 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
         assert np.array_equal(x, y)
 
 
-def test_register_sort_equals_lds_sort(reg, scene):
-    """k_sort_cloud_reg<4|8|16> (keys in registers, shuffles, few barriers) must produce the permutation and the boxes of
-    k_sort_cloud_lds: everything downstream -- covariances, correspondences, fp32 distances -- is bitwise the same."""
-    import os
+def test_tiled_sort_from_host_and_device_clouds(reg, scene):
+    """The tiled register sort (k_sort_tiles / k_merge_tiles / k_boxes_sorted, 2048 < n <= 16384) reads a host cloud straight
+    from pinned memory with the bounding box reduced on the host, a device cloud from the pack kernel's output with the box
+    reduced on the device: both must give the permutation the brute-force kernels see -- everything downstream
+    (covariances, correspondences, fp32 distances, H, b) is bitwise the same, in all three tile classes and at their edges."""
+    import torch
     for n, m in ((2049, 4096), (4097, 8192), (8193, 12000), (16384, 9000)):
         src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(8, n), "odometry")
         out = []
-        # the tiled multi-block sort (default), one register-sorting block per cloud, one LDS-sorting block per cloud
-        # (the default also reads the host clouds straight from pinned memory, box reduced on the host: APDGICP_DIRECT_STAGE)
-        for env in ({}, {"APDGICP_DIRECT_STAGE": "0"}, {"APDGICP_SORT_TILED": "0"}, {"APDGICP_SORT_REG": "0"}):
+        for form, env in (("host", {}), ("device", {}), ("host", {"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute"})):
             g = _handle_with_env(reg, reg.FastAPDGICP, env, max_correspondence_distance=2.0)
-            g.setInputSource(src)
-            g.setInputTarget(tgt)
+            g.setInputSource(src if form == "host" else torch.from_numpy(src).cuda())
+            g.setInputTarget(tgt if form == "host" else torch.from_numpy(tgt).cuda())
             c, H, b = g.linearize(guess.astype(np.float64))
             corr, sqd = g.correspondences()
             out.append((g.getSourceCovariances(), g.getTargetCovariances(), corr, sqd, c, H, b))
@@ -983,7 +976,7 @@ def test_measurement_hooks(reg, scene):
     assert np.array_equal(np.asarray(res["T"]), np.asarray(ref["T"]))
     ms, launches, pair_iters = b.last_nn_profile()
     ticks, s_per_lane, splits = b.last_ticks()
-    default_shape = not any(os.environ.get(v) for v in ("APDGICP_NN_MODE", "APDGICP_NN_S", "APDGICP_NN_T"))  # tools/knob_matrix.sh
+    default_shape = not os.environ.get("APDGICP_NN_MODE")  # tools/knob_matrix.sh
     assert ticks == 10 and (not default_shape or (s_per_lane == 1 and splits == 1))
     assert launches >= 1 and 0.0 < ms / launches < 5.0          # a search launch takes tens of microseconds
     assert 1 <= pair_iters <= 8 * 10

@@ -11,7 +11,9 @@ import pytest
 
 import ref as R
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("APDGICP_LM_POOL", "1") == "0" or os.environ.get("APDGICP_NN_MODE") == "brute",
+                                 reason="tools/knob_matrix.sh row without the pair pool: these tests compare the pool WITH the host-polled loop")]
 
 LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
 T_TOL, R_TOL = 1e-3, 1e-4
@@ -24,18 +26,8 @@ def reg():
     return importlib.import_module("riv-slam_amd.registration")
 
 
-def host_polled(reg, params):
-    """a batch handle that runs LM through run_align's host-polled loop (the round-2 path): the cross-check"""
-    os.environ["APDGICP_LM_POOL"] = "0"
-    try:
-        b = reg.BatchAPDGICP(params)
-        b._polled = True
-        return b
-    finally:
-        os.environ.pop("APDGICP_LM_POOL", None)
-
-
 def polled_align(b, pairs, guesses):
+    """the same batch through run_align's host-polled loop (the round-2 path, APDGICP_LM_POOL=0): the cross-check"""
     os.environ["APDGICP_LM_POOL"] = "0"
     try:
         return b.align(pairs, guesses).copy()
