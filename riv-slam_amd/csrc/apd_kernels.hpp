@@ -1530,7 +1530,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE,
   while (smask) {
     const int gb0 = (sb0 + __builtin_ctzll(smask)) * kSuperGroups;
     smask &= smask - 1;
-    const int nb = min(64, ngroups - gb0);
     if (gb0 > 0) {
       mybox = G(c.gbox)[min(gb0 + lane, ngroups - 1)];
       if (gb0 + lane >= ngroups) mybox = nobox;
@@ -1999,8 +1998,8 @@ __device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int 
 constexpr int LIN_BLK = 256;
 constexpr int kSerialRows = 32;  // up to this many block rows (8192 points) the last block adds them one after the other
 
-__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c);
-__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c);
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws);
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws);
 __device__ __forceinline__ void fill_from_sums(PairState& s, const double* v);
 
 // Cross-block traffic inside one launch (the rows of partial sums, read by the last block of a pair) goes through
@@ -2142,7 +2141,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
       if (tid == 0) {
         if (w.init) init_pair_state(ls, w.init + pair, cst.max_iterations);  // first tick: the state starts here
         fill_from_sums(ls, red);
-        lm_after_gather(ls, cst);
+        lm_after_gather(ls, cst, red_scratch);  // (the reduction scratch is free by now)
       }
       __syncthreads();
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
@@ -2195,7 +2194,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   }
   if (fuse) {  // the last block of the pair to arrive decides (L:145-172): no launch of its own
     __shared__ PairState ls;
-    __shared__ double s_yi;
+    __shared__ double s_yi, s_ws[48];
     const int nblk = (N + LIN_BLK - 1) / LIN_BLK;
     if (last_block_of_pair(w.ticket + w.npairs + pair, nblk, tid)) {
       const double* rows = w.errpart + (size_t)pair * w.nblk_max;
@@ -2216,7 +2215,7 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
       __syncthreads();
       if (tid == 0) {
-        lm_decide_after_sum(ls, s_yi, cst);
+        lm_decide_after_sum(ls, s_yi, cst, s_ws);
         if (w.post) post_result(*w.post, w.post_seq, ls);
       }
       __syncthreads();
@@ -2227,19 +2226,22 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
 
 // ----------------------------------------------------------------------------------------------
 // The Gauss-Newton / Levenberg-Marquardt bookkeeping (L:55-173) as a per-pair state machine.
-__device__ __forceinline__ void lm_trial(PairState& s) {  // L:137-144
-  double H[36], b[6], d[6];
+// s lives in LDS, ws is 48 doubles of LDS: H, b, the factor and the step stay there (see solve6_spd_ws)
+__device__ __forceinline__ void lm_trial(PairState& s, double* ws) {  // L:137-144
+  // phase by phase through LDS (the compiler barriers keep one phase's values from staying in registers through the next:
+  // the step runs in ONE lane of a kernel whose register budget belongs to the per-point pass)
+  solve6_spd_ws(s.H, s.lambda, s.b, s.d, ws);
+  asm volatile("" ::: "memory");
+  s.delta = make_delta(s.d);
+  asm volatile("" ::: "memory");
 #pragma unroll
-  for (int q = 0; q < 36; q++) H[q] = s.H[q];
+  for (int i = 0; i < 3; i++) {  // xi = delta * x0 (rigid_mul's operations, one row at a time)
+    const double a0 = s.delta.m[4 * i], a1 = s.delta.m[4 * i + 1], a2 = s.delta.m[4 * i + 2], a3 = s.delta.m[4 * i + 3];
 #pragma unroll
-  for (int q = 0; q < 6; q++) b[q] = s.b[q];
-  solve6_spd(H, s.lambda, b, d);
-#pragma unroll
-  for (int q = 0; q < 6; q++) s.d[q] = d[q];
-  const Rigid delta = make_delta(d);
-  const Rigid x0 = s.x0;
-  s.delta = delta;
-  s.xi = rigid_mul(delta, x0);
+    for (int j = 0; j < 3; j++) s.xi.m[4 * i + j] = a0 * s.x0.m[j] + a1 * s.x0.m[4 + j] + a2 * s.x0.m[8 + j];
+    s.xi.m[4 * i + 3] = a0 * s.x0.m[3] + a1 * s.x0.m[7] + a2 * s.x0.m[11] + a3;
+  }
+  asm volatile("" ::: "memory");
 }
 
 // after step_optimize returned `ok` (L:71-75): convergence test and loop bookkeeping
@@ -2281,11 +2283,11 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 }
 
 // one lane: the optimiser step once H, b and the cost are in the state
-__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws) {
   s.n_lin += 1;
   if (c.optimizer == 1) {  // step_gn
     s.lambda = 0.0;
-    lm_trial(s);
+    lm_trial(s, ws);
     s.x0 = s.xi;
     for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
     step_done(s, c, true);
@@ -2302,12 +2304,12 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c) {
     step_done(s, c, false);
     return;
   }
-  lm_trial(s);
+  lm_trial(s, ws);
   s.status = ST_NEED_ERR;
 }
 
 // after k_error: L:145-172 (one lane)
-__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c) {
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws) {
   s.yi = yi;
   s.n_err += 1;
   double den = 0.0;
@@ -2325,7 +2327,7 @@ __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, con
       step_done(s, c, false);
       return;
     }
-    lm_trial(s);  // next inner iteration, status stays ST_NEED_ERR
+    lm_trial(s, ws);  // next inner iteration, status stays ST_NEED_ERR
     return;
   }
   s.x0 = s.xi;  // L:166-169

@@ -274,4 +274,51 @@ APD_HD void solve6_spd(const double* H, double lambda, const double* b, double* 
   }
 }
 
+// The same elimination with its triangular factor, pivots and intermediate vector in caller-provided memory (48 doubles of
+// LDS in the last block of k_linearize / k_error, where ONE lane runs it): held in registers they were 48 doubles that the
+// per-point pass of the kernel around it had to spill to scratch for.  Same operations in the same order: the same bits.
+APD_HD void solve6_spd_ws(const double* H, double lambda, const double* b, double* x, double* ws) {
+  double* L = ws;        // [6][6], strictly lower part used
+  double* D = ws + 36;   // [6]
+  double* y = ws + 42;   // [6]
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = H[j + 6 * j] + lambda;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < j) dj -= L[6 * j + k] * L[6 * j + k] * D[k];
+    D[j] = dj;
+    const bool ok = fabs(dj) > 1e-300;
+    const double inv = ok ? 1.0 / dj : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i > j) {
+        double v = H[i + 6 * j];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (k < j) v -= L[6 * i + k] * L[6 * j + k] * D[k];
+        L[6 * i + j] = v * inv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double v = -b[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < i) v -= L[6 * i + k] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = fabs(D[i]) > 1e-300 ? y[i] / D[i] : 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k > i) v -= L[6 * k + i] * x[k];
+    x[i] = v;
+  }
+}
+
 }  // namespace apd
