@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0
 # measured plain (non-packed, non-fused) fp32 VALU issue ceiling of this chip: 62e12 lane-ops/s / 64 lanes
 # (tools/ubench_valu.hip, profiles/r01_ubench_valu.txt) -- the roof of the exact, FMA-free nearest-neighbour arithmetic
 VALU_WAVE_INSTR_PEAK = 62.0e12 / 64
+# the chip's theoretical VALU issue ceiling: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
+VALU_WAVE_INSTR_THEORETICAL = 1024 * 2.4e9 / 2
+LM_LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)   # the launch file's registration parameters (LM, L:17)
 
 
 def parse_args():
@@ -47,6 +50,9 @@ def parse_args():
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--points", type=int, default=N_PTS)
     ap.add_argument("--kind", default="odometry", choices=("odometry", "loop"), help="scene.make_pair kind of the synthetic pairs")
+    ap.add_argument("--optimizer", default="gn", choices=("gn", "lm"),
+                    help="gn: BASELINE configs[1] (20 Gauss-Newton iterations, no early exit); lm: the reference's optimiser with the launch parameters "
+                         "(with --kind loop: SURVEY 8d's C4 shard) on ONE pooled handle with --handles batches in flight")
     ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 4; 1: one handle with three pair groups)")
     ap.add_argument("--groups", type=int, default=1, help="pair groups (HIP streams) per handle when several handles are in flight")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
@@ -97,8 +103,10 @@ def percentiles(xs):
             "mean": round(float(a.mean()), 4), "min": round(float(a.min()), 4), "max": round(float(a.max()), 4)}
 
 
-def bench_params(reg):
+def bench_params(reg, optimizer="gn"):
     # configs[1]: GN, 20 iterations, never early-exit; gate / APD variances as shipped in the launch file
+    if optimizer == "lm":
+        return reg.default_params(**LM_LAUNCH)
     return reg.default_params(optimizer=reg.OPT_GN, max_iterations=GN_ITERS, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
                               max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
 
@@ -166,21 +174,27 @@ def main():
     pair_idx = [(2 * i, 2 * i + 1) for i in range(P)]
     torch.cuda.synchronize()
 
-    params = bench_params(reg)
+    lm = args.optimizer == "lm"
+    params = bench_params(reg, args.optimizer)
     # Consecutive steps are independent batches, so several of them are kept in flight: step s runs on batch handle s % H
     # (H = --handles, 4 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
     # underfed (32 pairs: three groups of latency-bound tick kernels); with several steps at different phases one handle's
     # covariance kernels fill the gaps of the others' ticks.  Every handle registers its own copy of the step's clouds.
-    H = args.handles if args.handles > 0 else 4   # r02 (lazy group streams: every handle's stream on a hardware queue of its own): 3 / 4 / 5 / 6 handles 1.00 / 0.92 / 0.99 / 0.99 ms per step; with a process group 1.00 / 0.96 / 1.14
+    # Levenberg-Marquardt (--optimizer lm): ONE handle; its pair pool merges the H batches in flight, each in its own range of
+    # cloud slots (include/apdgicp_hip.h), H = 8 by default.
+    H = args.handles if args.handles > 0 else (8 if lm else 4)   # r02 (lazy group streams: every handle's stream on a hardware queue of its own): 3 / 4 / 5 / 6 handles 1.00 / 0.92 / 0.99 / 0.99 ms per step; with a process group 1.00 / 0.96 / 1.14
     batches = []
-    for _ in range(H):
+    for _ in range(1 if lm else H):
         bh = reg.BatchAPDGICP(params, device=local_rank)
         bh.set_profiling(os.environ.get("APDGICP_BENCH_NOPROF", "0") != "1")
-        if H > 1:
+        if H > 1 and not lm:
             bh.set_pair_groups(max(1, args.groups))
         batches.append(bh)
     batch = batches[0]
-    pairs_arr = batch.make_pairs(pair_idx, guesses)
+    # slot s % H of the schedule: (handle, first cloud slot, pair table)
+    slots = [(batches[0], 2 * P * h, batch.make_pairs([(2 * P * h + a, 2 * P * h + b_) for a, b_ in pair_idx], guesses)) if lm else
+             (batches[h], 0, batch.make_pairs(pair_idx, guesses)) for h in range(H)]
+    pairs_arr = slots[0][2]
     clouds_arg = batch.pack_clouds(d_clouds)   # the pointer array a C caller would hold; the clouds themselves are re-registered every step
     hstreams = [torch.cuda.ExternalStream(bh.stream_ptr(), device=local_rank) for bh in batches]
 
@@ -195,25 +209,29 @@ def main():
     # A step = set this rank's 64 fresh clouds (packed, sorted, covariances recomputed) + register its 32 pairs + (N > 1)
     # all-gather the records.  enqueue returns without waiting (Gauss-Newton: the run length is known); a step is collected
     # -- waited for, gathered -- just before its handle is needed again, H steps later.
-    def enqueue_step(bh):
-        bh.set_clouds(0, clouds_arg)
-        return bh.align_enqueue(pairs_arr)
+    def enqueue_step(h):
+        bh, base, arr = slots[h]
+        bh.set_clouds(base, clouds_arg, producer_wait=False)   # (resident inputs, complete long ago: no wait on torch's stream, which carries the all-gathers)
+        return bh.align_enqueue(arr)
 
     # N > 1: the all-gather of a step reads that step's record buffer, which its handle overwrites two enqueues later (the
     # handle alternates between two buffers).  So the host does not wait for the collective where it issues it, but one round
     # later, when the same handle is collected again -- just in front of the enqueue that could reuse the buffer.  Waiting at
     # once made every rank wait for the slowest rank's same step, every step; this way ranks may drift by a few steps.
-    gather_done = {}   # handle -> event behind its last all-gather
+    gather_done = {}   # slot -> event behind its last all-gather
+    lat = []           # submit -> collect of every step of the timed region, seconds
 
-    def collect_step(bh, ticket):
-        ev = gather_done.get(id(bh))
+    def collect_step(h, ticket, t_submit):
+        bh = slots[h][0]
+        ev = gather_done.get(h)
         if ev is not None:
             ev.synchronize()
         local = bh.align_collect(ticket, device=True)        # zero-copy view of that step's records on the device
+        lat.append(time.perf_counter() - t_submit)
         out = aligner.gather(local, total_pairs, wait=False)
         if use_dist:
             if ev is None:
-                ev = gather_done[id(bh)] = torch.cuda.Event()
+                ev = gather_done[h] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
         ms, k, pr = bh.last_nn_profile()
         nn_acc[0] += ms
@@ -226,12 +244,13 @@ def main():
         for s in range(count):
             h = s % H
             if tickets[h] is not None:
-                out = collect_step(batches[h], tickets[h])
-            tickets[h] = enqueue_step(batches[h])
+                out = collect_step(h, *tickets[h])
+            t_sub = time.perf_counter()
+            tickets[h] = (enqueue_step(h), t_sub)
         for s in range(count, count + H):   # the steps still in flight, oldest first
             h = s % H
             if tickets[h] is not None:
-                out = collect_step(batches[h], tickets[h])
+                out = collect_step(h, *tickets[h])
                 tickets[h] = None
         for ev in gather_done.values():      # every collective of this run has read its records (and `out` is complete)
             ev.synchronize()
@@ -249,18 +268,19 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(R)]
     ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(H + 1)] for _ in range(R)]
     nn_acc[:] = [0.0, 0, 0]
+    lat.clear()
     gathered = None
     for r in range(R):
         sync_all()
         ev0[r].record(hstreams[0])           # the GPU is idle: this timestamp is the start of the region on the device clock
         t0 = time.perf_counter()
         gathered = run_steps(K)              # every step enqueued AND collected (and gathered) inside the timed region
-        for h in range(H):
+        for h in range(len(hstreams)):
             ev1[r][h].record(hstreams[h])    # behind the last batch of every handle ...
-        ev1[r][H].record(torch.cuda.current_stream())   # ... and behind the last gather
+        ev1[r][len(hstreams)].record(torch.cuda.current_stream())   # ... and behind the last gather
         sync_all()
         host_s.append(time.perf_counter() - t0)
-        event_ms.append(max(ev0[r].elapsed_time(e) for e in ev1[r]))
+        event_ms.append(max(ev0[r].elapsed_time(e) for e in ev1[r][:len(hstreams) + 1]))
     nn_ms, nn_launches, nn_pairs = nn_acc
     host_t = torch.tensor(host_s, dtype=torch.float64, device="cuda")
     if use_dist:
@@ -274,7 +294,7 @@ def main():
     out = None
     if rank == 0:
         recs = sharded.records_from_bytes(gathered)
-        assert len(recs) == total_pairs and int(recs["n_linearize"].min()) == GN_ITERS
+        assert len(recs) == total_pairs and (lm or int(recs["n_linearize"].min()) == GN_ITERS)
         nn_mode = os.environ.get("APDGICP_NN_MODE", "pruned")
         # ---- roofline of the dominant kernel, the nearest-neighbour search: ALGORITHMIC HBM bytes per launch = per pair
         # 16(N+M) (both sorted clouds) + 16N (warm-start hints) + 8N (result), SURVEY 8d / DESIGN 3, over the kernel's own
@@ -283,12 +303,16 @@ def main():
         pairs_per_launch = nn_pairs / max(1, nn_launches)
         nn_kernel = batch.last_nn_kernel()
         keeps = nn_kernel.startswith("k_nn_compact") or os.environ.get("APDGICP_NN_SKIN", "1") != "0"
-        # per pair and launch: both sorted clouds 16(N+M), warm-start hints 16N, (neighbour keeping) the points' records 16N, result 8N
-        bytes_per_pair = 16.0 * (n + n) + 16.0 * n + (16.0 * n if keeps and nn_mode != "brute" else 0.0) + 8.0 * n
+        # ALGORITHMIC bytes per pair and launch, SURVEY 8d: the search's share of B_lin = both sorted clouds 16(N+M) + the result 8N
+        # = 40N for N = M; a whole tick (search + linearize) B_lin = 124N.  What the implementation moves on top of that -- the
+        # warm-start hints (16N) and the neighbour-keeping records (16N) -- is traffic, not algorithm: it shows in `traffic`.
+        bytes_per_pair = 16.0 * (n + n) + 8.0 * n
         bytes_per_launch = bytes_per_pair * pairs_per_launch
         nn_gbs = bytes_per_launch / (avg_nn_ms * 1e-3) / 1e9 if avg_nn_ms > 0 else 0.0
-        # whole-registration algorithmic bytes, SURVEY 8d: B_reg = 40(N+M) + L(108N + 16M)
-        b_reg = 40.0 * (2 * n) + GN_ITERS * (108.0 * n + 16.0 * n)
+        # whole-registration algorithmic bytes, SURVEY 8d: B_reg = 40(N+M) + L(108N + 16M) (+ 56N per compute_error, LM)
+        n_lin = float(recs["n_linearize"].mean())
+        n_err = float(recs["n_compute_error"].mean())
+        b_reg = 40.0 * (2 * n) + n_lin * (108.0 * n + 16.0 * n) + n_err * 56.0 * n
         hbm_gbs = b_reg * P / (ms_per_step * 1e-3) / 1e9
         pmc, traffic, issue = None, None, None
         try:
@@ -298,13 +322,14 @@ def main():
         # PMC numbers come from a separate committed profiling run (rocprofv3 --pmc passes cannot run inside this process):
         # reported only when that run had this launch shape, and tagged with where they come from
         step_issue = None
-        if pmc and pmc.get("points") == n and pmc.get("pairs_per_launch") == round(pairs_per_launch) and pmc.get("nn_mode", "pruned") == nn_mode \
+        if not lm and pmc and pmc.get("points") == n and pmc.get("pairs_per_launch") == round(pairs_per_launch) and pmc.get("nn_mode", "pruned") == nn_mode \
                 and pmc.get("kind", "odometry") == args.kind and pmc.get("kernel", "").replace(" ", "") == nn_kernel.replace(" ", ""):
             traffic = pmc.get("hbm_bytes_per_launch")
             if pmc.get("SQ_INSTS_VALU"):
                 valu_rate = pmc["SQ_INSTS_VALU"] / (avg_nn_ms * 1e-3)
                 issue = {"bound": "valu-issue", "achieved": round(valu_rate / 1e9, 2), "peak": round(VALU_WAVE_INSTR_PEAK / 1e9, 2),
                          "unit": "G wave-instructions/s", "frac": round(valu_rate / VALU_WAVE_INSTR_PEAK, 4),
+                         "peak_theoretical": round(VALU_WAVE_INSTR_THEORETICAL / 1e9, 1), "frac_of_theoretical": round(valu_rate / VALU_WAVE_INSTR_THEORETICAL, 4),
                          "valu_instructions_per_launch": pmc["SQ_INSTS_VALU"], "source": pmc.get("source", "profiles/pmc_nn_latest.json"),
                          "note": "VALU wave-instructions per launch (PMC, committed profile of the same launch shape) / this run's launch "
                                  "time, against the measured plain-fp32 issue ceiling (62 Tlane-op/s / 64)"}
@@ -318,45 +343,60 @@ def main():
                 rate = per_step / (ms_per_step * 1e-3)
                 step_issue = {"bound": "valu-issue", "achieved": round(rate / 1e9, 1), "peak": round(VALU_WAVE_INSTR_PEAK / 1e9, 2),
                               "unit": "G wave-instructions/s", "frac": round(rate / VALU_WAVE_INSTR_PEAK, 4),
+                              "peak_theoretical": round(VALU_WAVE_INSTR_THEORETICAL / 1e9, 1), "frac_of_theoretical": round(rate / VALU_WAVE_INSTR_THEORETICAL, 4),
                               "valu_instructions_per_step": per_step, "source": pmc.get("source"),
                               "note": "sum over the step's batch kernels (search and linearize x 20 ticks, covariances, sort, pack) of their PMC "
                                       "VALU instruction counts / ms_per_step"}
         out = {
-            "metric": "APD-GICP registrations/s (8k-pt scan pairs, GN-20, covariances recomputed)",
+            "metric": ("APD-GICP registrations/s (8k-pt scan pairs, GN-20, covariances recomputed)" if not lm else
+                       "APD-GICP registrations/s (8k-pt pairs, Levenberg-Marquardt with the launch parameters, covariances recomputed)"),
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 nearest-neighbour search + f64 covariance/Mahalanobis/Hessian", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] (8k x 8k scan pair, 20 GN iterations) x {P} independent pairs per GPU per step "
-                                   f"(= per-GPU shard of configs[3]); pair kind '{args.kind}'", "points": n, "pairs_per_gpu": P,
-                       "gn_iterations": GN_ITERS, "kind": args.kind, "nn_mode": nn_mode, "nn_sources_per_lane": nn_S, "nn_target_splits": nn_T,
-                       "ticks": ticks, "steps_in_flight": H, "batch_handles": H},
+            "config": {"workload": (f"BASELINE configs[1] (8k x 8k scan pair, 20 GN iterations) x {P} independent pairs per GPU per step "
+                                    f"(= per-GPU shard of configs[3]); pair kind '{args.kind}'" if not lm else
+                                    f"BASELINE configs[3], per-GPU shard as SURVEY 8d specifies it: {P} pairs per GPU per step, kind '{args.kind}'"
+                                    f"{' from the identity (loop_detector.cpp:225)' if args.kind == 'loop' else ''}, LM with the launch parameters"),
+                       "points": n, "pairs_per_gpu": P, "optimizer": args.optimizer,
+                       "gn_iterations": GN_ITERS if not lm else None,
+                       "linearizations_per_pair": {"mean": round(n_lin, 2), "min": int(recs["n_linearize"].min()), "max": int(recs["n_linearize"].max())},
+                       "kind": args.kind, "nn_mode": nn_mode, "nn_sources_per_lane": nn_S, "nn_target_splits": nn_T,
+                       "ticks": ticks, "steps_in_flight": H, "batch_handles": len(batches)},
             "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": rccl_version,
             "timing": {"repeats": R, "steps_per_repeat": K, "statistic": "median over repeats (each: K steps, barrier + sync both sides, max over ranks)",
                        "host_ms_per_step": percentiles([t / K * 1e3 for t in host_s]),
                        "event_ms_per_step": percentiles([t / K for t in event_ms]),
                        "first_repeat_ms_per_step": round(host_s[0] / K * 1e3, 4),
+                       "step_latency_ms": percentiles([t * 1e3 for t in lat]),
+                       "step_latency_note": f"submit -> collect of one step (host clock): {H} steps are in flight, so a step's kernels may take up to "
+                                            "this long although a step LEAVES every ms_per_step",
                        "registrations_per_s": {"p10": round(total_pairs * K / float(np.percentile(host_s, 90)), 1),
                                                "p90": round(total_pairs * K / float(np.percentile(host_s, 10)), 1)}},
-            "ms_per_gn_iter_batched": round(ms_per_step / GN_ITERS, 4),
+            "ms_per_gn_iter_batched": round(ms_per_step / GN_ITERS, 4) if not lm else None,
             "roofline": {"kernel": nn_kernel + (" (exact fp32 nearest neighbour: Hilbert-sorted clouds, bounding-box pruning, LDS-staged target "
                                                 "groups, neighbours kept while provably unchanged)" if nn_mode != "brute" else
                                                 " (brute-force fp32 nearest neighbour, LDS-tiled)"),
                          "bound": "hbm", "achieved": round(nn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "binding_roof": "instruction issue (vector + scalar), not HBM: see roofline_issue; the HBM fraction is the north star's extra",
+                         "kernel_ms_per_step": round(avg_nn_ms * (ticks if not lm else n_lin), 4),
+                         "kernel_time_check": "kernel_ms_per_step (average launch x launches per step) <= timing.step_latency_ms: the launches of one step overlap with "
+                                              "those of the other steps in flight, so it may exceed ms_per_step",
                          "traffic_source": (pmc.get("source", "profiles/pmc_nn_latest.json") if traffic else None),
                          "avg_launch_ms": round(avg_nn_ms, 5), "launches_timed": nn_launches, "pairs_per_launch": round(pairs_per_launch, 2),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "achieved = algorithmic bytes per launch (16(N+M) + 16N + 16N + 8N per pair) / the kernel's average duration in "
+                         "note": "achieved = SURVEY 8d's algorithmic bytes per launch (16(N+M) + 8N = 40N per pair) / the kernel's average duration in "
                                  "the timed region (HIP events on the launching stream).  The working set is MALL/L2 resident and the kernel "
-                                 "is issue/latency bound, so the HBM fraction is small by construction; roofline_issue is the roof that binds"},
+                                 "is issue/latency bound, so the HBM fraction is small by construction; roofline_issue is the roof that binds.  "
+                                 "`traffic` (PMC, committed profile) also carries the warm-start hints and neighbour-keeping records: 2.2 x the algorithmic bytes"},
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,
-                                  "note": "whole step: B_reg x pairs / ms_per_step"},
+                                  "note": "whole step: B_reg x pairs / ms_per_step; B_reg = 40(N+M) + L(108N+16M) + E 56N with the run's mean L, E"},
         }
 
-        if world == 1 and not args.no_diagnostics:
+        if world == 1 and not args.no_diagnostics and not lm:
             # ---- outside the timed region: what the pruned kernel really executes, and the brute-force kernel on the same data
             def one_step(env):
                 old = {k_: os.environ.get(k_) for k_ in env}
@@ -392,7 +432,7 @@ def main():
                                   "note": "the pruned search returns the brute-force result bit for bit; bruteforce_equivalent is NOT a hardware "
                                           "rate (it counts pairs that were proven irrelevant, not evaluated)"}
                 del bs
-            bf = one_step({"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute", "APDGICP_STREAMS": "1", "APDGICP_PROFILE_STRIDE": "1"})
+            bf = one_step({"APDGICP_NN_MODE": "brute", "APDGICP_KNN_MODE": "brute", "APDGICP_PROFILE_STRIDE": "1"})
             ms_b, k_b, pr_b = bf.last_nn_profile()
             tf_b = 8.0 * n * n * pr_b / max(1e-9, ms_b * 1e-3) / 1e12
             _, sb, tb = bf.last_ticks()
@@ -424,18 +464,67 @@ def main():
             # cached (pointer-equality tokens), i.e. 20 x (search + Mahalanobis + H/b + step) on device-resident data
             cached = timed(lambda: (one.setInputSource(ds, token=11), one.setInputTarget(dt, token=12), one.align(g)))
             out["single_pair"] = {"ms_per_registration": percentiles(single), "registrations_per_s": round(1e3 / float(np.median(single)), 1),
-                                  "ms_per_gn_iteration": round(float(np.median(cached)) / GN_ITERS, 4)}
+                                  "ms_per_gn_iteration": round(float(np.median(cached)) / GN_ITERS, 4) if not lm else None}
+
+            if not lm and not args.no_diagnostics:
+                # ---- second object: SURVEY 8d's C4 shard -- 32 loop-closure candidates at 8192 points, aligned
+                # from the identity (loop_detector.cpp:225) by Levenberg-Marquardt with the launch parameters, both clouds fresh every
+                # batch -- on ONE handle and ONE host thread, 8 batches in flight in the handle's pair pool
+                F4, P4 = 8, 32
+                lm_clouds, lm_host = [], []
+                for p_ in range(P4):
+                    s_, t_, _, _ = scene.make_pair(n, n, scene.pair_seed(4, p_), "loop")
+                    lm_host.append((s_, t_))
+                    lm_clouds += [torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()]
+                torch.cuda.synchronize()
+                bl = reg.BatchAPDGICP(reg.default_params(**LM_LAUNCH), device=local_rank)
+                lm_packed = bl.pack_clouds(lm_clouds)
+                eye = [np.eye(4, dtype=np.float32)] * P4
+                lm_pairs = [bl.make_pairs([(2 * P4 * f + 2 * i, 2 * P4 * f + 2 * i + 1) for i in range(P4)], eye) for f in range(F4)]
+
+                def lm_steps(count):
+                    tk, res_ = [None] * F4, None
+                    for s_i in range(count):
+                        f = s_i % F4
+                        if tk[f] is not None:
+                            res_ = bl.align_collect(tk[f])
+                        bl.set_clouds(2 * P4 * f, lm_packed, producer_wait=False)
+                        tk[f] = bl.align_enqueue(lm_pairs[f])
+                    for s_i in range(count, count + F4):
+                        if tk[s_i % F4] is not None:
+                            res_ = bl.align_collect(tk[s_i % F4])
+                            tk[s_i % F4] = None
+                    return res_
+                lm_steps(2 * F4)
+                lm_ms = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    lm_recs = lm_steps(40)
+                    bl.synchronize()
+                    lm_ms.append((time.perf_counter() - t1) / 40 * 1e3)
+                lm_med = float(np.median(lm_ms))
+                its = [int(x) for x in lm_recs["n_linearize"]]
+                out["lm_loop_batch"] = {"metric": "ms per batch of 32 loop-closure registrations (8k x 8k, identity guess, LM with the launch parameters, covariances recomputed)",
+                                        "value": round(lm_med, 4), "unit": "ms per batch", "higher_is_better": False,
+                                        "registrations_per_s": round(P4 * 1e3 / lm_med, 1), "ms_per_batch": percentiles(lm_ms),
+                                        "handles": 1, "host_threads": 1, "batches_in_flight": F4,
+                                        "linearizations_per_pair": {"min": min(its), "median": float(np.median(its)), "max": max(its), "sum": sum(its)},
+                                        "compute_error_evaluations": int(lm_recs["n_compute_error"].sum()), "converged": int(lm_recs["converged"].sum()),
+                                        "note": "pooled Levenberg-Marquardt batches (include/apdgicp_hip.h): every tick is one launch over the pairs of all batches "
+                                                "in flight that still run; round 2's host-polled loop: 5.2 ms per batch on one handle"}
+                del bl
 
             if not args.no_cpu_baseline:
                 # ---- CPU baseline: the oracle's OpenMP restatement ("port") on the same pairs, bounded sample, thread sweep.
                 # Same work per registration as the GPU step: both clouds set fresh (kd-trees and covariances rebuilt), GN-20.
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))
                 import ref as R_
-                kw = dict(optimizer=1, max_iterations=GN_ITERS, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
-                          max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+                kw = (dict(optimizer=1, max_iterations=GN_ITERS, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
+                           max_correspondence_distance=2.0, azimuth_variance_deg=1.0) if not lm else dict(LM_LAUNCH))
                 ncores = os.cpu_count() or 1
                 sweep_threads = sorted({c for c in (8, 16, 32, 64, ncores) if c <= ncores})
-                share = args.cpu_seconds / (len(sweep_threads) + 2)
+                share = args.cpu_seconds / (len(sweep_threads) + 3)
                 worst_t, worst_r, checked, cursor = 0.0, 0.0, 0, 0
                 sweep = {}
 
@@ -461,10 +550,15 @@ def main():
                     rate, done, used = run_cfg(th, share)
                     sweep[str(used)] = {"registrations_per_s": round(rate, 3), "pairs": done}
                 best_threads = max(sweep, key=lambda k_: sweep[k_]["registrations_per_s"])
-                rate, done, used = run_cfg(int(best_threads), 2 * share)
+                reps_cpu = [run_cfg(int(best_threads), share) for _ in range(3)]     # three repeats at the best thread count: median + spread
+                rates = sorted(r_[0] for r_ in reps_cpu)
+                rate, done, used = rates[1], sum(r_[1] for r_ in reps_cpu), reps_cpu[0][2]
                 out["cpu_baseline"] = {"value": round(rate, 3), "unit": "registrations/s", "cores": used, "kind": "port",
-                                       "sample": f"{done} of the {P} timed pairs at the best thread count of the sweep (same clouds, both clouds set "
-                                                 f"fresh, GN-20; kd-tree + OpenMP restatement of the reference, not the reference binary)",
+                                       "repeats": {"n": 3, "statistic": "median", "min": round(rates[0], 3), "max": round(rates[2], 3),
+                                                   "spread_rel": round((rates[2] - rates[0]) / rates[1], 3)},
+                                       "sample": f"{done} registrations of the {P} timed pairs in three repeats at the best thread count of the sweep (same clouds, "
+                                                 f"both clouds set fresh, {'GN-20' if not lm else 'LM with the launch parameters'}; kd-tree + OpenMP restatement "
+                                                 f"of the reference, not the reference binary)",
                                        "thread_sweep": sweep, "all_cores": {"cores": ncores, **sweep.get(str(ncores), {})},
                                        "openmp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_WAIT_POLICY": os.environ.get("OMP_WAIT_POLICY"),
                                                   "schedule": "guided,8"}}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define APDGICP_ABI_VERSION 2   /* 2: + inlier_fraction, wait_producer, get_stream */
+#define APDGICP_ABI_VERSION 3   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots */
 
 typedef enum {
   APDGICP_OK = 0,
@@ -40,7 +40,7 @@ typedef enum {
   APDGICP_ERR_HIP = -2,           /* a HIP runtime call failed (no device, OOM, launch failure) */
   APDGICP_ERR_NO_INPUT = -3,      /* source/target (or correspondences) not set yet */
   APDGICP_ERR_TOO_FEW_POINTS = -4,/* cloud has fewer than k_correspondences points (reference: UB, A:318-321) */
-  APDGICP_ERR_UNSUPPORTED = -5,   /* e.g. k_correspondences > 32, unknown regularization (reference aborts, A:341-343) */
+  APDGICP_ERR_UNSUPPORTED = -5,   /* e.g. k_correspondences > 64, unknown regularization (reference aborts, A:341-343) */
   APDGICP_ERR_INTERNAL = -6
 } apdgicp_status;
 
@@ -65,7 +65,7 @@ typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
  * defaults: A:14-28, H:107-109, L:11-24.  The ROS factory overrides some of them
  * (registrations.cpp:41-48). */
 typedef struct {
-  int32_t k_correspondences;            /* setCorrespondenceRandomness, A:45 ; default 20 ; 3..32 */
+  int32_t k_correspondences;            /* setCorrespondenceRandomness, A:45 ; default 20 ; 1..64 (33..64: exact, through the brute-force covariance kernel) */
   int32_t max_iterations;               /* pcl setMaximumIterations ; default 64, L:13 */
   int32_t lm_max_iterations;            /* L:19 ; default 10 */
   int32_t optimizer;                    /* apdgicp_optimizer ; default LM */
@@ -193,8 +193,8 @@ int apdgicp_batch_set_params(apdgicp_batch* b, const apdgicp_params* p);
 int apdgicp_batch_clear(apdgicp_batch* b);
 /* returns the cloud's index (>= 0) or a negative status */
 int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
-/* replaces cloud `index` (0 <= index <= number of clouds; == appends) in place, reusing its device
- * buffers; its covariances are recomputed by the next align */
+/* sets cloud slot `index` (>= 0; slots need not be contiguous: a caller that keeps several batches in flight gives each its own
+ * range), reusing the slot's device buffers; its covariances are recomputed by the next align */
 int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
 /* sets clouds first_index .. first_index+count-1 in one call (one pack launch when on_device):
  * xyz[i] / n[i] describe cloud first_index+i, all with the same stride */
@@ -228,6 +228,11 @@ int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream);              /* s
  *   error flag, every batch in flight at that moment fails at its collect; the handle stays usable.
  *   APDGICP_LM_POOL=0 in the environment selects the round-2 host-polled loop instead (the cross-check of tests/test_lm_pool.py). */
 int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int64_t n_pairs, uint64_t* ticket);
+/* Serves the Levenberg-Marquardt pair pool without waiting: reads the polls that have arrived and keeps the chunks of ticks
+ * enqueued ahead.  Every call of the handle does this anyway; a caller that goes away for more than a few hundred microseconds
+ * between calls while batches are in flight (a worker thread waiting for its next job) calls this in between so that the GPU
+ * does not run out of enqueued ticks.  No-op for Gauss-Newton handles and when nothing is in flight. */
+int apdgicp_batch_pump(apdgicp_batch* b);
 /* A batch runs as up to three pair groups on three HIP streams (about 8 pairs per group), which is the best a single handle
  * can do.  A caller that keeps several HANDLES busy at once -- batch s on handle s % 3, each enqueued before the previous
  * ones are collected -- does better with one group (= one stream, larger launches) per handle: one handle's covariance

@@ -407,6 +407,24 @@ void load_T(const double Tcm[16], M4& T) {
     for (int j = 0; j < 4; j++) T.m[i][j] = Tcm[i + 4 * j];
 }
 
+// A:149: `pt = trans.cast<float>() * input_->at(i).getVector4fMap()` -- an Isometry3f times a Vector4f whose 4th coefficient is 1.
+// Which fp32 operation order Eigen 3.3 emits for this 4x4 * 4x1 product cannot be read off here (no Eigen in the image): order 0,
+// ((r0 x + r1 y) + r2 z) + t, is its coefficient-based lazy product and what the GPU kernels evaluate.  The other orders exist
+// ONLY for tests/measure/transform_order_sensitivity.py, which quantifies how far the registered pose moves if the reference's
+// build summed differently (packet code with or without FMA, other associations): the one place where an unpinned oracle could
+// differ from the reference by more than rounding of sums -- a nearest-neighbour tie or near-tie resolved the other way.
+int g_xf_order = 0;
+inline float xf_row(const float* r, const F3& a) {
+  switch (g_xf_order) {
+    case 1: return std::fmaf(r[2], a.z, std::fmaf(r[1], a.y, r[0] * a.x)) + r[3];              // packet pmadd chain, translation added last
+    case 2: return r[0] * a.x + (r[1] * a.y + (r[2] * a.z + r[3]));                            // accumulated from the last column
+    case 3: return (r[0] * a.x + r[1] * a.y) + (r[2] * a.z + r[3]);                            // pairwise
+    case 4: return std::fmaf(r[0], a.x, std::fmaf(r[1], a.y, std::fmaf(r[2], a.z, r[3])));     // fully fused, from the last column
+    case 5: return std::fmaf(r[2], a.z, std::fmaf(r[1], a.y, std::fmaf(r[0], a.x, r[3])));     // fully fused, translation first
+    default: return ((r[0] * a.x + r[1] * a.y) + r[2] * a.z) + r[3];
+  }
+}
+
 // A:133-194
 void update_correspondences(Ref& r, const M4& T) {
   const int n = (int)r.src.pts.size();
@@ -428,9 +446,7 @@ void update_correspondences(Ref& r, const M4& T) {
   for (int i = 0; i < n; i++) {
     const F3& a = r.src.pts[i];
     F3 pt;  // A:149
-    pt.x = ((Tf[0][0] * a.x + Tf[0][1] * a.y) + Tf[0][2] * a.z) + Tf[0][3];
-    pt.y = ((Tf[1][0] * a.x + Tf[1][1] * a.y) + Tf[1][2] * a.z) + Tf[1][3];
-    pt.z = ((Tf[2][0] * a.x + Tf[2][1] * a.y) + Tf[2][2] * a.z) + Tf[2][3];
+    pt.x = xf_row(Tf[0], a), pt.y = xf_row(Tf[1], a), pt.z = xf_row(Tf[2], a);
     static thread_local std::vector<Cand> heap;
     heap.clear();
     heap.reserve(2);
@@ -627,6 +643,8 @@ void* ref_create(const RefParams* p) {
   return r;
 }
 void ref_destroy(void* h) { delete (Ref*)h; }
+// measurement only (tests/measure/transform_order_sensitivity.py): 0 = the reference order, see xf_row
+void ref_set_transform_order(int order) { g_xf_order = order; }
 void ref_set_params(void* h, const RefParams* p) { ((Ref*)h)->p = *p; }
 int ref_set_num_threads(void* h, int n) {
   Ref* r = (Ref*)h;

@@ -1,14 +1,25 @@
 // Loop-closure candidate batches sharded over the GPUs of one node from ONE C++ process (the Python / one
-// process per GPU form is riv-slam_amd/sharded.py).
+// process per GPU form is riv-slam_amd/sharded.py), pipelined: several batches are in flight on every device.
 //
 // Independent (source, target) pairs -- the candidates of loop_detector.cpp:222-236 / :404-423 -- are block-partitioned over
-// the devices exactly like sharded.block_partition: pair p belongs to device p / ceil(P / D).  One host thread per device
-// registers its block through its own apdgicp_batch handle; there is no collective on the data path.  The only exchange is
-// ONE ncclAllGather (RCCL over xGMI) of the fixed-size result records, 96 bytes per pair, issued by every device thread on the
-// stream its batch ran on, so that every device -- in particular the one next to the pose-graph owner -- ends up with all
-// results.  The payload is a few KB: latency-bound, hence one call per batch.
+// the devices exactly like sharded.block_partition: pair p belongs to device p / ceil(P / D).  There is no collective on the
+// data path.  The only exchange is ONE ncclAllGather (RCCL over xGMI) of the fixed-size result records, 96 bytes per pair, per
+// batch, so that every device -- in particular the one next to the pose-graph owner -- ends up with all results.  The payload
+// is a few KB: latency-bound, hence one call per batch.
 //
-// Needs <hip/hip_runtime_api.h> and <rccl/rccl.h> (link amdhip64 + rccl).  Header-only.
+// Execution: one persistent worker thread per device (created once, with the communicators, streams, handles and record
+// buffers: nothing is allocated or spawned per call once the buffers have their size).  enqueue() validates the batch on the
+// calling thread, hands every worker its block and returns a ticket; a worker registers its block's clouds, enqueues the
+// registrations (apdgicp_batch_align_enqueue: nothing waits) and only then collects the OLDEST batch it still has in flight,
+// issues that batch's all-gather on a stream of its own and moves on -- the gather of batch j is waited for when its slot is
+// needed again or when the caller collects it, so ranks may drift by a few batches and the GPU always has `in_flight`
+// batches queued.  Gauss-Newton batches run on `in_flight` handles with one pair group each (bench.py's schedule);
+// Levenberg-Marquardt batches -- the reference's default -- run on ONE handle whose pair pool merges the batches in flight
+// (include/apdgicp_hip.h), each in its own range of cloud slots.  A worker that fails -- bad cloud, HIP error, device error
+// flag -- still takes part in the collective with a zeroed block and reports the error at collect(): no rank is left
+// waiting in ncclAllGather (every rank calls the collectives in ticket order).
+//
+// Needs <hip/hip_runtime_api.h> and <rccl/rccl.h> (link amdhip64 + rccl + pthread).  Header-only.
 #ifndef FAST_GICP_SHARDED_BATCH_HIP_HPP
 #define FAST_GICP_SHARDED_BATCH_HIP_HPP
 
@@ -16,9 +27,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -32,6 +48,7 @@ struct ShardCloud {
   const float* xyz;
   int64_t n;
   int64_t stride_bytes;
+  int on_device = 0;  // != 0: xyz is device memory ON THE DEVICE OF THE RANK that owns the pairs referencing the cloud
 };
 
 /// [begin, end) per device: contiguous blocks of ceil(P / D) pairs, the last ones short or empty (== sharded.block_partition)
@@ -44,13 +61,40 @@ inline std::vector<std::pair<int64_t, int64_t>> block_partition(int64_t n_pairs,
 
 class ShardedBatchAlignerHip {
  public:
-  /// devices: HIP device indices, one rank each (rank r = devices[r])
-  ShardedBatchAlignerHip(const apdgicp_params* params, const std::vector<int>& devices) : devices_(devices), ranks_(devices.size()) {
+  /// devices: HIP device indices, one rank each (rank r = devices[r]); in_flight: batches kept in flight per device (1 .. 8)
+  ShardedBatchAlignerHip(const apdgicp_params* params, const std::vector<int>& devices, int in_flight = 4)
+      : devices_(devices), slots_(std::max(1, std::min(8, in_flight))) {
     const int D = (int)devices.size();
+    apdgicp_params dflt;
+    apdgicp_default_params(&dflt);
+    params_ = params ? *params : dflt;
+    pooled_ = params_.optimizer == APDGICP_OPT_LM;
     comms_.assign((size_t)D, nullptr);
     if (D == 0) {
       error_ = "no devices";
       return;
+    }
+    // Order matters for speed, not for correctness: the HIP runtime deals the streams of a process onto its hardware queues
+    // in creation order, so the handles (whose streams carry the registrations) come first, RCCL's internal streams and the
+    // two service streams of every rank after them (measured: docs/experiments.md).
+    for (int r = 0; r < D; r++) ranks_.emplace_back(new Rank);
+    for (int r = 0; r < D; r++) {
+      Rank& k = *ranks_[(size_t)r];
+      k.slots.resize((size_t)slots_);
+      if (hipSetDevice(devices[(size_t)r]) != hipSuccess) {
+        error_ = "hipSetDevice failed on device " + std::to_string(devices[(size_t)r]);
+        return;
+      }
+      const int nh = pooled_ ? 1 : slots_;
+      for (int h = 0; h < nh; h++) {
+        apdgicp_batch* b = nullptr;
+        if (apdgicp_batch_create(&params_, devices[(size_t)r], nullptr, &b) != 0) {
+          error_ = std::string("apdgicp_batch_create: ") + apdgicp_last_error();
+          return;
+        }
+        if (nh > 1) apdgicp_batch_set_pair_groups(b, 1);  // several handles share the GPU: one stream, larger launches each
+        k.handles.push_back(b);
+      }
     }
     if (ncclCommInitAll(comms_.data(), D, devices.data()) != ncclSuccess) {
       error_ = "ncclCommInitAll failed";
@@ -58,25 +102,42 @@ class ShardedBatchAlignerHip {
       return;
     }
     for (int r = 0; r < D; r++) {
-      Rank& k = ranks_[(size_t)r];
-      if (hipSetDevice(devices[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess) {
+      Rank& k = *ranks_[(size_t)r];
+      if (hipSetDevice(devices[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&k.gstream, hipStreamNonBlocking) != hipSuccess ||
+          hipStreamCreateWithFlags(&k.cstream, hipStreamNonBlocking) != hipSuccess) {
         error_ = "stream creation failed on device " + std::to_string(devices[(size_t)r]);
         return;
       }
-      if (apdgicp_batch_create(params, devices[(size_t)r], (void*)k.stream, &k.batch) != 0) {
-        error_ = std::string("apdgicp_batch_create: ") + apdgicp_last_error();
-        return;
-      }
+      for (Slot& s : k.slots)
+        if (hipEventCreateWithFlags(&s.gathered, hipEventDisableTiming) != hipSuccess) {
+          error_ = "event creation failed";
+          return;
+        }
     }
+    for (int r = 0; r < D; r++) ranks_[(size_t)r]->th = std::thread([this, r]() { worker(r); });
   }
   ~ShardedBatchAlignerHip() {
+    for (auto& kp : ranks_) {
+      {
+        std::lock_guard<std::mutex> g(kp->mu);
+        kp->stop = true;
+      }
+      kp->cv.notify_all();
+    }
+    for (auto& kp : ranks_)
+      if (kp->th.joinable()) kp->th.join();
     for (size_t r = 0; r < ranks_.size(); r++) {
-      Rank& k = ranks_[r];
+      Rank& k = *ranks_[r];
       (void)hipSetDevice(devices_[r]);
-      if (k.batch) apdgicp_batch_destroy(k.batch);
-      if (k.send) (void)hipFree(k.send);
-      if (k.recv) (void)hipFree(k.recv);
-      if (k.stream) (void)hipStreamDestroy(k.stream);
+      if (k.gstream) (void)hipStreamSynchronize(k.gstream);
+      for (apdgicp_batch* b : k.handles) apdgicp_batch_destroy(b);
+      for (Slot& s : k.slots) {
+        if (s.send) (void)hipFree(s.send);
+        if (s.recv) (void)hipFree(s.recv);
+        if (s.gathered) (void)hipEventDestroy(s.gathered);
+      }
+      if (k.gstream) (void)hipStreamDestroy(k.gstream);
+      if (k.cstream) (void)hipStreamDestroy(k.cstream);
     }
     for (ncclComm_t c : comms_)
       if (c) ncclCommDestroy(c);
@@ -86,104 +147,282 @@ class ShardedBatchAlignerHip {
   bool ok() const { return error_.empty(); }
   const std::string& error() const { return error_; }
   int world() const { return (int)devices_.size(); }
+  int in_flight() const { return slots_; }
+  /// with ONE device the all-gather is a copy; RCCL is still called by default (the path the multi-GPU job takes)
+  void set_gather_when_alone(bool on) { gather_when_alone_ = on; }
 
-  /// Registers pairs[i] = (source cloud, target cloud, guess) -- indices into `clouds` -- and returns all P records in pair
-  /// order (read back from rank `root`, which like every rank holds the gathered buffer).  0 or a negative apdgicp_status.
-  int align(const std::vector<ShardCloud>& clouds, const std::vector<apdgicp_pair>& pairs, std::vector<apdgicp_result>* results, int root = 0) {
-    if (!ok() || !results) return APDGICP_ERR_INVALID_ARG;
+  /// Hands the batch to the workers and returns its ticket (> 0) in *ticket; 0 or a negative apdgicp_status.  pairs[i] =
+  /// (source cloud, target cloud, guess) with indices into `clouds`.  Nothing waits unless `in_flight` batches are already
+  /// queued.  The cloud memory must stay valid until the batch has been collected (or in_flight later batches enqueued).
+  int enqueue(const std::vector<ShardCloud>& clouds, const std::vector<apdgicp_pair>& pairs, uint64_t* ticket) {
+    if (!ok() || !ticket) return APDGICP_ERR_INVALID_ARG;
     const int D = world();
     const int64_t P = (int64_t)pairs.size();
-    results->assign((size_t)P, apdgicp_result());
-    if (P == 0) return 0;
+    // everything that can be wrong with the batch is found HERE, before a worker has entered a collective
+    for (const apdgicp_pair& q : pairs)
+      for (int32_t idx : {q.source_cloud, q.target_cloud})
+        if (idx < 0 || (size_t)idx >= clouds.size() || !clouds[(size_t)idx].xyz || clouds[(size_t)idx].n <= 0 || clouds[(size_t)idx].stride_bytes < 12) {
+          error_text_ = "pair references a missing or empty cloud";
+          return APDGICP_ERR_INVALID_ARG;
+        }
     const auto parts = block_partition(P, D);
-    const int64_t per = parts[0].second - parts[0].first;
-    std::vector<int> rc((size_t)D, 0);
-    std::vector<std::string> msg((size_t)D);
-    std::vector<std::thread> threads;
-    for (int r = 0; r < D; r++)
-      threads.emplace_back([&, r]() { rc[(size_t)r] = run_rank(r, clouds, pairs, parts[(size_t)r].first, parts[(size_t)r].second, per, &msg[(size_t)r]); });
-    for (auto& t : threads) t.join();
-    for (int r = 0; r < D; r++)
-      if (rc[(size_t)r] < 0) {
-        error_text_ = msg[(size_t)r];
-        return rc[(size_t)r];
-      }
-    // every rank's `recv` holds D blocks of `per` records (short blocks zero-padded): trim them back into pair order
-    Rank& k = ranks_[(size_t)root];
-    std::vector<apdgicp_result> all((size_t)(per * D));
-    if (hipSetDevice(devices_[(size_t)root]) != hipSuccess ||
-        hipMemcpy(all.data(), k.recv, all.size() * sizeof(apdgicp_result), hipMemcpyDeviceToHost) != hipSuccess)
-      return APDGICP_ERR_HIP;
-    for (int r = 0; r < D; r++)
-      for (int64_t p = parts[(size_t)r].first; p < parts[(size_t)r].second; p++) (*results)[(size_t)p] = all[(size_t)(r * per + (p - parts[(size_t)r].first))];
-    return 0;
-  }
-  const std::string& last_error_text() const { return error_text_; }
-  /// device pointer of rank r's gathered buffer (world * per records), valid until the next align
-  const void* gathered_on(int r) const { return ranks_[(size_t)r].recv; }
-
- private:
-  struct Rank {
-    hipStream_t stream = nullptr;
-    apdgicp_batch* batch = nullptr;
-    char* send = nullptr;
-    char* recv = nullptr;
-    size_t send_cap = 0, recv_cap = 0;
-  };
-
-  int run_rank(int r, const std::vector<ShardCloud>& clouds, const std::vector<apdgicp_pair>& pairs, int64_t b, int64_t e, int64_t per, std::string* msg) {
-    Rank& k = ranks_[(size_t)r];
-    const int D = world();
-    auto fail = [&](int code, const char* what) {
-      *msg = std::string(what) + ": " + apdgicp_last_error();
-      return code;
-    };
-    if (hipSetDevice(devices_[(size_t)r]) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipSetDevice");
-    const size_t rec = sizeof(apdgicp_result);
-    if ((size_t)per * rec > k.send_cap) {
-      if (k.send) (void)hipFree(k.send);
-      if (hipMalloc((void**)&k.send, (size_t)per * rec) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMalloc");
-      k.send_cap = (size_t)per * rec;
-    }
-    if ((size_t)per * rec * D > k.recv_cap) {
-      if (k.recv) (void)hipFree(k.recv);
-      if (hipMalloc((void**)&k.recv, (size_t)per * rec * D) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMalloc");
-      k.recv_cap = (size_t)per * rec * D;
-    }
-    if (hipMemsetAsync(k.send, 0, (size_t)per * rec, k.stream) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMemsetAsync");
-    int rc = 0;
-    if (e > b) {
+    const int64_t per = P > 0 ? parts[0].second - parts[0].first : 0;
+    const uint64_t seq = ++seq_;
+    for (int r = 0; r < D; r++) {
+      std::unique_ptr<Job> job(new Job);
+      job->seq = seq, job->per = per, job->begin = parts[(size_t)r].first, job->end = parts[(size_t)r].second;
       // this rank's clouds: the ones its pairs reference, renumbered in order of first use
       std::vector<int> local(clouds.size(), -1);
-      std::vector<apdgicp_pair> mine;
-      if ((rc = apdgicp_batch_clear(k.batch)) < 0) return fail(rc, "apdgicp_batch_clear");
-      for (int64_t p = b; p < e; p++) {
+      for (int64_t p = job->begin; p < job->end; p++) {
         apdgicp_pair q = pairs[(size_t)p];
         for (int32_t* idx : {&q.source_cloud, &q.target_cloud}) {
-          if (*idx < 0 || (size_t)*idx >= clouds.size()) return fail(APDGICP_ERR_INVALID_ARG, "pair references a missing cloud");
           if (local[(size_t)*idx] < 0) {
-            const ShardCloud& c = clouds[(size_t)*idx];
-            const int id = apdgicp_batch_add_cloud(k.batch, c.xyz, c.n, c.stride_bytes, 0);
-            if (id < 0) return fail(id, "apdgicp_batch_add_cloud");
-            local[(size_t)*idx] = id;
+            local[(size_t)*idx] = (int)job->clouds.size();
+            job->clouds.push_back(clouds[(size_t)*idx]);
           }
           *idx = local[(size_t)*idx];
         }
-        mine.push_back(q);
+        job->pairs.push_back(q);
       }
-      void* d_res = nullptr;
-      if ((rc = apdgicp_batch_align_async(k.batch, mine.data(), (int64_t)mine.size(), &d_res)) < 0) return fail(rc, "apdgicp_batch_align_async");
-      if (hipMemcpyAsync(k.send, d_res, mine.size() * rec, hipMemcpyDeviceToDevice, k.stream) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMemcpyAsync");
+      Rank& k = *ranks_[(size_t)r];
+      std::unique_lock<std::mutex> g(k.mu);
+      k.cv.wait(g, [&]() { return (int)k.queue.size() < slots_; });  // back-pressure
+      k.queue.push_back(std::move(job));
+      g.unlock();
+      k.cv.notify_all();
     }
-    // every rank calls the collective, an empty block contributes zeros
-    if (ncclAllGather(k.send, k.recv, (size_t)per * rec, ncclChar, comms_[(size_t)r], k.stream) != ncclSuccess) return fail(APDGICP_ERR_HIP, "ncclAllGather");
-    if (hipStreamSynchronize(k.stream) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipStreamSynchronize");
+    *ticket = seq;
     return 0;
   }
 
+  /// Waits for the batch of `ticket` (one of the last in_flight enqueued) on every rank and returns all P records in pair
+  /// order, read from rank `root`'s copy of the gathered buffer.  0, or the first rank's negative apdgicp_status
+  /// (last_error_text() says which and why).
+  int collect(uint64_t ticket, std::vector<apdgicp_result>* results, int root = 0) {
+    if (!ok() || !results || ticket == 0 || ticket > seq_ || root < 0 || root >= world()) return APDGICP_ERR_INVALID_ARG;
+    const int D = world();
+    int rc = 0;
+    int64_t per = 0, total = 0;
+    std::vector<std::pair<int64_t, int64_t>> ranges((size_t)D);
+    for (int r = 0; r < D; r++) {
+      Rank& k = *ranks_[(size_t)r];
+      Slot& s = k.slots[(size_t)(ticket % (uint64_t)slots_)];
+      std::unique_lock<std::mutex> g(k.mu);
+      k.want = std::max(k.want, ticket);  // (an idle worker finishes what it has in flight up to here)
+      k.cv.notify_all();
+      k.cv.wait(g, [&]() { return s.issued_seq >= ticket || k.dead; });
+      if (s.issued_seq != ticket) {
+        error_text_ = k.dead ? "rank " + std::to_string(r) + ": worker stopped" : "ticket is older than the batches in flight";
+        return APDGICP_ERR_INVALID_ARG;
+      }
+      if (s.rc < 0 && rc == 0) rc = s.rc, error_text_ = "rank " + std::to_string(r) + ": " + s.msg;
+      per = s.per, ranges[(size_t)r] = {s.begin, s.end}, total = std::max(total, s.end);
+    }
+    Rank& k = *ranks_[(size_t)root];
+    Slot& s = k.slots[(size_t)(ticket % (uint64_t)slots_)];
+    results->assign((size_t)total, apdgicp_result());
+    if (hipSetDevice(devices_[(size_t)root]) != hipSuccess || hipEventSynchronize(s.gathered) != hipSuccess) return APDGICP_ERR_HIP;
+    if (rc < 0 || total == 0) return rc;
+    std::vector<apdgicp_result> all((size_t)(per * D));
+    if (hipMemcpy(all.data(), s.recv, all.size() * sizeof(apdgicp_result), hipMemcpyDeviceToHost) != hipSuccess) return APDGICP_ERR_HIP;
+    // every rank's `recv` holds D blocks of `per` records (short blocks zero-padded): trim them back into pair order
+    for (int r = 0; r < D; r++)
+      for (int64_t p = ranges[(size_t)r].first; p < ranges[(size_t)r].second; p++) (*results)[(size_t)p] = all[(size_t)(r * per + (p - ranges[(size_t)r].first))];
+    return 0;
+  }
+
+  /// enqueue + collect
+  int align(const std::vector<ShardCloud>& clouds, const std::vector<apdgicp_pair>& pairs, std::vector<apdgicp_result>* results, int root = 0) {
+    uint64_t t = 0;
+    const int rc = enqueue(clouds, pairs, &t);
+    if (rc < 0) return rc;
+    return collect(t, results, root);
+  }
+  const std::string& last_error_text() const { return error_text_; }
+  /// device pointer of rank r's gathered buffer of batch `ticket` (world * per records; wait for it with collect first)
+  const void* gathered_on(int r, uint64_t ticket) const { return ranks_[(size_t)r]->slots[(size_t)(ticket % (uint64_t)slots_)].recv; }
+
+ private:
+  struct Job {
+    uint64_t seq = 0;
+    int64_t per = 0, begin = 0, end = 0;
+    std::vector<ShardCloud> clouds;
+    std::vector<apdgicp_pair> pairs;
+  };
+  struct Slot {
+    char* send = nullptr;
+    char* recv = nullptr;
+    size_t send_cap = 0, recv_cap = 0;
+    hipEvent_t gathered = nullptr;
+    // worker-private until published under the rank's mutex
+    uint64_t started_seq = 0, align_ticket = 0;
+    bool busy = false;
+    int start_rc = 0;
+    std::string start_msg;
+    int64_t s_per = 0, s_begin = 0, s_end = 0;
+    // published: the batch whose all-gather has been ISSUED on this slot
+    uint64_t issued_seq = 0;
+    int rc = 0;
+    std::string msg;
+    int64_t per = 0, begin = 0, end = 0;
+  };
+  struct Rank {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Job>> queue;
+    bool stop = false, dead = false;
+    uint64_t want = 0;
+    hipStream_t gstream = nullptr, cstream = nullptr;  // all-gathers; the copy of a block into its send buffer
+    std::vector<apdgicp_batch*> handles;
+    std::vector<Slot> slots;
+    int cloud_cap = 64;  // pooled mode: cloud slots per batch in flight (grows; the descriptor table the handle uploads is as long as the highest slot)
+    std::vector<const float*> ptrs;
+    std::vector<int64_t> ns;
+  };
+
+  apdgicp_batch* handle_of(Rank& k, uint64_t seq) { return pooled_ ? k.handles[0] : k.handles[(size_t)(seq % (uint64_t)slots_)]; }
+
+  // registers the block's clouds and enqueues its registrations on the slot's handle; errors are kept for the gather
+  void start(int r, Rank& k, Slot& s, const Job& job) {
+    s.busy = true, s.started_seq = job.seq, s.start_rc = 0, s.start_msg.clear(), s.align_ticket = 0;
+    s.s_per = job.per, s.s_begin = job.begin, s.s_end = job.end;
+    auto fail = [&](int code, const char* what) { s.start_rc = code, s.start_msg = std::string(what) + ": " + apdgicp_last_error(); };
+    if (hipSetDevice(devices_[(size_t)r]) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipSetDevice");
+    const size_t rec = sizeof(apdgicp_result), D = (size_t)world();
+    if ((size_t)job.per * rec > s.send_cap || (size_t)job.per * rec * D > s.recv_cap) {  // (first batches only)
+      if (hipEventSynchronize(s.gathered) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipEventSynchronize");
+      if (s.send) (void)hipFree(s.send);
+      if (s.recv) (void)hipFree(s.recv);
+      s.send = s.recv = nullptr, s.send_cap = s.recv_cap = 0;
+      const size_t cap = std::max<size_t>((size_t)job.per * rec * 2, 4096);
+      if (hipMalloc((void**)&s.send, cap) != hipSuccess || hipMalloc((void**)&s.recv, cap * D) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMalloc");
+      s.send_cap = cap, s.recv_cap = cap * D;
+    }
+    if (job.pairs.empty()) return;
+    apdgicp_batch* b = handle_of(k, job.seq);
+    int base = 0;
+    if (pooled_) {  // one handle, the batches in flight side by side in its cloud slots
+      if ((int)job.clouds.size() > k.cloud_cap) {
+        if (apdgicp_batch_synchronize(b) < 0) return fail(APDGICP_ERR_HIP, "apdgicp_batch_synchronize");
+        while (k.cloud_cap < (int)job.clouds.size()) k.cloud_cap *= 2;
+      }
+      base = (int)(job.seq % (uint64_t)slots_) * k.cloud_cap;
+    }
+    const bool all_dev = std::all_of(job.clouds.begin(), job.clouds.end(), [&](const ShardCloud& c) { return c.on_device && c.stride_bytes == job.clouds[0].stride_bytes; });
+    int rc = 0;
+    if (all_dev) {  // one pack launch for the whole block
+      k.ptrs.resize(job.clouds.size()), k.ns.resize(job.clouds.size());
+      for (size_t c = 0; c < job.clouds.size(); c++) k.ptrs[c] = job.clouds[c].xyz, k.ns[c] = job.clouds[c].n;
+      if ((rc = apdgicp_batch_set_clouds(b, base, (int)job.clouds.size(), k.ptrs.data(), k.ns.data(), job.clouds[0].stride_bytes, 1)) < 0)
+        return fail(rc, "apdgicp_batch_set_clouds");
+    } else {
+      for (size_t c = 0; c < job.clouds.size(); c++)
+        if ((rc = apdgicp_batch_set_cloud(b, base + (int)c, job.clouds[c].xyz, job.clouds[c].n, job.clouds[c].stride_bytes, job.clouds[c].on_device)) < 0)
+          return fail(rc, "apdgicp_batch_set_cloud");
+    }
+    std::vector<apdgicp_pair> mine = job.pairs;
+    for (apdgicp_pair& q : mine) q.source_cloud += base, q.target_cloud += base;
+    if ((rc = apdgicp_batch_align_enqueue(b, mine.data(), (int64_t)mine.size(), &s.align_ticket)) < 0) return fail(rc, "apdgicp_batch_align_enqueue");
+  }
+
+  // collects the slot's batch, issues its all-gather (always: a failed block contributes zeros) and publishes the outcome
+  void finish(int r, Rank& k, Slot& s) {
+    int rc = s.start_rc;
+    std::string msg = s.start_msg;
+    (void)hipSetDevice(devices_[(size_t)r]);
+    const size_t rec = sizeof(apdgicp_result);
+    void* d_res = nullptr;
+    if (rc == 0 && s.align_ticket) {
+      rc = apdgicp_batch_align_collect(handle_of(k, s.started_seq), s.align_ticket, &d_res, nullptr);
+      if (rc < 0) msg = std::string("apdgicp_batch_align_collect: ") + apdgicp_last_error();
+    }
+    const size_t mine = (size_t)(s.s_end - s.s_begin) * rec, block = (size_t)s.s_per * rec;
+    bool gather_ok = s.send && s.recv && block <= s.send_cap;
+    if (gather_ok) {
+      // the block goes into the slot's send buffer NOW, on a stream nothing else uses: the gather stream may sit behind an
+      // earlier collective that waits for a slower rank, and the handle reuses the record buffer a few batches later
+      if (hipMemsetAsync(s.send, 0, block, k.cstream) != hipSuccess) gather_ok = false;
+      if (gather_ok && rc == 0 && d_res && mine && hipMemcpyAsync(s.send, d_res, mine, hipMemcpyDeviceToDevice, k.cstream) != hipSuccess) gather_ok = false;
+      if (hipStreamSynchronize(k.cstream) != hipSuccess) gather_ok = false;
+      // every rank calls the collective, in ticket order; an empty or failed block contributes zeros
+      if (block && world() == 1 && !gather_when_alone_) {  // one device: the "gather" is a copy
+        if (hipMemcpyAsync(s.recv, s.send, block, hipMemcpyDeviceToDevice, k.gstream) != hipSuccess) gather_ok = false;
+      } else if (block && ncclAllGather(s.send, s.recv, block, ncclChar, comms_[(size_t)r], k.gstream) != ncclSuccess) {
+        gather_ok = false;
+      }
+    }
+    if (!gather_ok && rc == 0) rc = APDGICP_ERR_HIP, msg = "record gather failed";
+    (void)hipEventRecord(s.gathered, k.gstream);
+    s.busy = false;
+    {
+      std::lock_guard<std::mutex> g(k.mu);
+      s.issued_seq = s.started_seq, s.rc = rc, s.msg = msg, s.per = s.s_per, s.begin = s.s_begin, s.end = s.s_end;
+    }
+    k.cv.notify_all();
+  }
+
+  void worker(int r) {
+    Rank& k = *ranks_[(size_t)r];
+    std::deque<uint64_t> inflight;  // batches started and not yet finished, oldest first (consecutive tickets: every rank gets every batch)
+    for (;;) {
+      std::unique_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> g(k.mu);
+        auto ready = [&]() {
+          // a new batch; or somebody waits for a batch that is only enqueued so far; or shutdown
+          return !k.queue.empty() || k.stop || (!inflight.empty() && k.want >= inflight.front());
+        };
+        if (pooled_ && !inflight.empty()) {
+          // the pair pool of the handle is served by the calls of this thread: while it has nothing else to do it keeps the
+          // chunks of ticks enqueued ahead (apdgicp_batch_pump), instead of sleeping until the caller's next move
+          while (!ready()) {
+            g.unlock();
+            (void)apdgicp_batch_pump(k.handles[0]);
+            g.lock();
+            if (!ready()) k.cv.wait_for(g, std::chrono::microseconds(50));
+          }
+        } else {
+          k.cv.wait(g, ready);
+        }
+        if (!k.queue.empty()) {
+          job = std::move(k.queue.front());
+          k.queue.pop_front();
+        } else if (k.stop && inflight.empty()) {
+          break;
+        }
+      }
+      k.cv.notify_all();  // (room in the queue)
+      if (!job) {  // nothing new: the oldest batch in flight leaves
+        finish(r, k, k.slots[(size_t)(inflight.front() % (uint64_t)slots_)]);
+        inflight.pop_front();
+        continue;
+      }
+      Slot& s = k.slots[(size_t)(job->seq % (uint64_t)slots_)];
+      if ((int)inflight.size() == slots_) {  // the slot's previous batch is the oldest in flight
+        finish(r, k, s);
+        inflight.pop_front();
+      }
+      (void)hipSetDevice(devices_[(size_t)r]);
+      (void)hipEventSynchronize(s.gathered);  // the gather that last read this slot's buffers
+      start(r, k, s, *job);
+      inflight.push_back(job->seq);
+    }
+    {
+      std::lock_guard<std::mutex> g(k.mu);
+      k.dead = true;
+    }
+    k.cv.notify_all();
+  }
+
   std::vector<int> devices_;
-  std::vector<Rank> ranks_;
+  int slots_ = 4;
+  bool pooled_ = false;
+  bool gather_when_alone_ = true;  // world size 1: still go through RCCL (set_gather_when_alone(false): a plain copy)
+  apdgicp_params params_;
+  std::vector<std::unique_ptr<Rank>> ranks_;
   std::vector<ncclComm_t> comms_;
+  uint64_t seq_ = 0;
   std::string error_, error_text_;
 };
 

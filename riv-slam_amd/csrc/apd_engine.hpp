@@ -275,7 +275,8 @@ class Engine {
   // for its own device when it is created -- no process-wide "done once" flag that a second device or thread could trip over.
   static int set_kernel_attributes() {
     APD_HIP(hipFuncSetAttribute((const void*)k_sort_cloud_lds, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
-    APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_LDS_BYTES));
+    APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov<64>, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes_brute(64)));
+    APD_HIP(hipFuncSetAttribute((const void*)k_knn_cov<128>, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes_brute(128)));
     APD_HIP(hipFuncSetAttribute((const void*)k_merge_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_LDS_MAX_N * 8));
     return 0;
   }
@@ -380,8 +381,8 @@ class Engine {
 
   int set_params(const apdgicp_params* p) {
     if (!p) return fail(APDGICP_ERR_INVALID_ARG, "params is null");
-    if (p->k_correspondences < 1 || p->k_correspondences > KNN_NC)
-      return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
+    if (p->k_correspondences < 1 || p->k_correspondences > 2 * KNN_NC)
+      return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 64]");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
     if (pool.on) APD_TRY(pool_drain());  // the batches in flight finish with the parameters they were enqueued with
@@ -539,7 +540,7 @@ class Engine {
 
   // many device-resident clouds at once: one pack launch instead of one per cloud
   int set_clouds_device(int first, int count, const float* const* xyz, const int64_t* ns, int64_t stride_bytes) {
-    if (first < 0 || count <= 0 || first > (int)clouds.size()) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud range");
+    if (first < 0 || count <= 0 || first + (long long)count > (1 << 24)) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud range");
     if (!xyz || !ns) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
     APD_HIP(hipSetDevice(device));
@@ -771,7 +772,7 @@ class Engine {
     int nmax = 0;
     long long total = 0;
     for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
-    if (knn_pruned) {
+    if (knn_pruned && params.k_correspondences <= KNN_NC) {
       // queries per wave = 64 / lanes per query: fewer queries per wave shorten the per-wave dependency chain and shrink its LDS
       // lists, which wins whenever the GPU is not already full (r01, 2 clouds of 8k: 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16)
       const int qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;
@@ -792,8 +793,13 @@ class Engine {
                            params.regularization, d_errflag.as<int>());
     } else {
       const dim3 grid((unsigned)((nmax + KNN_BLK - 1) / KNN_BLK), (unsigned)count);
-      hipLaunchKernelGGL(k_knn_cov, grid, dim3(KNN_BLK), KNN_LDS_BYTES, st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
-                         params.regularization, d_errflag.as<int>());
+      // the brute-force kernel: the cross-check (APDGICP_KNN_MODE=brute), and the only path for 32 < k <= 64
+      if (params.k_correspondences <= KNN_NC)
+        hipLaunchKernelGGL(k_knn_cov<64>, grid, dim3(KNN_BLK), knn_lds_bytes_brute(64), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>());
+      else
+        hipLaunchKernelGGL(k_knn_cov<128>, grid, dim3(KNN_BLK), knn_lds_bytes_brute(128), st, d_desc.as<CloudDesc>(), d_list, params.k_correspondences,
+                           params.regularization, d_errflag.as<int>());
     }
     APD_HIP(hipGetLastError());
     for (int i = 0; i < count; i++) clouds[ids[i]].cov_valid = true;
@@ -1513,11 +1519,20 @@ class Engine {
   int pool_pump(bool block) {
     if (!pool.layout_valid) return block ? fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight") : 0;
     APD_HIP(hipSetDevice(device));
-    while (pool.seq_seen < pool.seq_enq && *(volatile int*)&pool_hdr(pool.seq_seen + 1)->seq == (int)(pool.seq_seen + 1))
+    bool progress = false;
+    while (pool.seq_seen < pool.seq_enq && *(volatile int*)&pool_hdr(pool.seq_seen + 1)->seq == (int)(pool.seq_seen + 1)) {
       APD_TRY(pool_process(pool.seq_seen + 1));
+      progress = true;
+    }
     APD_TRY(pool_topup());
-    if (!block) return 0;
-    if (pool.seq_seen == pool.seq_enq) return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for");
+    if (!block || progress) return 0;  // (a header that had arrived already may be the one the caller waits for: it looks again)
+    if (pool.seq_seen == pool.seq_enq) {
+      std::string st;
+      for (int l = 0; l < pool.lanes; l++)
+        st += " [" + std::to_string(l) + ": state " + std::to_string((int)pool.jobs[l].state) + " ticket " + std::to_string(pool.jobs[l].ticket) + " np " +
+              std::to_string(pool.jobs[l].np) + " admitted at " + std::to_string(pool.jobs[l].admit_seq) + "]";
+      return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for (chunk " + std::to_string(pool.seq_enq) + ", list bound " + std::to_string(pool.ub) + ";" + st + ")");
+    }
     const uint64_t want = pool.seq_seen + 1;
     volatile int* word = (volatile int*)&pool_hdr(want)->seq;
     {

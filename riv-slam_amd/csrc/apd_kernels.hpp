@@ -299,8 +299,11 @@ __global__ void k_export_corr(const int* corr, const float* sqd, const int* perm
 //   sweep 2: collect every candidate with (d, idx) <= tau into a per-thread LDS list (expected
 //            ~1.5 k entries); on overflow tau is tightened from the list and the sweep repeats.
 //   select : k rounds of lexicographic (d, idx) min-extraction; accumulate sums in fp64.
-constexpr int KNN_BLK = 128, KNN_CAP = 64, KNN_NC = 32, KNN_TILE = 1024;
-constexpr int KNN_LDS_BYTES = KNN_TILE * 16 + KNN_CAP * KNN_BLK * 8;
+//   KNN_CAP: list entries per query -- 64 for k <= 32; 128 for 32 < k <= 64 (setCorrespondenceRandomness takes any k, A:45-47;
+//   the launch file ships 20).  Beyond 32 the class minima give no bound (tau starts at +inf) and every overflow restart keeps
+//   about k / KNN_CAP of the candidates: correct, a sweep per restart, the slow path of a setting nobody ships.
+constexpr int KNN_BLK = 128, KNN_NC = 32, KNN_TILE = 1024;
+__host__ __device__ constexpr int knn_lds_bytes_brute(int cap) { return KNN_TILE * 16 + cap * KNN_BLK * 8; }
 
 __device__ __forceinline__ void knn_load_tile(float4* tile, const float4* pts, int t0, int n, int tid) {
   const float inf = __builtin_inff();
@@ -310,6 +313,7 @@ __device__ __forceinline__ void knn_load_tile(float4* tile, const float4* pts, i
   }
 }
 
+template <int KNN_CAP>
 __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* tile = (float4*)smem;

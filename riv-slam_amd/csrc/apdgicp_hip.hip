@@ -575,7 +575,7 @@ int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64
 int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device) {
   return guarded([&]() -> int {
     if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
-    if (index < 0 || index > (int)b->eng.clouds.size()) return fail(APDGICP_ERR_INVALID_ARG, "cloud index out of range");
+    if (index < 0 || index >= (1 << 24)) return fail(APDGICP_ERR_INVALID_ARG, "cloud index out of range");
     APD_TRY(b->eng.set_cloud(index, xyz, n, stride_bytes, on_device, 0));
     return index;
   });
@@ -630,6 +630,13 @@ int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int
     APD_TRY(e.run_align(/*defer_poll=*/true));
     *ticket = e.align_seq;
     return 0;
+  });
+}
+
+int apdgicp_batch_pump(apdgicp_batch* b) {
+  return guarded([&]() -> int {
+    if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+    return b->eng.pool.on ? b->eng.pool_pump(false) : 0;
   });
 }
 

@@ -4,7 +4,8 @@
 // picks the best candidate of the same batch the way LoopDetector::matching does (loop_detector.cpp:387-441).
 // usage: test_multi_device <batch.bin> [max_devices]        (no argument: compile/link check only)
 //   batch.bin: int32 n_clouds, then per cloud int32 n + n*3 floats; int32 n_pairs, then per pair int32 src, int32 tgt, float guess[16]
-// prints: world <D> pairs <P> sharded_equals_single <0|1> gathered_on_all_ranks <0|1> loop_best <i> loop_score <s>
+// prints: world <D> pairs <P> sharded_equals_single <0|1> gathered_on_all_ranks <0|1> pipelined_equals_single <0|1> errors_ok <0|1> loop_best <i> loop_score <s>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,32 +69,77 @@ int main(int argc, char** argv) {
     }
     apdgicp_batch_destroy(b);
   }
-  // ---- sharded over D devices, one thread each, records gathered with RCCL
+  // ---- sharded over D devices (one persistent worker thread each), records gathered with RCCL
   fast_gicp::ShardedBatchAlignerHip sharded(&prm, devices);
   if (!sharded.ok()) {
     std::fprintf(stderr, "sharded: %s\n", sharded.error().c_str());
     return 5;
   }
   std::vector<apdgicp_result> res;
-  int same = 1, all_ranks = 1;
+  int same = 1, all_ranks = 1, pipelined = 1, errors_ok = 1;
+  uint64_t last_ticket = 0;
   for (int rep = 0; rep < 2; rep++) {  // twice: buffers and communicators are reused
-    if (sharded.align(clouds, pairs, &res, /*root=*/D - 1) != 0) {
+    if (sharded.enqueue(clouds, pairs, &last_ticket) != 0 || sharded.collect(last_ticket, &res, /*root=*/D - 1) != 0) {
       std::fprintf(stderr, "sharded align: %s\n", sharded.last_error_text().c_str());
       return 5;
     }
-    same = same && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
+    same = same && (int)res.size() == np && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
   }
   {  // every rank holds the same gathered buffer
     const auto parts = fast_gicp::block_partition(np, D);
     const size_t bytes = (size_t)(parts[0].second - parts[0].first) * D * sizeof(apdgicp_result);
     std::vector<char> ref(bytes), got(bytes);
     (void)hipSetDevice(0);
-    (void)hipMemcpy(ref.data(), sharded.gathered_on(0), bytes, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ref.data(), sharded.gathered_on(0, last_ticket), bytes, hipMemcpyDeviceToHost);
     for (int r = 1; r < D; r++) {
       (void)hipSetDevice(r);
-      (void)hipMemcpy(got.data(), sharded.gathered_on(r), bytes, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(got.data(), sharded.gathered_on(r, last_ticket), bytes, hipMemcpyDeviceToHost);
       all_ranks = all_ranks && std::memcmp(ref.data(), got.data(), bytes) == 0;
     }
+  }
+  {  // pipelined: as many batches in flight as the aligner keeps, then two more, collected in order; the Gauss-Newton form too
+    std::vector<uint64_t> tickets;
+    for (int q = 0; q < sharded.in_flight() + 2; q++) {
+      uint64_t t = 0;
+      if (sharded.enqueue(clouds, pairs, &t) != 0) return 5;
+      tickets.push_back(t);
+      if ((int)tickets.size() > sharded.in_flight() - 1) {  // keep in_flight - 1 uncollected
+        const uint64_t c = tickets[tickets.size() - (size_t)sharded.in_flight()];
+        if (sharded.collect(c, &res) != 0) return 5;
+        pipelined = pipelined && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
+      }
+    }
+    for (size_t q = tickets.size() - (size_t)sharded.in_flight() + 1; q < tickets.size(); q++) {
+      if (sharded.collect(tickets[q], &res) != 0) return 5;
+      pipelined = pipelined && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
+    }
+    apdgicp_params gn = prm;
+    gn.optimizer = APDGICP_OPT_GN, gn.max_iterations = 5, gn.transformation_epsilon = 1e-300, gn.rotation_epsilon = 1e-300;
+    std::vector<apdgicp_result> single_gn((size_t)np), r1, r2;
+    apdgicp_batch* b = nullptr;
+    if (apdgicp_batch_create(&gn, 0, nullptr, &b) != 0) return 4;
+    for (const auto& c : clouds)
+      if (apdgicp_batch_add_cloud(b, c.xyz, c.n, c.stride_bytes, 0) < 0) return 4;
+    if (apdgicp_batch_align(b, pairs.data(), np, single_gn.data()) != 0) return 4;
+    apdgicp_batch_destroy(b);
+    fast_gicp::ShardedBatchAlignerHip sharded_gn(&gn, devices, 3);
+    uint64_t t1 = 0, t2 = 0, t3 = 0;
+    if (!sharded_gn.ok() || sharded_gn.enqueue(clouds, pairs, &t1) != 0 || sharded_gn.enqueue(clouds, pairs, &t2) != 0 || sharded_gn.enqueue(clouds, pairs, &t3) != 0) return 5;
+    if (sharded_gn.collect(t2, &r2) != 0 || sharded_gn.collect(t1, &r1) != 0 || sharded_gn.collect(t3, &res) != 0) return 5;
+    for (const auto* v : {&r1, &r2, &res}) pipelined = pipelined && std::memcmp(v->data(), single_gn.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
+  }
+  {  // errors: a pair that names a missing cloud is refused on the calling thread; a cloud with a non-finite point fails its own
+     // batch at collect -- after every rank has been through the collective -- and the aligner stays usable
+    std::vector<apdgicp_pair> bad_pairs = pairs;
+    bad_pairs.back().source_cloud = (int32_t)clouds.size() + 3;
+    uint64_t t = 0;
+    errors_ok = errors_ok && sharded.enqueue(clouds, bad_pairs, &t) < 0;
+    std::vector<float> poisoned = store[(size_t)pairs[0].source_cloud];
+    poisoned[7] = std::nanf("");
+    std::vector<fast_gicp::ShardCloud> bad_clouds = clouds;
+    bad_clouds[(size_t)pairs[0].source_cloud].xyz = poisoned.data();
+    errors_ok = errors_ok && sharded.enqueue(bad_clouds, pairs, &t) == 0 && sharded.collect(t, &res) < 0;
+    errors_ok = errors_ok && sharded.align(clouds, pairs, &res) == 0 && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
   }
   // ---- candidate selection: every pair whose target is the target of pair 0 is a candidate of that keyframe
   fast_gicp::LoopVerifierHip verifier(&prm, 0);
@@ -120,7 +166,7 @@ int main(int argc, char** argv) {
   const auto& c2 = clouds[(size_t)pairs[0].source_cloud];
   const double fs = infcalc.calc_fitness_score(c1.xyz, c1.n, c2.xyz, c2.n, 12, relpose);
   infcalc.calc_information_matrix(c1.xyz, c1.n, c2.xyz, c2.n, 12, relpose, inf);
-  std::printf("world %d pairs %d sharded_equals_single %d gathered_on_all_ranks %d loop_best %d loop_score %.17g candidates %zu fitness %.17g inf00 %.17g inf33 %.17g\n", D,
-              np, same, all_ranks, match.best, match.best_score, cand.size(), fs, inf[0], inf[3 + 6 * 3]);
-  return same && all_ranks ? 0 : 1;
+  std::printf("world %d pairs %d sharded_equals_single %d gathered_on_all_ranks %d pipelined_equals_single %d errors_ok %d loop_best %d loop_score %.17g candidates %zu fitness %.17g inf00 %.17g inf33 %.17g\n", D,
+              np, same, all_ranks, pipelined, errors_ok, match.best, match.best_score, cand.size(), fs, inf[0], inf[3 + 6 * 3]);
+  return same && all_ranks && pipelined && errors_ok ? 0 : 1;
 }

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""How much could "parity unpinned" bite?  The one fp32 operation whose ORDER the restatement had to assume is
+`pt = trans.cast<float>() * input_->at(i).getVector4fMap()` (fast_apdgicp_impl.hpp:149): the oracle and the HIP kernels evaluate
+((r0 x + r1 y) + r2 z) + t (Eigen's coefficient-based product).  This script re-runs the CPU oracle with five other plausible
+orders (FMA packet code, other associations; oracle/apdgicp_ref.cpp:xf_row) on seeded pairs and reports, against order 0:
+the fraction of points whose transformed position differs in at least one bit, the number of correspondences that change at
+the first linearize, and the change of the registered pose.  CPU only (no GPU, no reference).  Prints one JSON object."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref as R  # noqa
+scene = importlib.import_module("riv-slam_amd.scene")
+
+ORDERS = {0: "((r0 x + r1 y) + r2 z) + t   [reference order assumed]", 1: "fma(r2,z, fma(r1,y, r0 x)) + t", 2: "r0 x + (r1 y + (r2 z + t))",
+          3: "(r0 x + r1 y) + (r2 z + t)", 4: "fma(r0,x, fma(r1,y, fma(r2,z, t)))", 5: "fma(r2,z, fma(r1,y, fma(r0,x, t)))"}
+LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+LM_TIGHT = dict(max_correspondence_distance=2.0, transformation_epsilon=1e-4, azimuth_variance_deg=1.0)
+GN = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+N_PAIRS = int(os.environ.get("PAIRS", 24))
+L = R.lib()
+out = {"orders": ORDERS, "pairs_per_config": N_PAIRS, "configs": {}}
+for tag, kw, kind, n in (("lm_launch_odometry_8k", LM, "odometry", 8192), ("lm_tight_loop_4k", LM_TIGHT, "loop", 4096), ("gn20_odometry_8k", GN, "odometry", 8192)):
+    worst = {o: {"t_m": 0.0, "r_rad": 0.0, "corr_changed_first_linearize": 0, "iterations_changed": 0} for o in ORDERS if o}
+    for p in range(N_PAIRS):
+        src, tgt, _, guess = scene.make_pair(n, n, scene.pair_seed(40, p), kind)
+        g = guess if kind == "odometry" else np.eye(4, dtype=np.float32)
+        base = None
+        for o in ORDERS:
+            L.ref_set_transform_order(o)
+            h = R.RefAPDGICP(R.default_params(**kw))
+            h.setInputSource(src), h.setInputTarget(tgt)
+            h.linearize(np.asarray(g, dtype=np.float64))
+            corr = h.correspondences()[0].copy()
+            T = h.align(g)
+            if o == 0:
+                base = (T, corr, h.nr_iterations)
+                continue
+            te, re_ = scene.pose_error(base[0], T)
+            w = worst[o]
+            w["t_m"], w["r_rad"] = max(w["t_m"], te), max(w["r_rad"], re_)
+            w["corr_changed_first_linearize"] = max(w["corr_changed_first_linearize"], int(np.sum(corr != base[1])))
+            w["iterations_changed"] += int(h.nr_iterations != base[2])
+    L.ref_set_transform_order(0)
+    out["configs"][tag] = {str(o): worst[o] for o in worst}
+out["tolerance"] = "north_star: 1e-3 m / 1e-4 rad"
+out["max_over_everything"] = {"t_m": max(w["t_m"] for c in out["configs"].values() for w in c.values()),
+                              "r_rad": max(w["r_rad"] for c in out["configs"].values() for w in c.values())}
+print(json.dumps(out, indent=1))

@@ -24,8 +24,33 @@ def build_exe():
     return EXE
 
 
+def build_bench():
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_sharded")
+    lib_dir = os.path.join(ROOT, "riv-slam_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "riv-slam_amd", "cpp"), os.path.join(ROOT, "tests", "cpp", "bench_sharded.cpp"),
+                           "-L", lib_dir, "-lapdgicp_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-o", exe])
+    return exe
+
+
+def write_batch_file(path, clouds, pairs, guesses):
+    """the file format of tests/cpp/test_multi_device.cpp and bench_sharded.cpp"""
+    with open(path, "wb") as f:
+        np.array([len(clouds)], dtype=np.int32).tofile(f)
+        for c in clouds:
+            np.array([len(c)], dtype=np.int32).tofile(f)
+            np.ascontiguousarray(c[:, :3], dtype=np.float32).tofile(f)
+        np.array([len(pairs)], dtype=np.int32).tofile(f)
+        for (s_, t_), g in zip(pairs, guesses):
+            np.array([s_, t_], dtype=np.int32).tofile(f)
+            np.asfortranarray(g).T.astype(np.float32).tofile(f)
+
+
 def test_multi_device_harness_compiles_and_links():
     exe = build_exe()
+    assert subprocess.run([build_bench()], capture_output=True, text=True, timeout=120).stdout.startswith("compile-only")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "compile-only" in out.stdout
 
@@ -70,6 +95,7 @@ def test_sharded_cpp_equals_single_handle_and_python_verifier(scene, pkg, tmp_pa
     vals = dict(zip(tok[0::2], tok[1::2]))
     assert int(vals["world"]) >= 1 and int(vals["pairs"]) == 7
     assert vals["sharded_equals_single"] == "1" and vals["gathered_on_all_ranks"] == "1"
+    assert vals["pipelined_equals_single"] == "1" and vals["errors_ok"] == "1"
     # the C++ selection == the Python mirror of LoopDetector::matching on the same candidates
     kw = dict(max_correspondence_distance=2.0, transformation_epsilon=0.01, azimuth_variance_deg=1.0)
     b = reg.BatchAPDGICP(reg.default_params(**kw))
@@ -87,3 +113,34 @@ def test_sharded_cpp_equals_single_handle_and_python_verifier(scene, pkg, tmp_pa
     fs = calc.calc_fitness_score(clouds[pairs[0][1]], clouds[pairs[0][0]], T0)
     inf = im.information_from_fitness(calc.params, fs)
     assert float(vals["fitness"]) == fs and float(vals["inf00"]) == inf[0, 0] and float(vals["inf33"]) == inf[3, 3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ("gn", "lm"))
+def test_cpp_pipelined_bench_records_equal_the_python_path(scene, tmp_path, optimizer):
+    """tests/cpp/bench_sharded.cpp (the C++ caller's form of bench.py's step: device-resident clouds re-registered every batch,
+    several batches in flight per device, one all-gather per batch): its records must be those of a Python batch handle."""
+    exe = build_bench()
+    reg = importlib.import_module("riv-slam_amd.registration")
+    P, n = 8, 3000
+    clouds, pairs, guesses = [], [], []
+    for p in range(P):
+        s, t, _, g = scene.make_pair(n, n, scene.pair_seed(2, p), "odometry" if optimizer == "gn" else "loop")
+        clouds += [s, t]
+        pairs.append((2 * p, 2 * p + 1))
+        guesses.append(g if optimizer == "gn" else np.eye(4, dtype=np.float32))
+    path, out_path = tmp_path / "bench.bin", tmp_path / "records.bin"
+    write_batch_file(path, clouds, pairs, guesses)
+    out = subprocess.run([exe, str(path), optimizer, "6", "2", str(out_path)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    rep = json.loads(line)
+    assert rep["records_stable"] == 1 and rep["pairs_per_device"] == P
+    kw = (dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+          if optimizer == "gn" else dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0))
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    b.set_clouds(0, clouds)
+    want = b.align(pairs, guesses)
+    assert open(out_path, "rb").read() == want.tobytes()

@@ -65,7 +65,7 @@ def test_cov_vs_oracle_2k_and_ragged(reg, scene):
 
 def test_cov_k_values(reg, golden):
     cloud = golden["lin_source"][:700]
-    for k in (5, 10, 32):
+    for k in (5, 10, 32, 33, 48, 64):   # (beyond 32: the brute-force kernel with 128-entry lists)
         g = reg.FastAPDGICP(reg.default_params(k_correspondences=k, regularization=0))
         g.setInputSource(cloud)
         o = R.RefAPDGICP(R.default_params(k_correspondences=k, regularization=0))
@@ -367,7 +367,7 @@ def test_errors_are_codes_not_crashes(reg, golden):
         g.align(None)
     assert e.value.code == -4
     with pytest.raises(reg.ApdgicpError) as e:
-        g.setCorrespondenceRandomness(33)
+        g.setCorrespondenceRandomness(65)
     assert e.value.code == -5
     g.params.k_correspondences = 20
     with pytest.raises(reg.ApdgicpError):
@@ -525,6 +525,34 @@ def test_one_scan_against_eight_keyframes(reg, scene, mode):
     for k in (0, 7):
         g.setInputTarget(tgts[k])
         assert np.array_equal(reg.result_matrix(res[k]), g.align(guesses[k])), k
+
+
+@pytest.mark.parametrize("mode", ("lm_launch", "gn20"))
+def test_c3_one_scan_against_eight_keyframes_at_full_size(reg, scene, mode):
+    """BASELINE configs[2] at the size SURVEY 8d names: one 8192-point scan against the last 8 keyframes (8192 points each) in
+    one batch, keyframe covariances cached, a new scan every call.  Flags and iteration counts exact against the oracle, poses
+    inside north_star's tolerance (1e-3 m / 1e-4 rad), for the launch parameters (LM) and for 20 Gauss-Newton iterations."""
+    src, tgts, _, guesses = scene.make_keyframe_set(8192, 8192, 8, scene.pair_seed(3, 0))
+    kw = (dict(LAUNCH) if mode == "lm_launch" else
+          dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0))
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    si = b.add_cloud(src)
+    ti = [b.add_cloud(t) for t in tgts]
+    b.compute_covariances()
+    pairs = b.make_pairs([(si, t) for t in ti], guesses)
+    first = b.align(pairs).copy()
+    b.set_cloud(si, src)          # the next frame's call: the scan is registered again, the keyframes stay
+    res = b.align(pairs)
+    assert res.tobytes() == first.tobytes()
+    for k in range(8):
+        o = R.RefAPDGICP(R.default_params(**kw))
+        o.setInputSource(src)
+        o.setInputTarget(tgts[k])
+        To = o.align(guesses[k])
+        te, re_ = scene.pose_error(To, reg.result_matrix(res[k]))
+        assert te <= T_TOL and re_ <= R_TOL, (k, te, re_)
+        assert [res[k]["converged"], res[k]["iterations"], res[k]["n_linearize"], res[k]["n_compute_error"]] == \
+            [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error], k
 
 
 @pytest.mark.parametrize("optimizer", ("gn", "lm"))

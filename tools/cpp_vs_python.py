@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""The C++ multi-device host path against the Python one on the same box and the same pairs: 32 pairs of
+8192 points per device per batch, clouds resident in HBM and re-registered every batch.
+  gn: bench.py's step (odometry pairs, GN-20)      -- Python: four batch handles in flight; C++: ShardedBatchAlignerHip, 4 in flight
+  lm: SURVEY 8d's C4 shard (loop pairs from the identity, LM launch parameters) -- Python: one pooled handle, 8 in flight; C++: the same handle behind the aligner
+Prints one JSON object; records of the C++ runs are checked against the Python handles byte for byte."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch  # noqa
+import __graft_entry__ as ge  # noqa
+ge.build()
+reg = importlib.import_module("riv-slam_amd.registration")
+scene = importlib.import_module("riv-slam_amd.scene")
+import bench  # noqa
+import test_cpp_multi_device as T  # noqa
+
+P, N = 32, 8192
+exe = T.build_bench()
+out = {}
+tmp = os.environ.get("TMPDIR", "/tmp")
+for mode in ("gn", "lm"):
+    kind = "odometry" if mode == "gn" else "loop"
+    clouds, pairs, guesses = [], [], []
+    for p in range(P):
+        s, t, _, g = scene.make_pair(N, N, scene.pair_seed(2 if mode == "gn" else 4, p), kind)
+        clouds += [s, t]
+        pairs.append((2 * p, 2 * p + 1))
+        guesses.append(g if mode == "gn" else np.eye(4, dtype=np.float32))
+    path, rec = os.path.join(tmp, f"cppbench_{mode}.bin"), os.path.join(tmp, f"cppbench_{mode}.rec")
+    T.write_batch_file(path, clouds, pairs, guesses)
+    F = 4 if mode == "gn" else 8
+    best = None
+    for rep in range(3):
+        r = subprocess.run([exe, path, mode, "60", "12", rec, str(F), "1"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        best = j if best is None or j["ms_per_step"] < best["ms_per_step"] else best
+    # the Python path on the same pairs
+    params = bench.bench_params(reg) if mode == "gn" else reg.default_params(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+    d_clouds = [torch.from_numpy(c).cuda() for c in clouds]
+    if mode == "gn":
+        hs = [reg.BatchAPDGICP(params) for _ in range(4)]
+        for h in hs:
+            h.set_pair_groups(1)
+        arr, packed = hs[0].make_pairs(pairs, guesses), hs[0].pack_clouds(d_clouds)
+
+        def run(count):
+            tk, res = [None] * 4, None
+            for s in range(count):
+                h = hs[s % 4]
+                if tk[s % 4] is not None:
+                    res = h.align_collect(tk[s % 4])
+                h.set_clouds(0, packed, producer_wait=False)
+                tk[s % 4] = h.align_enqueue(arr)
+            for s in range(count, count + 4):
+                if tk[s % 4] is not None:
+                    res = hs[s % 4].align_collect(tk[s % 4])
+                    tk[s % 4] = None
+            return res
+    else:
+        b = reg.BatchAPDGICP(params)
+        packed = b.pack_clouds(d_clouds)
+        arrs = [b.make_pairs([(2 * P * f + 2 * i, 2 * P * f + 2 * i + 1) for i in range(P)], guesses) for f in range(F)]
+
+        def run(count):
+            tk, res = [None] * F, None
+            for s in range(count):
+                f = s % F
+                if tk[f] is not None:
+                    res = b.align_collect(tk[f])
+                b.set_clouds(2 * P * f, packed, producer_wait=False)
+                tk[f] = b.align_enqueue(arrs[f])
+            for s in range(count, count + F):
+                if tk[s % F] is not None:
+                    res = b.align_collect(tk[s % F])
+                    tk[s % F] = None
+            return res
+    run(12)
+    ts = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run(60)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 60 * 1e3)
+    out[mode] = {"cpp_ms_per_step": best["ms_per_step"], "python_ms_per_step": round(min(ts), 4), "cpp_over_python": round(best["ms_per_step"] / min(ts), 3),
+                 "in_flight": F, "records_byte_equal": open(rec, "rb").read() == res.tobytes(), "cpp": best}
+print(json.dumps(out))
