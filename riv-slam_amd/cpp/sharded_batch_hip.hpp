@@ -31,6 +31,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -76,7 +77,7 @@ class ShardedBatchAlignerHip {
     }
     // Order matters for speed, not for correctness: the HIP runtime deals the streams of a process onto its hardware queues
     // in creation order, so the handles (whose streams carry the registrations) come first, RCCL's internal streams and the
-    // two service streams of every rank after them (measured: docs/experiments.md).
+    // gather stream of every rank after them (measured: docs/experiments.md).
     for (int r = 0; r < D; r++) ranks_.emplace_back(new Rank);
     for (int r = 0; r < D; r++) {
       Rank& k = *ranks_[(size_t)r];
@@ -103,8 +104,7 @@ class ShardedBatchAlignerHip {
     }
     for (int r = 0; r < D; r++) {
       Rank& k = *ranks_[(size_t)r];
-      if (hipSetDevice(devices[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&k.gstream, hipStreamNonBlocking) != hipSuccess ||
-          hipStreamCreateWithFlags(&k.cstream, hipStreamNonBlocking) != hipSuccess) {
+      if (hipSetDevice(devices[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&k.gstream, hipStreamNonBlocking) != hipSuccess) {
         error_ = "stream creation failed on device " + std::to_string(devices[(size_t)r]);
         return;
       }
@@ -134,10 +134,10 @@ class ShardedBatchAlignerHip {
       for (Slot& s : k.slots) {
         if (s.send) (void)hipFree(s.send);
         if (s.recv) (void)hipFree(s.recv);
+        if (s.stage) (void)hipHostFree(s.stage);
         if (s.gathered) (void)hipEventDestroy(s.gathered);
       }
       if (k.gstream) (void)hipStreamDestroy(k.gstream);
-      if (k.cstream) (void)hipStreamDestroy(k.cstream);
     }
     for (ncclComm_t c : comms_)
       if (c) ncclCommDestroy(c);
@@ -252,8 +252,9 @@ class ShardedBatchAlignerHip {
   struct Slot {
     char* send = nullptr;
     char* recv = nullptr;
+    char* stage = nullptr;  // pinned host copy of the block's records on their way into `send`
     size_t send_cap = 0, recv_cap = 0;
-    hipEvent_t gathered = nullptr;
+    hipEvent_t gathered = nullptr;  // behind the slot's all-gather
     // worker-private until published under the rank's mutex
     uint64_t started_seq = 0, align_ticket = 0;
     bool busy = false;
@@ -273,12 +274,14 @@ class ShardedBatchAlignerHip {
     std::deque<std::unique_ptr<Job>> queue;
     bool stop = false, dead = false;
     uint64_t want = 0;
-    hipStream_t gstream = nullptr, cstream = nullptr;  // all-gathers; the copy of a block into its send buffer
+    hipStream_t gstream = nullptr;  // the all-gathers
     std::vector<apdgicp_batch*> handles;
     std::vector<Slot> slots;
     int cloud_cap = 64;  // pooled mode: cloud slots per batch in flight (grows; the descriptor table the handle uploads is as long as the highest slot)
     std::vector<const float*> ptrs;
     std::vector<int64_t> ns;
+    double t_collect = 0, t_post = 0, t_start = 0, t_idle = 0;  // worker-thread milliseconds (SHARDED_TIMING=1 prints them)
+    long n_fin = 0;
   };
 
   apdgicp_batch* handle_of(Rank& k, uint64_t seq) { return pooled_ ? k.handles[0] : k.handles[(size_t)(seq % (uint64_t)slots_)]; }
@@ -294,9 +297,12 @@ class ShardedBatchAlignerHip {
       if (hipEventSynchronize(s.gathered) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipEventSynchronize");
       if (s.send) (void)hipFree(s.send);
       if (s.recv) (void)hipFree(s.recv);
-      s.send = s.recv = nullptr, s.send_cap = s.recv_cap = 0;
+      if (s.stage) (void)hipHostFree(s.stage);
+      s.send = s.recv = s.stage = nullptr, s.send_cap = s.recv_cap = 0;
       const size_t cap = std::max<size_t>((size_t)job.per * rec * 2, 4096);
-      if (hipMalloc((void**)&s.send, cap) != hipSuccess || hipMalloc((void**)&s.recv, cap * D) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipMalloc");
+      if (hipMalloc((void**)&s.send, cap) != hipSuccess || hipMalloc((void**)&s.recv, cap * D) != hipSuccess ||
+          hipHostMalloc((void**)&s.stage, cap, hipHostMallocDefault) != hipSuccess)
+        return fail(APDGICP_ERR_HIP, "hipMalloc");
       s.send_cap = cap, s.recv_cap = cap * D;
     }
     if (job.pairs.empty()) return;
@@ -328,23 +334,29 @@ class ShardedBatchAlignerHip {
 
   // collects the slot's batch, issues its all-gather (always: a failed block contributes zeros) and publishes the outcome
   void finish(int r, Rank& k, Slot& s) {
+    const auto tf0 = std::chrono::steady_clock::now();
     int rc = s.start_rc;
     std::string msg = s.start_msg;
     (void)hipSetDevice(devices_[(size_t)r]);
     const size_t rec = sizeof(apdgicp_result);
-    void* d_res = nullptr;
-    if (rc == 0 && s.align_ticket) {
-      rc = apdgicp_batch_align_collect(handle_of(k, s.started_seq), s.align_ticket, &d_res, nullptr);
-      if (rc < 0) msg = std::string("apdgicp_batch_align_collect: ") + apdgicp_last_error();
-    }
     const size_t mine = (size_t)(s.s_end - s.s_begin) * rec, block = (size_t)s.s_per * rec;
-    bool gather_ok = s.send && s.recv && block <= s.send_cap;
+    bool gather_ok = s.send && s.recv && s.stage && block <= s.send_cap;
+    // The block's records come home with the batch's last poll (pinned memory): they go from the slot's own pinned staging
+    // buffer into its send buffer by an asynchronous copy IN FRONT of the gather on the gather stream.  Nothing here waits
+    // for the device -- on a busy GPU even a 3 KB copy kernel on a side stream waits a few hundred microseconds for a free
+    // CU, and a host thread that waits for it does not serve the handle's pair pool meanwhile (measured: 0.3 ms per batch).
+    if (gather_ok) memset(s.stage, 0, block);
+    if (rc == 0 && s.align_ticket && gather_ok) {
+      rc = apdgicp_batch_align_collect(handle_of(k, s.started_seq), s.align_ticket, nullptr, (apdgicp_result*)s.stage);
+      if (rc < 0) {
+        msg = std::string("apdgicp_batch_align_collect: ") + apdgicp_last_error();
+        memset(s.stage, 0, block);
+      }
+    }
+    const auto tf1 = std::chrono::steady_clock::now();
+    (void)mine;
     if (gather_ok) {
-      // the block goes into the slot's send buffer NOW, on a stream nothing else uses: the gather stream may sit behind an
-      // earlier collective that waits for a slower rank, and the handle reuses the record buffer a few batches later
-      if (hipMemsetAsync(s.send, 0, block, k.cstream) != hipSuccess) gather_ok = false;
-      if (gather_ok && rc == 0 && d_res && mine && hipMemcpyAsync(s.send, d_res, mine, hipMemcpyDeviceToDevice, k.cstream) != hipSuccess) gather_ok = false;
-      if (hipStreamSynchronize(k.cstream) != hipSuccess) gather_ok = false;
+      if (block && hipMemcpyAsync(s.send, s.stage, block, hipMemcpyHostToDevice, k.gstream) != hipSuccess) gather_ok = false;
       // every rank calls the collective, in ticket order; an empty or failed block contributes zeros
       if (block && world() == 1 && !gather_when_alone_) {  // one device: the "gather" is a copy
         if (hipMemcpyAsync(s.recv, s.send, block, hipMemcpyDeviceToDevice, k.gstream) != hipSuccess) gather_ok = false;
@@ -360,6 +372,9 @@ class ShardedBatchAlignerHip {
       s.issued_seq = s.started_seq, s.rc = rc, s.msg = msg, s.per = s.s_per, s.begin = s.s_begin, s.end = s.s_end;
     }
     k.cv.notify_all();
+    k.t_collect += std::chrono::duration<double, std::milli>(tf1 - tf0).count();
+    k.t_post += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count();
+    k.n_fin++;
   }
 
   void worker(int r) {
@@ -405,9 +420,14 @@ class ShardedBatchAlignerHip {
       }
       (void)hipSetDevice(devices_[(size_t)r]);
       (void)hipEventSynchronize(s.gathered);  // the gather that last read this slot's buffers
+      const auto ts0 = std::chrono::steady_clock::now();
       start(r, k, s, *job);
+      k.t_start += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
       inflight.push_back(job->seq);
     }
+    if (std::getenv("SHARDED_TIMING") && k.n_fin)
+      std::fprintf(stderr, "[sharded] rank %d: %ld batches; per batch: collect %.3f ms, gather issue %.3f ms, start %.3f ms\n", r, k.n_fin, k.t_collect / k.n_fin,
+                   k.t_post / k.n_fin, k.t_start / k.n_fin);
     {
       std::lock_guard<std::mutex> g(k.mu);
       k.dead = true;
