@@ -750,9 +750,26 @@ class Engine {
     APD_HIP(hipSetDevice(device));
     APD_TRY(upload_desc());
     APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), cstream));
+    long long total = 0;
+    for (int id : ids) total += clouds[id].n;
+    if (fuse_first_search && defer_errflag && !pool.on && knn_pruned && nn_pruned && params.k_correspondences <= KNN_NC && ids.size() <= 2 && total < 40000) {
+      pending_knn = ids;  // apdgicp_align: launched together with the cold search of the first tick (k_knn_and_search)
+      return 0;
+    }
     APD_TRY(launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), cstream));
     if (!defer_errflag) APD_TRY(check_errflag("k_knn_cov"));
     return 0;
+  }
+  // apdgicp_align sets fuse_first_search around its set-up and run: the covariance launch of the clouds set since the last align
+  // is held back (pending_knn) and goes out with the first tick's search; anything else that could need the covariances first
+  // calls flush_pending_knn
+  bool fuse_first_search = false;
+  std::vector<int> pending_knn;
+  int flush_pending_knn() {
+    if (pending_knn.empty()) return 0;
+    const std::vector<int> ids = pending_knn;
+    pending_knn.clear();
+    return launch_knn(ids.data(), d_ids.as<int>(), (int)ids.size(), stream);
   }
   // the listed clouds that still need covariances, validated, without duplicates
   int filter_cov_ids(const std::vector<int>& ids_in, bool force, std::vector<int>& ids) {
@@ -815,6 +832,7 @@ class Engine {
   // K = 8: 0.90 / 0.92 / 0.92 ms with 1 / 2 / 3 groups, K = 12: 1.12 / 0.98 / 1.02, K = 24: 1.41 / 1.23 / 1.17)
   bool keep_maha = true;  // false for batch handles: nothing reads mahalanobis_ there unless the optimiser is LM (k_error)
   int max_groups = 1 << 30;  // apdgicp_batch_set_pair_groups: a caller that keeps several batches (handles) in flight wants one group each
+  int ngroups_for_first_tick() const { return group_count(); }
   int group_count() const { return std::max(1, std::min<int>(std::min<int>(ngroups_cfg, max_groups), (npairs + 4) / 8)); }
   int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
@@ -1036,7 +1054,29 @@ class Engine {
   // one tick of the state machines of the pairs in `sp`
   int launch_tick(Span sp) {
     nn_cap = gate_cap();
-    const int rc_nn = launch_nn(sp);
+    int rc_nn = 0;
+    if (!pending_knn.empty()) {
+      const long long tick_blocks = (long long)sp.np * ((t_nmax_src() + 63) / 64);
+      if (init_tick && sp.np == 1 && !in_pool && !nn_W && tick_blocks <= 256 && !(profile_nn && (cur_tick + profile_phase) % profile_stride == 0)) {
+        // one launch: the covariances of the clouds just set + this tick's cold search (k_knn_and_search)
+        int nmax = 0;
+        for (int id : pending_knn) nmax = std::max(nmax, clouds[id].n);
+        const int tasks = (nmax + 3) / 4, knn_blocks = ((int)pending_knn.size() * tasks + 7) / 8;
+        Work w = t_work();
+        w.pair0 = sp.p0, w.cap = nn_cap, w.init = d_guess.as<Rigid>();
+        last_nn_kernel = "k_knn_and_search";
+        hipLaunchKernelGGL(k_knn_and_search, dim3((unsigned)(knn_blocks + (t_nmax_src() + 63) / 64)), dim3(512), (size_t)8 * knn_coop_lds_bytes(4), sp.st,
+                           d_desc.as<CloudDesc>(), d_ids.as<int>(), (int)pending_knn.size(), tasks, params.k_correspondences, params.regularization,
+                           d_errflag.as<int>(), d_stats.as<unsigned long long>(), t_pairs(), (const PairState*)t_state(), w);
+        for (int id : pending_knn) clouds[id].cov_valid = true;
+        pending_knn.clear();
+      } else {
+        rc_nn = flush_pending_knn();
+        if (rc_nn == 0) rc_nn = launch_nn(sp);
+      }
+    } else {
+      rc_nn = launch_nn(sp);
+    }
     nn_cap = std::numeric_limits<float>::infinity();
     APD_TRY(rc_nn);
     APD_TRY(launch_linearize(sp, 2));
@@ -1134,6 +1174,7 @@ class Engine {
     // the fused optimiser builds the state in the last block of the first k_linearize (Work::init): one launch less per
     // align.  The arrival counters reset themselves; only a run that ended in an error may have left them mid-count
     fold_init = nn_pruned && tick_cap > 0 && !tickets_dirty;
+    if (!fold_init || ngroups_for_first_tick() > 1) APD_TRY(flush_pending_knn());  // (the fused launch belongs to the folded first tick on the main stream)
     if (!fold_init) {
       hipLaunchKernelGGL(k_init_state, dim3((npairs + 63) / 64), dim3(64), 0, stream, d_state.as<PairState>(), d_guess.as<Rigid>(), npairs,
                          params.max_iterations, b_ticket.as<int>());

@@ -1078,15 +1078,13 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
 }
 
 template <int S, int W>
-__global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+__device__ __forceinline__ void nn_pruned_block(const PairDesc* pairs, const PairState* st, const Work& w, unsigned bx, unsigned by) {
   __shared__ float4 txy[W][kGroupPts / 2];
   __shared__ float2 tz[W][kGroupPts / 2];
   __shared__ float cbl[W][6 * kGroupChunks];
   __shared__ float gbl[6 * GB_BATCH];
   __shared__ unsigned long long mrg[W > 1 ? W * 64 * S : 1];
   __shared__ float2 mrg2[W > 1 ? W * 64 * S : 1];
-  unsigned bx, by;
-  xcd_remap(bx, by);
   const int pair = pair_of(w, by);
   if (pair < 0) return;  // (pooled batches: the launch was sized for more pairs than are still running)
   const int status = w.init ? (int)ST_NEED_LIN : st[pair].status;  // status, descriptors and pose: one round of scalar loads, not three
@@ -1110,6 +1108,13 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
     const int i = base + s * 64 + lane;
     if (i < N) out[i] = ((unsigned long long)__float_as_uint(best[s]) << 32) | bestc[s];
   }
+}
+
+template <int S, int W>
+__global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  nn_pruned_block<S, W>(pairs, st, w, bx, by);
 }
 
 // k_nn_compact: the same search for optimiser ticks in which many points keep their neighbour (nn_warm_start).  A wave pays
@@ -1359,19 +1364,17 @@ __device__ __forceinline__ unsigned long long group_or_u64(unsigned long long v)
 #ifndef APD_KNN_WPE
 #define APD_KNN_WPE 5
 #endif
+// The work of ONE wave: the 64 / L queries starting at bx * (64 / L) of cloud c; knn_smem: the wave's own knn_coop_lds_bytes(64 / L)
+// bytes of LDS.  (k_knn_cov_coop: one wave per block; k_knn_and_search: eight.)
 template <int L>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE, 8))) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
-                                                     unsigned long long* stats, int raw /* 1: store the population covariance, k_regularize_covs follows */) {
+__device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned bx, int lane, unsigned long long* knn_smem, int k, int reg, int* err_flag,
+                                                  unsigned long long* stats, int raw /* 1: store the population covariance, k_regularize_covs follows */) {
   constexpr int QPW = 64 / L, NCL = KNN_NC / L, KQ_CAP = knn_coop_cap(L), KQ_STRIDE = KQ_CAP + 1, EPL = KQ_CAP / L;  // queries per wave, classes and list entries per lane
   static_assert(L == 4 || L == 8 || L == 16, "L lanes per query");
   static_assert(KQ_CAP % L == 0 && KQ_CAP <= 64 && KQ_WIN % KNN_NC == 0, "layout");
-  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
   unsigned long long* lst = knn_smem;                            // [query][slot], padded row
   float* cml = (float*)knn_smem;                                 // phase A only: [query][33] class minima (the lists are still empty)
-  unsigned bx, by;
-  xcd_remap(bx, by);
-  const CloudDesc c = clouds[cloud_ids[by]];
-  const int n = c.n, lane = threadIdx.x;
+  const int n = c.n;
   const int base = (int)bx * QPW;
   if (base >= n) return;
   const float inf = __builtin_inff();
@@ -1392,7 +1395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE,
   int cnt = 0;  // entries in this query's list (same value in its L lanes)
   int idx_bits = 1;
   while ((1 << idx_bits) < n) idx_bits++;
-  __syncthreads();
+  wave_lds_fence();  // (the wave's own LDS region: no block barrier -- eight independent waves share a block in k_knn_and_search)
   float tau_q = inf;  // (L == 4) the k-th smallest class minimum
   {
     float cmp[NCL];  // minima of the classes sub + L*m
@@ -1483,11 +1486,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE,
   if constexpr (L == 4) {
     tau_d = tau_q;
   } else {
-  __syncthreads();
+  wave_lds_fence();
   float cm[KNN_NC];
 #pragma unroll
   for (int s = 0; s < KNN_NC; s++) cm[s] = cml[slot * (KNN_NC + 1) + s];
-  __syncthreads();  // cml aliases the lists
+  wave_lds_fence();  // cml aliases the lists
 #pragma unroll
   for (int kk = 2; kk <= KNN_NC; kk <<= 1) {
 #pragma unroll
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE,
     }
   }
   }
-  __syncthreads();
+  wave_lds_fence();
   if (stats) { const long long t = clock64(); tB += t - tm, tm = t; }
   if (stats && lane == 0) {
     atomicAdd(stats + 4, (unsigned long long)n_groups), atomicAdd(stats + 7, 1ull);
@@ -1763,6 +1766,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE,
   if (stats && lane == 0) atomicAdd(stats + 15, (unsigned long long)(clock64() - tm));  // rounds + regularisation
   auto cov = GW(c.cov);
   cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
+}
+
+template <int L>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(APD_KNN_WPE, 8))) void k_knn_cov_coop(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag,
+                                                     unsigned long long* stats, int raw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
+  unsigned bx, by;
+  xcd_remap(bx, by);
+  const CloudDesc c = clouds[cloud_ids[by]];
+  knn_cov_coop_wave<L>(c, bx, (int)threadIdx.x, knn_smem, k, reg, err_flag, stats, raw);
+}
+
+// k_knn_and_search: the covariance k-NN of one or two freshly set clouds AND the first, cold search of a single registration in ONE
+// launch.  The search needs the sorted clouds, not their covariances (those are first read by k_linearize behind it), so the two
+// are independent -- but a HIP stream runs them one after the other (hipExtAnyOrderLaunch is not supported on gfx9 boards, and a
+// second stream costs more in event hand-overs than it hides): 42 + 21.5 us of a 131 us odometry frame.  Blocks of 512 threads:
+// the first knn_blocks run eight k_knn_cov_coop<16> waves each (wave-task t = block * 8 + wave: cloud t / tasks_per_cloud,
+// queries 4 (t % tasks_per_cloud) ...; the wave index must be wave-uniform -- readfirstlane -- or the cloud descriptor becomes per-lane
+// data and the compiler's divergent code around the cross-lane operations goes wrong), the others are the blocks of k_nn_pruned<1, 8>.
+// Same device functions, same results: 42.3 + 21.5 us -> 44.3 us, the odometry frame 131 -> 118 us.
+__global__ __launch_bounds__(512) void k_knn_and_search(const CloudDesc* clouds, const int* cloud_ids, int knn_count, int tasks_per_cloud, int k, int reg,
+                                                        int* err_flag, unsigned long long* stats, const PairDesc* pairs, const PairState* st, Work w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long knn_smem[];
+  constexpr unsigned wpb = 8;
+  const unsigned knn_blocks = ((unsigned)(knn_count * tasks_per_cloud) + wpb - 1u) / wpb;
+  if (blockIdx.x < knn_blocks) {
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);  // (wave-uniform: the descriptor loads stay scalar)
+    const unsigned task = blockIdx.x * wpb + (unsigned)wid;
+    const unsigned by = task / (unsigned)tasks_per_cloud, bx = task % (unsigned)tasks_per_cloud;
+    if ((int)by >= knn_count) return;  // (a wave that has ended does not count at the block's barriers)
+    knn_cov_coop_wave<16>(clouds[cloud_ids[by]], bx, lane, knn_smem + wid * (knn_coop_lds_bytes(4) / 8), k, reg, err_flag, stats, 0);
+  } else {
+    nn_pruned_block<1, 8>(pairs, st, w, blockIdx.x - knn_blocks, 0u);
+  }
 }
 
 // fast_apdgicp_impl.hpp:326-357 for covariances stored raw by k_knn_cov_coop: one lane per point, in place (the same function

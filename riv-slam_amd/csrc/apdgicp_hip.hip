@@ -298,8 +298,16 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
     float g[16];
     if (guess) memcpy(g, guess, sizeof(g));
     else identity16(g);
-    APD_TRY(ensure_pair(h, g));
     Engine& e = h->eng;
+    struct Fuse {  // the covariance launch of freshly set clouds goes out with the first tick's search (k_knn_and_search)
+      Engine& e;
+      explicit Fuse(Engine& e_) : e(e_) { e.fuse_first_search = true; }
+      ~Fuse() {
+        e.fuse_first_search = false;
+        (void)e.flush_pending_knn();  // (only after an error on the way: nothing stays pending)
+      }
+    } fuse(e);
+    APD_TRY(ensure_pair(h, g));
     APD_TRY(e.upload_guesses(g, 1));  // no-op when ensure_pair has just uploaded it
     APD_TRY(e.run_align());
     if (const ResultRec* r = e.host_results()) {  // came home with the last poll

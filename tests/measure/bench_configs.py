@@ -106,6 +106,29 @@ for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
         return b.align(pairs4)
     ms = timed(c4, 10)
     res = c4()
+    # ONE handle, ONE host thread, eight batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
+    # (include/apdgicp_hip.h); GN batches: two record buffers, so two in flight
+    F4 = 8 if tag == "lm_launch" else 2
+    b8 = reg.BatchAPDGICP(reg.default_params(**kw))
+    pairs8 = [b8.make_pairs([(2 * P4 * f + s_, 2 * P4 * f + t_) for s_, t_ in pr4], gs4) for f in range(F4)]
+    packed8 = b8.pack_clouds(cl4)
+
+    def c4_in_flight(count=24):
+        tk, last = [None] * F4, None
+        for s_i in range(count):
+            f = s_i % F4
+            if tk[f] is not None:
+                last = b8.align_collect(tk[f])
+            b8.set_clouds(2 * P4 * f, packed8, producer_wait=False)
+            tk[f] = b8.align_enqueue(pairs8[f])
+        for s_i in range(count, count + F4):
+            if tk[s_i % F4] is not None:
+                last = b8.align_collect(tk[s_i % F4])
+                tk[s_i % F4] = None
+        return last
+    res8 = c4_in_flight(2 * F4)
+    ms_in_flight = timed(c4_in_flight, 4) / 24
+    assert res8.tobytes() == res.tobytes()
     # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
     hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(4)]
     for h_ in hs:
@@ -150,7 +173,12 @@ for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
         n_checked += 1
     time.sleep(0.5)
     its = [int(x) for x in res["n_linearize"]]
+    for h_ in hs:
+        h_.close()
+    b.close(), b8.close()     # (handles left alive keep their streams: the next section's handles would share hardware queues with them)
     out[f"C4_loop_32_pairs_{tag}"] = {"ms_per_batch_one_handle": round(ms, 3), "registrations_per_s_one_handle": round(P4 * 1e3 / ms, 1),
+                                      f"ms_per_batch_one_handle_one_thread_{F4}_in_flight": round(ms_in_flight, 3),
+                                      f"registrations_per_s_one_handle_one_thread_{F4}_in_flight": round(P4 * 1e3 / ms_in_flight, 1),
                                       "ms_per_batch_three_handles_in_flight": round(ms3, 3), "registrations_per_s_three_handles": round(P4 * 1e3 / ms3, 1),
                                       "ms_per_batch_four_host_threads": round(ms_thr, 3), "registrations_per_s_four_host_threads": round(P4 * 1e3 / ms_thr, 1),
                                       "n_linearize_histogram": {str(k_): its.count(k_) for k_ in sorted(set(its))},

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerates the judged evidence on the GPU box into gpurun_out/ev/ (copy the *.md / *.json you want judged into profiles/,
-# named per round).   usage: gpurun -- 'bash tools/refresh_evidence.sh r02'
+# named per round).   usage: gpurun -- 'bash tools/refresh_evidence.sh r03'
 #   kernel_stats.md      rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
 #   bench_profiled.json  the JSON line printed by that same profiled run (its roofline.avg_launch_ms must agree with the table)
 #   pmc_*.md             separate --pmc passes (never combined with other trace domains): HBM bytes and the issue-side SQ counters
 #   pmc_nn_latest.json   per-launch PMC numbers of the batch's nearest-neighbour launches (bench.py's roofline.traffic / roofline_issue)
 #   bench.json           the un-profiled default run
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ev=gpurun_out/ev; mkdir -p $ev
 DRV="python3 bench.py --gpus 1 --steps 20 --warmup 5"
@@ -31,6 +31,17 @@ pass occ GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_M
 dbs=$(for n in fetch write insts busy; do find $ev/p_$n -name "*.db" | head -1; done)
 python3 tools/pmc_nn_json.py $ev/pmc_nn_latest.json 8192 odometry $dbs > /dev/null && cp $ev/pmc_nn_latest.json profiles/pmc_nn_latest.json
 timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
+# the reference's optimiser on the C4 shard (bench.py --kind loop --optimizer lm): the JSON line and its kernel table
+timeout 600 python3 bench.py --kind loop --optimizer lm --no-cpu-baseline > $ev/bench_lm_loop.json 2> $ev/bench_lm.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks_lm -o k -- python3 bench.py --kind loop --optimizer lm --no-cpu-baseline --repeats 3 > /dev/null 2> $ev/ks_lm.err
+python3 tools/rocpd_summary.py $(find $ev/ks_lm -name "*.db" | head -1) "$tag: 'python3 bench.py --kind loop --optimizer lm' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats_lm_loop.md
+python3 tools/rocpd_pool_ticks.py $(find $ev/ks_lm -name "*.db" | head -1) 20 > $ev/lm_pool_ticks.txt
+find $ev/ks_lm -type f ! -name "*.db" -delete
+# the other BASELINE configs, the odometry protocol through the C++ adapter, the C++ multi-device path against the Python one
+timeout 900 python3 tests/measure/bench_configs.py > $ev/other_configs.json 2> $ev/other_configs.err
+timeout 600 python3 tests/measure/odometry_protocol.py > $ev/odometry_protocol.json 2> $ev/odometry.err
+timeout 900 python3 tools/cpp_vs_python.py 2> $ev/cpp_vs_python.err | tail -1 > $ev/cpp_vs_python.json
+timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
 for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ; do rm -rf $d; done
 find $ev/ks -type f ! -name "*.db" -delete
 head -c 1500 $ev/bench.json; echo
