@@ -18,6 +18,22 @@ reg = importlib.import_module("riv-slam_amd.registration")
 scene = importlib.import_module("riv-slam_amd.scene")
 import ref as R  # noqa
 
+SECTIONS = ("C2", "C3", "C4_lm_launch", "C4_gn20", "C5")
+if len(sys.argv) < 2:
+    # every section in a process of its own: handles left over from an earlier section keep their HIP streams, and the runtime
+    # deals new streams onto its hardware queues behind them -- a one-handle batch with three pair groups measured 2.66 ms
+    # behind the LM section against 1.66 ms alone
+    import subprocess
+    merged = {}
+    for sec in SECTIONS:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), sec], capture_output=True, text=True, timeout=1200)
+        if r.returncode != 0:
+            sys.exit(r.stderr[-4000:])
+        merged.update(json.loads(r.stdout.strip().splitlines()[-1]))
+    print(json.dumps(merged, indent=1))
+    sys.exit(0)
+ONLY = sys.argv[1]
+
 GN = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0,
           azimuth_variance_deg=1.0)
 LM_LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
@@ -34,178 +50,187 @@ def timed(f, reps):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-# ---- C2: one 8k x 8k registration at a time (both clouds fresh / target cached), GN-20 and LM with the launch parameters
-s, t, _, g = scene.make_pair(8192, 8192, scene.pair_seed(2, 0), "odometry")
-ds, dt = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
-for tag, kw in (("gn20", GN), ("lm_launch", LM_LAUNCH)):
-    h = reg.FastAPDGICP(reg.default_params(**kw))
+def section_c2():
+    # ---- C2: one 8k x 8k registration at a time (both clouds fresh / target cached), GN-20 and LM with the launch parameters
+    s, t, _, g = scene.make_pair(8192, 8192, scene.pair_seed(2, 0), "odometry")
+    ds, dt = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    for tag, kw in (("gn20", GN), ("lm_launch", LM_LAUNCH)):
+        h = reg.FastAPDGICP(reg.default_params(**kw))
 
-    def fresh():
-        h.setInputTarget(dt)
-        h.setInputSource(ds)
-        h.align(g)
+        def fresh():
+            h.setInputTarget(dt)
+            h.setInputSource(ds)
+            h.align(g)
 
-    def cached():
-        h.setInputTarget(dt, token=7)
-        h.setInputSource(ds)
-        h.align(g)
-    ms_f, ms_c = timed(fresh, 10), timed(cached, 10)   # before the oracle: its OpenMP team keeps spinning for a while after a run
-    o = R.RefAPDGICP(R.default_params(**kw))
-    o.setInputSource(s), o.setInputTarget(t)
-    t0 = time.perf_counter()
-    To = o.align(g)
-    cpu_ms = (time.perf_counter() - t0) * 1e3
-    time.sleep(0.5)
-    te, re_ = scene.pose_error(To, h.getFinalTransformation())
-    out[f"C2_{tag}"] = {"ms_both_fresh": round(ms_f, 3), "ms_target_cached": round(ms_c, 3), "n_linearize": int(h.result.n_linearize),
-                        "cpu_oracle_ms": round(cpu_ms, 1), "cpu_threads": o.num_threads, "t_err_m": te, "r_err_rad": re_}
-
-# ---- C3: one scan against the last 8 keyframes of the same street (targets cached, a new scan every call)
-src3, tgts3, _, gs3 = scene.make_keyframe_set(8192, 8192, 8, scene.pair_seed(3, 0))
-d3 = torch.from_numpy(src3).cuda()
-for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
-    b = reg.BatchAPDGICP(reg.default_params(**kw))
-    src_i = b.add_cloud(d3)
-    tg = [b.add_cloud(torch.from_numpy(t).cuda()) for t in tgts3]
-    b.compute_covariances()
-    pairs = b.make_pairs([(src_i, k) for k in tg], gs3)
-
-    def c3():
-        b.set_cloud(src_i, d3)       # a new scan: source covariances recomputed, keyframe covariances cached
-        return b.align(pairs)
-    ms = timed(c3, 10)
-    res = c3()
-    te_max = re_max = 0.0
-    for k in range(8):
+        def cached():
+            h.setInputTarget(dt, token=7)
+            h.setInputSource(ds)
+            h.align(g)
+        ms_f, ms_c = timed(fresh, 10), timed(cached, 10)   # before the oracle: its OpenMP team keeps spinning for a while after a run
         o = R.RefAPDGICP(R.default_params(**kw))
-        o.setInputSource(src3), o.setInputTarget(tgts3[k])
-        te, re_ = scene.pose_error(o.align(gs3[k]), reg.result_matrix(res[k]))
-        te_max, re_max = max(te_max, te), max(re_max, re_)
-    time.sleep(0.5)
-    out[f"C3_1x8_{tag}"] = {"ms_per_batch": round(ms, 3), "registrations_per_s": round(8e3 / ms, 1), "n_linearize": [int(x) for x in res["n_linearize"]],
-                            "t_err_m": te_max, "r_err_rad": re_max}
+        o.setInputSource(s), o.setInputTarget(t)
+        t0 = time.perf_counter()
+        To = o.align(g)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        time.sleep(0.5)
+        te, re_ = scene.pose_error(To, h.getFinalTransformation())
+        out[f"C2_{tag}"] = {"ms_both_fresh": round(ms_f, 3), "ms_target_cached": round(ms_c, 3), "n_linearize": int(h.result.n_linearize),
+                            "cpu_oracle_ms": round(cpu_ms, 1), "cpu_threads": o.num_threads, "t_err_m": te, "r_err_rad": re_}
 
-# ---- C4 as the survey specifies it (8d): loop-closure candidates -- t <= 3 m, yaw <= 20 deg, identity guess
-# (loop_detector.cpp:225), LM with the launch parameters -- 32 pairs per batch (the per-GPU shard of 256 over 8 GPUs), both
-# clouds fresh.  The first search of every pair is cold and far from the solution: the regime the warm-start pruning does not help.
-P4 = 32
-cl4, pr4, gs4, host4 = [], [], [], []
-for p in range(P4):
-    s_, t_, _, g_ = scene.make_pair(8192, 8192, scene.pair_seed(4, p), "loop")
-    host4.append((s_, t_, g_))
-    cl4 += [torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()]
-    pr4.append((2 * p, 2 * p + 1))
-    gs4.append(g_)
-for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
-    b = reg.BatchAPDGICP(reg.default_params(**kw))
-    pairs4 = b.make_pairs(pr4, gs4)
-    packed = b.pack_clouds(cl4)
 
-    def c4():
-        b.set_clouds(0, packed)
-        return b.align(pairs4)
-    ms = timed(c4, 10)
-    res = c4()
-    # ONE handle, ONE host thread, eight batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
-    # (include/apdgicp_hip.h); GN batches: two record buffers, so two in flight
-    F4 = 8 if tag == "lm_launch" else 2
-    b8 = reg.BatchAPDGICP(reg.default_params(**kw))
-    pairs8 = [b8.make_pairs([(2 * P4 * f + s_, 2 * P4 * f + t_) for s_, t_ in pr4], gs4) for f in range(F4)]
-    packed8 = b8.pack_clouds(cl4)
+def section_c3():
+    # ---- C3: one scan against the last 8 keyframes of the same street (targets cached, a new scan every call)
+    src3, tgts3, _, gs3 = scene.make_keyframe_set(8192, 8192, 8, scene.pair_seed(3, 0))
+    d3 = torch.from_numpy(src3).cuda()
+    for tag, kw in (("lm_launch", LM_LAUNCH), ("gn20", GN)):
+        b = reg.BatchAPDGICP(reg.default_params(**kw))
+        src_i = b.add_cloud(d3)
+        tg = [b.add_cloud(torch.from_numpy(t).cuda()) for t in tgts3]
+        b.compute_covariances()
+        pairs = b.make_pairs([(src_i, k) for k in tg], gs3)
 
-    def c4_in_flight(count=24):
-        tk, last = [None] * F4, None
-        for s_i in range(count):
-            f = s_i % F4
-            if tk[f] is not None:
-                last = b8.align_collect(tk[f])
-            b8.set_clouds(2 * P4 * f, packed8, producer_wait=False)
-            tk[f] = b8.align_enqueue(pairs8[f])
-        for s_i in range(count, count + F4):
-            if tk[s_i % F4] is not None:
-                last = b8.align_collect(tk[s_i % F4])
-                tk[s_i % F4] = None
-        return last
-    res8 = c4_in_flight(2 * F4)
-    ms_in_flight = timed(c4_in_flight, 4) / 24
-    assert res8.tobytes() == res.tobytes()
-    # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
-    hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(4)]
-    for h_ in hs:
-        h_.set_pair_groups(1)
+        def c3():
+            b.set_cloud(src_i, d3)       # a new scan: source covariances recomputed, keyframe covariances cached
+            return b.align(pairs)
+        ms = timed(c3, 10)
+        res = c3()
+        te_max = re_max = 0.0
+        for k in range(8):
+            o = R.RefAPDGICP(R.default_params(**kw))
+            o.setInputSource(src3), o.setInputTarget(tgts3[k])
+            te, re_ = scene.pose_error(o.align(gs3[k]), reg.result_matrix(res[k]))
+            te_max, re_max = max(te_max, te), max(re_max, re_)
+        time.sleep(0.5)
+        out[f"C3_1x8_{tag}"] = {"ms_per_batch": round(ms, 3), "registrations_per_s": round(8e3 / ms, 1), "n_linearize": [int(x) for x in res["n_linearize"]],
+                                "t_err_m": te_max, "r_err_rad": re_max}
 
-    def c4x3():
-        tk = []
-        for h_ in hs[:3]:
-            h_.set_clouds(0, packed)
-            tk.append(h_.align_enqueue(pairs4))
-        for h_, t_k in zip(hs[:3], tk):
-            h_.align_collect(t_k)
-    ms3 = timed(c4x3, 6) / 3
-    # an LM batch polls as it goes, so enqueue blocks; one host thread per handle keeps several of them in flight
-    import threading
 
-    def c4_threads(nthreads=4, reps=4):
-        def work(h_):
-            for _ in range(reps):
-                h_.set_clouds(0, packed)
-                h_.align(pairs4)
-        ths = [threading.Thread(target=work, args=(h_,)) for h_ in hs[:nthreads]]
-        for t_ in ths:
-            t_.start()
-        for t_ in ths:
-            t_.join()
-    c4_threads()
-    torch.cuda.synchronize()
-    t0_ = time.perf_counter()
-    c4_threads()
-    ms_thr = (time.perf_counter() - t0_) * 1e3 / (4 * 4)
-    te_max = re_max = 0.0
-    n_checked = 0
-    counts_equal = True
+def section_c4():
+    # ---- C4 as the survey specifies it (8d): loop-closure candidates -- t <= 3 m, yaw <= 20 deg, identity guess
+    # (loop_detector.cpp:225), LM with the launch parameters -- 32 pairs per batch (the per-GPU shard of 256 over 8 GPUs), both
+    # clouds fresh.  The first search of every pair is cold and far from the solution: the regime the warm-start pruning does not help.
+    P4 = 32
+    cl4, pr4, gs4, host4 = [], [], [], []
     for p in range(P4):
-        o = R.RefAPDGICP(R.default_params(**kw))
-        o.setInputSource(host4[p][0]), o.setInputTarget(host4[p][1])
-        To = o.align(host4[p][2])
-        te, re_ = scene.pose_error(To, reg.result_matrix(res[p]))
-        te_max, re_max = max(te_max, te), max(re_max, re_)
-        counts_equal &= bool(o.hasConverged()) == bool(res[p]["converged"]) and o.nr_iterations == int(res[p]["iterations"])
-        n_checked += 1
-    time.sleep(0.5)
-    its = [int(x) for x in res["n_linearize"]]
-    for h_ in hs:
-        h_.close()
-    b.close(), b8.close()     # (handles left alive keep their streams: the next section's handles would share hardware queues with them)
-    out[f"C4_loop_32_pairs_{tag}"] = {"ms_per_batch_one_handle": round(ms, 3), "registrations_per_s_one_handle": round(P4 * 1e3 / ms, 1),
-                                      f"ms_per_batch_one_handle_one_thread_{F4}_in_flight": round(ms_in_flight, 3),
-                                      f"registrations_per_s_one_handle_one_thread_{F4}_in_flight": round(P4 * 1e3 / ms_in_flight, 1),
-                                      "ms_per_batch_three_handles_in_flight": round(ms3, 3), "registrations_per_s_three_handles": round(P4 * 1e3 / ms3, 1),
-                                      "ms_per_batch_four_host_threads": round(ms_thr, 3), "registrations_per_s_four_host_threads": round(P4 * 1e3 / ms_thr, 1),
-                                      "n_linearize_histogram": {str(k_): its.count(k_) for k_ in sorted(set(its))},
-                                      "converged": int(np.sum(res["converged"])), "pairs_checked_vs_cpu": n_checked,
-                                      "converged_and_iterations_equal_cpu": bool(counts_equal), "t_err_m": te_max, "r_err_rad": re_max}
+        s_, t_, _, g_ = scene.make_pair(8192, 8192, scene.pair_seed(4, p), "loop")
+        host4.append((s_, t_, g_))
+        cl4 += [torch.from_numpy(s_).cuda(), torch.from_numpy(t_).cuda()]
+        pr4.append((2 * p, 2 * p + 1))
+        gs4.append(g_)
+    for tag, kw in ((("lm_launch", LM_LAUNCH),) if ONLY == "C4_lm_launch" else (("gn20", GN),)):
+        b = reg.BatchAPDGICP(reg.default_params(**kw))
+        pairs4 = b.make_pairs(pr4, gs4)
+        packed = b.pack_clouds(cl4)
 
-# ---- C5: 100k x 500k
-s5, t5, _, g5 = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
-d5s, d5t = torch.from_numpy(s5).cuda(), torch.from_numpy(t5).cuda()
-h = reg.FastAPDGICP(reg.default_params(**GN))
-h.setInputTarget(d5t, token=5)
-h.setInputSource(d5s, token=6)
-t0 = time.perf_counter()
-h.align(g5)
-first = (time.perf_counter() - t0) * 1e3
+        def c4():
+            b.set_clouds(0, packed)
+            return b.align(pairs4)
+        ms = timed(c4, 10)
+        res = c4()
+        # ONE handle, ONE host thread, eight batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
+        # (include/apdgicp_hip.h); GN batches: two record buffers, so two in flight
+        F4 = 8 if tag == "lm_launch" else 2
+        b8 = reg.BatchAPDGICP(reg.default_params(**kw))
+        pairs8 = [b8.make_pairs([(2 * P4 * f + s_, 2 * P4 * f + t_) for s_, t_ in pr4], gs4) for f in range(F4)]
+        packed8 = b8.pack_clouds(cl4)
+
+        def c4_in_flight(count=24):
+            tk, last = [None] * F4, None
+            for s_i in range(count):
+                f = s_i % F4
+                if tk[f] is not None:
+                    last = b8.align_collect(tk[f])
+                b8.set_clouds(2 * P4 * f, packed8, producer_wait=False)
+                tk[f] = b8.align_enqueue(pairs8[f])
+            for s_i in range(count, count + F4):
+                if tk[s_i % F4] is not None:
+                    last = b8.align_collect(tk[s_i % F4])
+                    tk[s_i % F4] = None
+            return last
+        res8 = c4_in_flight(2 * F4)
+        ms_in_flight = timed(c4_in_flight, 4) / 24
+        assert res8.tobytes() == res.tobytes()
+        # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
+        hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(4)]
+        for h_ in hs:
+            h_.set_pair_groups(1)
+
+        def c4x3():
+            tk = []
+            for h_ in hs[:3]:
+                h_.set_clouds(0, packed)
+                tk.append(h_.align_enqueue(pairs4))
+            for h_, t_k in zip(hs[:3], tk):
+                h_.align_collect(t_k)
+        ms3 = timed(c4x3, 6) / 3
+        # an LM batch polls as it goes, so enqueue blocks; one host thread per handle keeps several of them in flight
+        import threading
+
+        def c4_threads(nthreads=4, reps=4):
+            def work(h_):
+                for _ in range(reps):
+                    h_.set_clouds(0, packed)
+                    h_.align(pairs4)
+            ths = [threading.Thread(target=work, args=(h_,)) for h_ in hs[:nthreads]]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+        c4_threads()
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        c4_threads()
+        ms_thr = (time.perf_counter() - t0_) * 1e3 / (4 * 4)
+        te_max = re_max = 0.0
+        n_checked = 0
+        counts_equal = True
+        for p in range(P4):
+            o = R.RefAPDGICP(R.default_params(**kw))
+            o.setInputSource(host4[p][0]), o.setInputTarget(host4[p][1])
+            To = o.align(host4[p][2])
+            te, re_ = scene.pose_error(To, reg.result_matrix(res[p]))
+            te_max, re_max = max(te_max, te), max(re_max, re_)
+            counts_equal &= bool(o.hasConverged()) == bool(res[p]["converged"]) and o.nr_iterations == int(res[p]["iterations"])
+            n_checked += 1
+        time.sleep(0.5)
+        its = [int(x) for x in res["n_linearize"]]
+        for h_ in hs:
+            h_.close()
+        b.close(), b8.close()     # (handles left alive keep their streams: the next section's handles would share hardware queues with them)
+        out[f"C4_loop_32_pairs_{tag}"] = {"ms_per_batch_one_handle": round(ms, 3), "registrations_per_s_one_handle": round(P4 * 1e3 / ms, 1),
+                                          f"ms_per_batch_one_handle_one_thread_{F4}_in_flight": round(ms_in_flight, 3),
+                                          f"registrations_per_s_one_handle_one_thread_{F4}_in_flight": round(P4 * 1e3 / ms_in_flight, 1),
+                                          "ms_per_batch_three_handles_in_flight": round(ms3, 3), "registrations_per_s_three_handles": round(P4 * 1e3 / ms3, 1),
+                                          "ms_per_batch_four_host_threads": round(ms_thr, 3), "registrations_per_s_four_host_threads": round(P4 * 1e3 / ms_thr, 1),
+                                          "n_linearize_histogram": {str(k_): its.count(k_) for k_ in sorted(set(its))},
+                                          "converged": int(np.sum(res["converged"])), "pairs_checked_vs_cpu": n_checked,
+                                          "converged_and_iterations_equal_cpu": bool(counts_equal), "t_err_m": te_max, "r_err_rad": re_max}
 
 
-def c5():
-    h.align(g5)                 # covariances cached: 20 GN iterations only
-ms = timed(c5, 3)
-o = R.RefAPDGICP(R.default_params(**GN))
-o.setInputSource(s5), o.setInputTarget(t5)
-t0 = time.perf_counter()
-To = o.align(g5)
-cpu_ms = (time.perf_counter() - t0) * 1e3
-te, re_ = scene.pose_error(To, h.getFinalTransformation())
-out["C5_100k_x_500k"] = {"ms_first_align_incl_sort_and_covariances": round(first, 1), "ms_per_align_cached": round(ms, 2),
-                         "ms_per_gn_iter": round(ms / 20, 3), "cpu_oracle_ms_incl_covariances": round(cpu_ms, 1), "cpu_threads": o.num_threads,
-                         "t_err_m": te, "r_err_rad": re_}
-print(json.dumps(out, indent=1))
+def section_c5():
+    # ---- C5: 100k x 500k
+    s5, t5, _, g5 = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
+    d5s, d5t = torch.from_numpy(s5).cuda(), torch.from_numpy(t5).cuda()
+    h = reg.FastAPDGICP(reg.default_params(**GN))
+    h.setInputTarget(d5t, token=5)
+    h.setInputSource(d5s, token=6)
+    t0 = time.perf_counter()
+    h.align(g5)
+    first = (time.perf_counter() - t0) * 1e3
+
+
+    def c5():
+        h.align(g5)                 # covariances cached: 20 GN iterations only
+    ms = timed(c5, 3)
+    o = R.RefAPDGICP(R.default_params(**GN))
+    o.setInputSource(s5), o.setInputTarget(t5)
+    t0 = time.perf_counter()
+    To = o.align(g5)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    te, re_ = scene.pose_error(To, h.getFinalTransformation())
+    out["C5_100k_x_500k"] = {"ms_first_align_incl_sort_and_covariances": round(first, 1), "ms_per_align_cached": round(ms, 2),
+                             "ms_per_gn_iter": round(ms / 20, 3), "cpu_oracle_ms_incl_covariances": round(cpu_ms, 1), "cpu_threads": o.num_threads,
+                             "t_err_m": te, "r_err_rad": re_}
+
+{"C2": section_c2, "C3": section_c3, "C4_lm_launch": section_c4, "C4_gn20": section_c4, "C5": section_c5}[ONLY]()
+print(json.dumps(out))

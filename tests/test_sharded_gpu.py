@@ -89,3 +89,76 @@ def test_bench_force_dist_prints_world_size_and_rccl_version():
     d = json.loads(lines[0])
     assert d["world_size"] == 1 and d["rccl_version"] and d["n_gpus"] == 1 and d["timing"]["repeats"] == 3
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["bound"] == "hbm"
+
+
+CHILD2 = textwrap.dedent("""
+    # one of TWO ranks that share GPU 0: the product engine (HIP batch) on every rank, the records gathered with gloo (two
+    # ranks on one device cannot form an RCCL communicator; the partition, the engine and the gather call are the real ones)
+    import importlib, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["APD_ROOT"])
+    reg = importlib.import_module("riv-slam_amd.registration")
+    scene = importlib.import_module("riv-slam_amd.scene")
+    sharded = importlib.import_module("riv-slam_amd.sharded")
+    rank, world, P = int(os.environ["RANK"]), 2, int(os.environ["APD_PAIRS"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    params = reg.default_params(max_correspondence_distance=2.0, transformation_epsilon=0.01, azimuth_variance_deg=1.0)
+    b = reg.BatchAPDGICP(params, device=0)
+
+    class Engine:
+        def align_block(self, idx):
+            clouds, guesses = [], []
+            for p in idx:
+                s, t, _, g = scene.make_pair(1500 + 100 * p, 1800, scene.pair_seed(12, p), "loop" if p % 2 else "odometry")
+                clouds += [s, t]
+                guesses.append(g)
+            if not idx:
+                return torch.zeros((0, 96), dtype=torch.uint8)
+            b.set_clouds(0, clouds)
+            return torch.from_numpy(b.align([(2 * i, 2 * i + 1) for i in range(len(idx))], guesses).view(np.uint8).reshape(len(idx), 96).copy())
+
+    al = sharded.ShardedBatchAligner(Engine())
+    assert al.world == 2 and al.my_block(P) == sharded.block_partition(P, 2)[rank]
+    out = al.align(P)
+    if rank == 1:     # the rank that did NOT register the first block holds everything too
+        open(os.environ["APD_OUT"], "wb").write(out.numpy().tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pairs", (6, 5))
+def test_two_ranks_share_one_gpu_with_the_product_engine(tmp_path, scene, n_pairs):
+    """World size 2 on the hardware there is: two processes, each with its own HIP batch handle on GPU 0, block partition,
+    one all-gather of the 96-byte records (gloo: RCCL refuses two ranks on one device).  Every record must equal the one a
+    single handle computes for the same pair."""
+    import importlib
+    import numpy as np
+    reg = importlib.import_module("riv-slam_amd.registration")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script, out_path = tmp_path / "child2.py", tmp_path / "gathered.bin"
+    script.write_text(CHILD2)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, APD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", APD_PAIRS=str(n_pairs),
+                   APD_OUT=str(out_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-3000:] for o in outs)
+    got = np.frombuffer(open(out_path, "rb").read(), dtype=reg.RESULT_DTYPE)
+    assert len(got) == n_pairs
+    params = reg.default_params(max_correspondence_distance=2.0, transformation_epsilon=0.01, azimuth_variance_deg=1.0)
+    single = reg.BatchAPDGICP(params)
+    clouds, guesses = [], []
+    for p in range(n_pairs):
+        s_, t_, _, g = scene.make_pair(1500 + 100 * p, 1800, scene.pair_seed(12, p), "loop" if p % 2 else "odometry")
+        clouds += [s_, t_]
+        guesses.append(g)
+    single.set_clouds(0, clouds)
+    want = single.align([(2 * i, 2 * i + 1) for i in range(n_pairs)], guesses)
+    assert got.tobytes() == want.tobytes()
