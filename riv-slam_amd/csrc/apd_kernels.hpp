@@ -2326,27 +2326,30 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 // one lane: the optimiser step once H, b and the cost are in the state
 __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws) {
   s.n_lin += 1;
-  if (c.optimizer == 1) {  // step_gn
+  const bool gn = c.optimizer == 1;
+  if (gn) {  // step_gn
     s.lambda = 0.0;
-    lm_trial(s, ws);
+  } else {
+    if (s.lambda < 0.0) {  // L:131-133
+      double mx = 0.0;
+      for (int q = 0; q < 6; q++) mx = fmax(mx, fabs(s.H[q + 6 * q]));
+      s.lambda = c.lm_init_lambda_factor * mx;
+    }
+    s.nu = 2.0;
+    s.inner = 0;
+    if (c.lm_max_iterations <= 0) {  // the for loop at L:136 never runs -> return false
+      step_done(s, c, false);
+      return;
+    }
+  }
+  lm_trial(s, ws);  // (ONE call site: two inlined copies of the solve and the trigonometry doubled the one-lane region's register demand)
+  if (gn) {
     s.x0 = s.xi;
     for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
     step_done(s, c, true);
-    return;
+  } else {
+    s.status = ST_NEED_ERR;
   }
-  if (s.lambda < 0.0) {  // L:131-133
-    double mx = 0.0;
-    for (int q = 0; q < 6; q++) mx = fmax(mx, fabs(s.H[q + 6 * q]));
-    s.lambda = c.lm_init_lambda_factor * mx;
-  }
-  s.nu = 2.0;
-  s.inner = 0;
-  if (c.lm_max_iterations <= 0) {  // the for loop at L:136 never runs -> return false
-    step_done(s, c, false);
-    return;
-  }
-  lm_trial(s, ws);
-  s.status = ST_NEED_ERR;
 }
 
 // after k_error: L:145-172 (one lane)
