@@ -1,5 +1,5 @@
 """Times calculate_covariances alone (k_knn_cov_*): 64 clouds of 8192 points by default.
-usage: python tools/knn_time.py [n_clouds] [n_points]; env APDGICP_KNN_QPW / APDGICP_KNN_COOP / APDGICP_STATS"""
+usage: python tools/knn_time.py [n_clouds] [n_points]; env APDGICP_STATS=1 prints the per-wave phase timers"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
