@@ -854,6 +854,29 @@ def test_pinned_cloud_buffers_are_reused_safely(reg, scene):
             assert np.array_equal(T2, fresh(src2, tgt, guess)[0]), (rnd, k)
 
 
+def test_a_host_cloud_replaced_by_a_device_cloud_before_any_align(reg, scene):
+    """A scan-sized host cloud stays in the slot's pinned buffer until the sort reads it (`staged`); replacing the slot through
+    apdgicp_batch_set_clouds(on_device = 1) -- or clearing it -- before any align must void that pinned copy: the registration has
+    to use the LATEST points (the flag used to survive, and the sort read the old host cloud)."""
+    import torch
+    kw = dict(max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    old_src, old_tgt, _, _ = scene.make_pair(8192, 8192, scene.pair_seed(13, 0), "odometry")
+    src, tgt, _, guess = scene.make_pair(8192, 6000, scene.pair_seed(13, 1), "odometry")
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    b.set_cloud(0, old_src)          # host clouds of the tiled-sort size class: staged, not yet sorted
+    b.set_cloud(1, old_tgt)
+    b.set_clouds(0, [torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()])   # same slots, device memory, another size
+    got = b.align([(0, 1)], [guess])
+    fresh = reg.BatchAPDGICP(reg.default_params(**kw))
+    fresh.set_clouds(0, [src, tgt])
+    want = fresh.align([(0, 1)], [guess])
+    assert got.tobytes() == want.tobytes()
+    # and the other way round: device first, then a host cloud into the same slot
+    b.set_clouds(0, [torch.from_numpy(old_src).cuda(), torch.from_numpy(old_tgt).cuda()])
+    b.set_cloud(0, src), b.set_cloud(1, tgt)
+    assert b.align([(0, 1)], [guess]).tobytes() == want.tobytes()
+
+
 def test_exact_ties_resolve_to_the_lowest_original_index(reg):
     """A source point exactly midway between two target points (equal fp32 distances, far apart on the
     Z-curve) and duplicated target points: the oracle's rule is (distance, index) lexicographic."""
