@@ -180,3 +180,30 @@ def test_c4_shard_at_full_size(reg, scene):
         assert te <= T_TOL and re_ <= R_TOL, (p, te, re_)
         assert [r0[p]["converged"], r0[p]["iterations"], r0[p]["n_linearize"], r0[p]["n_compute_error"]] == \
             [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error], p
+
+
+def test_pool_list_longer_than_one_poll_round(reg, scene):
+    """k_pool_poll compacts the list of running pairs 256 entries per round: two batches of 300 and 270 small pairs in flight
+    (a list of up to 570 entries, several rounds per poll, finished pairs leaving from every part of it) must give the records of
+    the host-polled loop, and a third batch admitted while the first two still run must too."""
+    kw = dict(max_correspondence_distance=2.5, transformation_epsilon=1e-3, azimuth_variance_deg=1.0)
+    base_clouds, base_guesses = [], []
+    for p in range(12):
+        s, t, _, g = scene.make_pair(600 + 37 * p, 700, scene.pair_seed(370, p), "loop" if p % 3 else "odometry")
+        base_clouds += [s, t]
+        base_guesses.append(g if p % 3 == 0 else np.eye(4, dtype=np.float32))
+    sizes = (300, 270, 40)
+    b = reg.BatchAPDGICP(reg.default_params(**kw))
+    b.set_clouds(0, base_clouds)      # 24 clouds shared by every pair of every batch: nothing is replaced while batches fly
+    batches = []
+    for k, n in enumerate(sizes):
+        idx = [(7 * i + 3 * k) % 12 for i in range(n)]
+        batches.append(([(2 * j, 2 * j + 1) for j in idx], [base_guesses[j] for j in idx]))
+    tickets = [b.align_enqueue(pairs, guesses) for pairs, guesses in batches]
+    got = [b.align_collect(t) for t in (tickets[1], tickets[0], tickets[2])]
+    ref_b = reg.BatchAPDGICP(reg.default_params(**kw))
+    ref_b.set_clouds(0, base_clouds)
+    for g, k in zip(got, (1, 0, 2)):
+        want = polled_align(ref_b, *batches[k])
+        assert len(g) == sizes[k] and g.tobytes() == want.tobytes(), k
+    assert len(set(int(x) for x in got[1]["n_linearize"])) > 3
