@@ -1406,12 +1406,20 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
     // The whole window lies inside the cloud unless the cloud is smaller than the window: a per-element bound check made
     // the compiler branch around every load and wait for each one on its own (32 dependent round trips to memory per wave)
     if (n >= KQ_WIN) {
+      if constexpr (L == 16) {  // eight points per lane: every load in flight together (one round trip instead of four)
+        float4 t[KQ_WIN / L];
+#pragma unroll
+        for (int u = 0; u < KQ_WIN / L; u++) t[u] = G(c.pts)[w0 + sub + L * u];
+#pragma unroll
+        for (int u = 0; u < KQ_WIN / L; u++) cmp[u % NCL] = fminf(cmp[u % NCL], sqdist1(t[u].x, t[u].y, t[u].z, q.x, q.y, q.z));
+      } else {
       for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
         float4 t[NCL];
 #pragma unroll
         for (int m = 0; m < NCL; m++) t[m] = G(c.pts)[w0 + sub + L * (t0 + m)];
 #pragma unroll
         for (int m = 0; m < NCL; m++) cmp[m] = fminf(cmp[m], sqdist1(t[m].x, t[m].y, t[m].z, q.x, q.y, q.z));
+      }
       }
     } else {
       for (int t0 = 0; t0 < KQ_WIN / L; t0 += NCL) {
@@ -1476,6 +1484,50 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
 #pragma unroll
       for (int r = 1; r < 8; r++) pick = ((k - 1) & 7) == r ? v[r] : pick;
       cmp[0] = __uint_as_float((unsigned)__shfl((int)pick, owner + ((k - 1) >> 3), 64));
+    } else if constexpr (L == 16) {
+      // Sixteen lanes per query: the 32 class minima sit two per lane (classes sub and 16 + sub) and are sorted where they are,
+      // position p = 16 r + sub, by the same all-ascending bitonic network -- partners in another lane of the 16-lane row come by
+      // DPP (quad_perm, row_half_mirror, row_mirror, row_ror:8, row_shl/shr:4), partners 16 positions away are the lane's other
+      // register: about 130 instructions.  (Until round 3 every one of the 16 lanes read all 32 minima back from LDS and ran
+      // the full 32-key network on its own: 720 instructions, a quarter of this variant's wave.)
+      unsigned v0 = __float_as_uint(cmp[0]), v1 = __float_as_uint(cmp[1]);
+      auto dpp = [](unsigned x, auto ctrl_) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl_)::value, 0xf, 0xf, false); };
+      using IC = std::integral_constant<int, 0>;
+      (void)sizeof(IC);
+      auto lane_stage = [&](auto ctrl_, int low_bit) {  // partner (r, sub ^ J) through DPP control `ctrl_`; the smaller key stays where sub & low_bit == 0
+        const bool lower = (sub & low_bit) == 0;
+        const unsigned o0 = dpp(v0, ctrl_), o1 = dpp(v1, ctrl_);
+        v0 = lower ? min(v0, o0) : max(v0, o0);
+        v1 = lower ? min(v1, o1) : max(v1, o1);
+      };
+      auto xor4_stage = [&]() {  // lane ^ 4: row_shl:4 (lane + 4) / row_shr:4 (lane - 4), chosen by lane bit 2
+        const bool lower = (sub & 4) == 0;
+        // (both moves by EVERY lane, then the choice: written as `lower ? shl : shr` the compiler branches, and a DPP move executed
+        // by half of the lanes reads its sources from the inactive other half)
+        const unsigned up0 = dpp(v0, std::integral_constant<int, 0x104>{}), dn0 = dpp(v0, std::integral_constant<int, 0x114>{});
+        const unsigned up1 = dpp(v1, std::integral_constant<int, 0x104>{}), dn1 = dpp(v1, std::integral_constant<int, 0x114>{});
+        const unsigned o0 = lower ? up0 : dn0, o1 = lower ? up1 : dn1;
+        v0 = lower ? min(v0, o0) : max(v0, o0);
+        v1 = lower ? min(v1, o1) : max(v1, o1);
+      };
+      const std::integral_constant<int, 0xB1> X1{};    // quad_perm [1,0,3,2]: lane ^ 1
+      const std::integral_constant<int, 0x4E> X2{};    // quad_perm [2,3,0,1]: lane ^ 2
+      const std::integral_constant<int, 0x1B> M3{};    // quad_perm [3,2,1,0]: lane ^ 3
+      const std::integral_constant<int, 0x141> M7{};   // row_half_mirror: lane ^ 7
+      const std::integral_constant<int, 0x140> M15{};  // row_mirror: lane ^ 15
+      const std::integral_constant<int, 0x128> X8{};   // row_ror:8: lane ^ 8
+      lane_stage(X1, 1);                                                       // kk = 2
+      lane_stage(M3, 2), lane_stage(X1, 1);                                    // kk = 4
+      lane_stage(M7, 4), lane_stage(X2, 2), lane_stage(X1, 1);                 // kk = 8
+      lane_stage(M15, 8), xor4_stage(), lane_stage(X2, 2), lane_stage(X1, 1);  // kk = 16
+      {  // kk = 32: p <-> p ^ 31 = (r ^ 1, sub ^ 15): register 0 keeps the minimum with the mirrored register 1
+        const unsigned m0 = dpp(v0, M15), m1 = dpp(v1, M15);
+        v0 = min(v0, m1), v1 = max(v1, m0);
+      }
+      lane_stage(X8, 8), xor4_stage(), lane_stage(X2, 2), lane_stage(X1, 1);
+      // the k-th smallest: position k - 1 = register (k - 1) >> 4 of lane (k - 1) & 15 of the query's row
+      const unsigned pick = ((k - 1) >> 4) ? v1 : v0;
+      cmp[0] = __uint_as_float((unsigned)__shfl((int)pick, owner + ((k - 1) & 15), 64));
     } else {
 #pragma unroll
       for (int m = 0; m < NCL; m++) cml[slot * (KNN_NC + 1) + sub + L * m] = cmp[m];
@@ -1483,7 +1535,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
     tau_q = cmp[0];
   }
   float tau_d = inf;
-  if constexpr (L == 4) {
+  if constexpr (L == 4 || L == 16) {
     tau_d = tau_q;
   } else {
   wave_lds_fence();
