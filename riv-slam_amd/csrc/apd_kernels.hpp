@@ -1665,6 +1665,18 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
         qm &= qm - 1;
         const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
         n_pairs++;
+#if defined(APD_PROBE_SALU) || defined(APD_PROBE_VALU)
+        {  // issue probe (tools/probe_issue.sh, docs/experiments.md): n extra independent scalar / vector instructions per step
+          int t_ = 0;
+#if defined(APD_PROBE_SALU)
+#pragma unroll
+          for (int u_ = 0; u_ < APD_PROBE_SALU; u_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_));
+#else
+#pragma unroll
+          for (int u_ = 0; u_ < APD_PROBE_VALU; u_++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
+#endif
+        }
+#endif
         unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
                                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
         const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
