@@ -233,6 +233,10 @@ int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int
  * between calls while batches are in flight (a worker thread waiting for its next job) calls this in between so that the GPU
  * does not run out of enqueued ticks.  No-op for Gauss-Newton handles and when nothing is in flight. */
 int apdgicp_batch_pump(apdgicp_batch* b);
+/* 1 when apdgicp_batch_align_enqueue runs batches through the pair pool with the handle's current parameters (Levenberg-Marquardt,
+ * pruned search, APDGICP_LM_POOL != 0): up to eight batches in flight on this one handle; 0: two record buffers, one batch at a
+ * time per handle for LM.  For callers that choose their pipelining accordingly (ShardedBatchAlignerHip). */
+int apdgicp_batch_is_pooled(apdgicp_batch* b);
 /* A batch runs as up to three pair groups on three HIP streams (about 8 pairs per group), which is the best a single handle
  * can do.  A caller that keeps several HANDLES busy at once -- batch s on handle s % 3, each enqueued before the previous
  * ones are collected -- does better with one group (= one stream, larger launches) per handle: one handle's covariance

@@ -86,16 +86,17 @@ class ShardedBatchAlignerHip {
         error_ = "hipSetDevice failed on device " + std::to_string(devices[(size_t)r]);
         return;
       }
-      const int nh = pooled_ ? 1 : slots_;
-      for (int h = 0; h < nh; h++) {
+      for (int h = 0; h < (pooled_ ? 1 : slots_); h++) {
         apdgicp_batch* b = nullptr;
         if (apdgicp_batch_create(&params_, devices[(size_t)r], nullptr, &b) != 0) {
           error_ = std::string("apdgicp_batch_create: ") + apdgicp_last_error();
           return;
         }
-        if (nh > 1) apdgicp_batch_set_pair_groups(b, 1);  // several handles share the GPU: one stream, larger launches each
+        if (r == 0 && h == 0) pooled_ = pooled_ && apdgicp_batch_is_pooled(b) == 1;  // (the library decides: APDGICP_LM_POOL=0 / brute-force search run LM one batch per handle)
         k.handles.push_back(b);
       }
+      if (!pooled_)
+        for (apdgicp_batch* b : k.handles) apdgicp_batch_set_pair_groups(b, slots_ > 1 ? 1 : 3);  // several handles share the GPU: one stream, larger launches each
     }
     if (ncclCommInitAll(comms_.data(), D, devices.data()) != ncclSuccess) {
       error_ = "ncclCommInitAll failed";

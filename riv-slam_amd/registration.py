@@ -89,7 +89,7 @@ SYMBOLS = [
     "apdgicp_batch_wait_producer", "apdgicp_get_stream", "apdgicp_batch_get_stream",
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
-    "apdgicp_batch_align_async", "apdgicp_batch_pump", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
+    "apdgicp_batch_align_async", "apdgicp_batch_pump", "apdgicp_batch_is_pooled", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
     "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_last_nn_kernel", "apdgicp_batch_debug_stats",
     "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
