@@ -1233,46 +1233,44 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
-// Threshold for the kth smallest (1-based) of the up-to-3 keys per lane (a key equal to ~0ull is
-// "absent"): returns tk such that exactly kth keys are <= tk.  Most-significant-bit-first radix select
-// on wave-uniform ballot masks -- no cross-lane data movement.  The descent stops as soon as every
-// key still in play is selected (tk = prefix | ones below; typically after ~15-20 of the 32 + lo_bits
-// steps), so tk need not be a key itself.  Bits [lo_bits, 32) of the low word are known to be zero
-// (original indices are < 2^lo_bits).  Needs kth <= number of present keys.
-__device__ __forceinline__ unsigned long long wave_kth_smallest3(unsigned long long a, unsigned long long b, unsigned long long c, int kth,
-                                                                 int lo_bits) {
-  unsigned long long la = __ballot(a != ~0ull), lb = __ballot(b != ~0ull), lc = __ballot(c != ~0ull);
-  int live = __popcll(la) + __popcll(lb) + __popcll(lc);
-  const unsigned ah = (unsigned)(a >> 32), bh = (unsigned)(b >> 32), ch = (unsigned)(c >> 32);
-  const unsigned al = (unsigned)a, bl = (unsigned)b, cl = (unsigned)c;
-  unsigned pre_hi = 0, pre_lo = 0;
-  for (int bit = 31; bit >= 0; bit--) {
-    const unsigned m = 1u << bit;
-    if (live == kth) return ((unsigned long long)(pre_hi | (m | (m - 1u))) << 32) | 0xFFFFFFFFull;
-    const unsigned long long za = la & __ballot((ah & m) == 0), zb = lb & __ballot((bh & m) == 0), zc = lc & __ballot((ch & m) == 0);
-    const int c0 = __popcll(za) + __popcll(zb) + __popcll(zc);
-    if (kth <= c0) {
-      la = za, lb = zb, lc = zc, live = c0;
+// A threshold tk with k <= #{keys <= tk} <= keep_max among the up-to-3 keys per lane (~0ull = absent; the keys are unique and more
+// than keep_max of them are present): bisection by rank with the keys themselves as probes -- the key in the lowest lane still
+// between the bounds, its rank counted with two or three ballots; a probe outside [k, keep_max] becomes the new lower or upper
+// bound.  A key of every rank exists, so some probe ends inside the window: about log2(n / (keep_max - k)) + 1 probes of ~20
+// instructions each.  Enough for tightening a full list: tau stays an upper bound of the k-th neighbour distance, the list shrinks
+// to at most keep_max entries.  (Until round 3 a most-significant-bit-first radix selection on ballot masks returned the EXACT k-th
+// smallest key: up to 32 + 13 bit steps of ~10 scalar instructions, 3 to 4 times per wave -- a fifth of the kernel's time:
+// 64 clouds 0.494 -> 0.404 ms with the window, whose lists keep up to twice as many entries and overflow 3.7 instead of 2.9 times.)
+__device__ __forceinline__ unsigned long long wave_kth_window3(unsigned long long a, unsigned long long b, unsigned long long c, int k, int keep_max) {
+  unsigned long long ea = __ballot(a != ~0ull), eb = __ballot(b != ~0ull), ec = __ballot(c != ~0ull);  // still between the bounds
+  for (;;) {
+    unsigned long long x;
+    if (ea) {
+      const int l = __builtin_ctzll(ea);
+      x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(a >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)a, l);
+    } else if (eb) {
+      const int l = __builtin_ctzll(eb);
+      x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
     } else {
-      kth -= c0, live -= c0;
-      la &= ~za, lb &= ~zb, lc &= ~zc;
-      pre_hi |= m;
+      const int l = __builtin_ctzll(ec);
+      x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(c >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)c, l);
     }
+    const int cnt = (int)(__popcll(__ballot(a <= x)) + __popcll(__ballot(b <= x)) + __popcll(__ballot(c <= x)));
+    if (cnt < k) ea &= __ballot(a > x), eb &= __ballot(b > x), ec &= __ballot(c > x);
+    else if (cnt > keep_max) ea &= __ballot(a < x), eb &= __ballot(b < x), ec &= __ballot(c < x);
+    else return x;
   }
-  for (int bit = lo_bits - 1; bit >= 0; bit--) {
-    const unsigned m = 1u << bit;
-    if (live == kth) return ((unsigned long long)pre_hi << 32) | (pre_lo | (m | (m - 1u)));
-    const unsigned long long za = la & __ballot((al & m) == 0), zb = lb & __ballot((bl & m) == 0), zc = lc & __ballot((cl & m) == 0);
-    const int c0 = __popcll(za) + __popcll(zb) + __popcll(zc);
-    if (kth <= c0) {
-      la = za, lb = zb, lc = zc, live = c0;
-    } else {
-      kth -= c0, live -= c0;
-      la &= ~za, lb &= ~zb, lc &= ~zc;
-      pre_lo |= m;
-    }
-  }
-  return ((unsigned long long)pre_hi << 32) | pre_lo;
+}
+// base + number of set bits of `mask` below this lane
+__device__ __forceinline__ int mbcnt_add(unsigned long long mask, int base) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
+}
+// mask bit of this lane ? a : b, with the mask where a ballot left it (written as `(m >> lane) & 1 ? a : b` the compiler rebuilds
+// the lane predicate with a compare of its own)
+__device__ __forceinline__ int lane_select(unsigned long long mask, int a, int b) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
 }
 // v_writelane_b32 with a constant lane (this toolchain has no builtin for it; one scalar source at most besides the lane)
 template <int LANE>
@@ -1310,7 +1308,10 @@ __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { retu
 //      sums in rank order (Mom9), cov = S2/k - m m^T (A:323-324), 3x3 Jacobi eigen-decomposition and the regularisation
 //      (A:326-357) -- in the epilogue for a single cloud, in k_regularize_covs for batches.
 // (The one-lane-per-query predecessor of this kernel, k_knn_cov_pruned, is in the history of round 2 and in docs/experiments.md.)
-constexpr int KQ_WIN = 128;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.683 / 0.674 / 0.675 / 0.695 / 0.735 ms (64 clouds)
+#ifndef APD_KNN_WIN
+#define APD_KNN_WIN 128
+#endif
+constexpr int KQ_WIN = APD_KNN_WIN;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.683 / 0.674 / 0.675 / 0.695 / 0.735 ms (64 clouds)
 // list entries per query -- 60 with 4 lanes per query (16 queries per wave: 7.8 KB of lists, what five resident waves per SIMD
 // leave of the LDS; 48 overflowed 3.8 times per wave, 60 does 2.9 times, and every overflow is a radix select of about 300
 // scalar instructions on the ONE scalar unit the four SIMDs share), 48 otherwise
@@ -1318,6 +1319,10 @@ constexpr int KQ_WIN = 128;  // window: measured 64 / 96 / 128 / 192 / 256 -> 0.
 #define APD_KNN_CAP4 60
 #endif
 __host__ __device__ constexpr int knn_coop_cap(int lanes_per_query) { return lanes_per_query == 4 ? APD_KNN_CAP4 : 48; }
+#ifndef APD_KNN_KEEP
+#define APD_KNN_KEEP 40
+#endif
+constexpr int KQ_KEEP = APD_KNN_KEEP;  // a full list is tightened to between k and this many entries (32 / 40 / 48: 0.409 / 0.404 / 0.406 ms)
 __host__ __device__ constexpr int knn_coop_lds_bytes(int qpw) { return qpw * (knn_coop_cap(64 / qpw) + 1) * 8; }  // lists only (boxes in registers, window from L1)
 
 template <int CTRL>
@@ -1328,20 +1333,29 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
 }
 // butterflies over aligned groups of L lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then (L >= 8) row_half_mirror and
 // (L == 16) row_mirror, which pair every lane with one of the other half once the halves are uniform
+// Keys as doubles.  A key is (bits of a finite non-negative float) << 32 | index: as an IEEE double that is a finite non-negative
+// number (the high word stays below 0x7F800000 < 0x7FF00000), and non-negative doubles order like their bit patterns -- so the
+// smaller / larger of two keys is ONE v_min_f64 / v_max_f64 instead of a 64-bit compare and two selects per word.  fp64
+// denormals are never flushed on this target (keys of tiny distances are denormal doubles), nothing here is a NaN: the
+// "absent" key of phase C is +infinity (kKeyInf), not ~0, which as a double would be a NaN that min / max drop.
+constexpr unsigned long long kKeyInf = 0x7FF0000000000000ull;
+// (the instructions themselves: through fmin() / fmax() the compiler first canonicalises every operand it has not produced itself)
+__device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b) {
+  unsigned long long r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned long long key_max(unsigned long long a, unsigned long long b) {
+  unsigned long long r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int L>
 __device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
-  unsigned long long o = dpp_u64<0xB1>(v);
-  v = o < v ? o : v;
-  o = dpp_u64<0x4E>(v);
-  v = o < v ? o : v;
-  if (L >= 8) {
-    o = dpp_u64<0x141>(v);  // row_half_mirror
-    v = o < v ? o : v;
-  }
-  if (L == 16) {
-    o = dpp_u64<0x140>(v);  // row_mirror: pairs the two (by now uniform) halves of the 16-lane row
-    v = o < v ? o : v;
-  }
+  v = key_min(v, dpp_u64<0xB1>(v));
+  v = key_min(v, dpp_u64<0x4E>(v));
+  if (L >= 8) v = key_min(v, dpp_u64<0x141>(v));   // row_half_mirror
+  if (L == 16) v = key_min(v, dpp_u64<0x140>(v));  // row_mirror: pairs the two (by now uniform) halves of the 16-lane row
   return v;
 }
 template <int CTRL>
@@ -1393,8 +1407,6 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
   Box mybox = G(c.gbox)[min(lane, ngroups - 1)];
   if (lane >= ngroups) mybox = nobox;  // lane g keeps the box of group gb0 + g in registers: no LDS copy
   int cnt = 0;  // entries in this query's list (same value in its L lanes)
-  int idx_bits = 1;
-  while ((1 << idx_bits) < n) idx_bits++;
   wave_lds_fence();  // (the wave's own LDS region: no block barrier -- eight independent waves share a block in k_knn_and_search)
   float tau_q = inf;  // (L == 4) the k-th smallest class minimum
   {
@@ -1660,11 +1672,14 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
       g = next_group();
       if (g >= 0) fetch(g);
       n_groups++;
+      n_pairs += (unsigned)__popcll(qm);
+      // (The scalar unit is what this loop waits for -- see the probe in docs/experiments.md -- so its bookkeeping is written for
+      // it: one s_bitset0 instead of the add / addc / and of `qm &= qm - 1`, the step counter outside, stores without exec-mask
+      // regions, the can't-happen check only behind a tightening.)
       while (qm) {
         const int qq = __builtin_ctzll(qm);  // owner lane of the query
-        qm &= qm - 1;
+        asm("s_bitset0_b64 %0, %1" : "+s"(qm) : "s"(qq));
         const float qx = readlane_f(q.x, qq), qy = readlane_f(q.y, qq), qz = readlane_f(q.z, qq);
-        n_pairs++;
 #if defined(APD_PROBE_SALU) || defined(APD_PROBE_VALU)
         {  // issue probe (tools/probe_issue.sh, docs/experiments.md): n extra independent scalar / vector instructions per step
           int t_ = 0;
@@ -1686,28 +1701,31 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
         if ((m0 | m1) == 0) continue;  // the box passed the test, none of its 128 points does
         int cntq = __builtin_amdgcn_readlane(cnt, qq);
         if (cntq + __popcll(m0) + __popcll(m1) > KQ_CAP) {
-          // List full: tau becomes the k-th smallest key of (stored keys U this group's hits); only
-          // keys <= tau survive.  tau only decreases, so nothing of the final answer is ever dropped,
-          // and exactly k keys remain afterwards (keys are unique), which always fits.
+          // List full: tau becomes a key of rank k .. KQ_KEEP among (stored keys U this group's hits); only keys <= tau survive.
+          // tau only decreases and stays >= the k-th smallest key seen, so nothing of the final answer is ever dropped, and at
+          // most KQ_KEEP keys remain afterwards, which always fits.
           const unsigned long long mine = lane < cntq ? row[lane] : ~0ull;  // KQ_CAP <= 64: one entry per lane
           const unsigned long long h0 = k0 <= tk ? k0 : ~0ull, h1 = k1 <= tk ? k1 : ~0ull;
-          tk = wave_kth_smallest3(mine, h0, h1, k, idx_bits);
+          tk = wave_kth_window3(mine, h0, h1, k, max(k, KQ_KEEP));
           const unsigned long long keep = __ballot(mine <= tk);
           if (mine <= tk) row[__popcll(keep & ((1ull << lane) - 1ull))] = mine;
           cntq = __popcll(keep);
           if (owner == qq) tau_hi = (unsigned)(tk >> 32), tau_lo = (unsigned)tk;
           m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
           n_compact++;
+          if (cntq + (int)__popcll(m0) + (int)__popcll(m1) > KQ_CAP) {  // impossible by construction (<= KQ_KEEP now); never silently wrong
+            if (lane == 0) atomicExch(err_flag, 4);
+            m0 = m1 = 0;
+          }
         }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int total = cntq + __popcll(m0) + __popcll(m1);
-        if (total > KQ_CAP) {  // impossible by construction (total == k after a tightening); never silently wrong
-          if (lane == 0) atomicExch(err_flag, 4);
-        } else {
-          if (k0 <= tk) row[cntq + __popcll(m0 & below)] = k0;
-          if (k1 <= tk) row[cntq + __popcll(m0) + __popcll(m1 & below)] = k1;
-          if (owner == qq) cnt = total;
-        }
+        const int n0 = cntq + (int)__popcll(m0), total = n0 + (int)__popcll(m1);
+        // Every lane stores both keys, the ones that are no hits into the row's spare slot (KQ_CAP: never read) -- as `if (hit)
+        // row[..] = key` each store sat in an exec-mask region of its own: s_and_saveexec, s_cbranch_execz, s_or exec per key.
+        // Slot = entries before + hits in lower lanes: v_mbcnt adds its count to an operand (as `popc(m & below)` the compiler
+        // builds two ANDs and two bit counts per key).
+        row[lane_select(m0, mbcnt_add(m0, cntq), KQ_CAP)] = k0;
+        row[lane_select(m1, mbcnt_add(m1, n0), KQ_CAP)] = k1;
+        if (owner == qq) cnt = total;
       }
     }
   }
@@ -1730,13 +1748,12 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
 #pragma unroll
   for (int t = 0; t < EPL; t++) {
     const int a = sub + L * t;
-    e[t] = a < cnt ? row[a] : ~0ull;
+    e[t] = a < cnt ? row[a] : kKeyInf;
   }
   {
     auto cx = [&](int a, int b) {
       const unsigned long long x = e[a], y = e[b];
-      const bool lt = x < y;
-      e[a] = lt ? x : y, e[b] = lt ? y : x;
+      e[a] = key_min(x, y), e[b] = key_max(x, y);
     };
     if constexpr (EPL == 3) {
       cx(0, 2), cx(0, 1), cx(1, 2);
@@ -1778,7 +1795,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
       for (int u = 0; u < L; u++) {
         if (t * L + u < k) {  // (uniform)
           unsigned long long bk = group_min_u64<L>(head);
-          if (bk == ~0ull) {
+          if (bk == kKeyInf) {
             atomicExch(err_flag, 2);
             bk = (unsigned long long)(unsigned)i;  // keeps the gathers in range
           }
@@ -1786,7 +1803,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
           if (head == bk) {  // keys are unique: one lane of the query
             head = next;
             cpos++;
-            next = cpos < EPL ? mine[cpos] : ~0ull;
+            next = cpos < EPL ? mine[cpos] : kKeyInf;
           }
         }
       }
@@ -2005,15 +2022,17 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     // APD sensor-noise covariance from the transformed point (A:167-184)
     const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
     const double aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
-    const double cos_aoa = cos(aoa);
+    double sin_aoa, cos_aoa;
+    sincos_pi(aoa, &sin_aoa, &cos_aoa);
+    (void)sin_aoa;
     const double s_x = dist * cst.dist_var / 400;
     const double s_y = dist * cst.sin_az / cos_aoa;
     const double s_z = dist * cst.sin_el / cos_aoa;
     const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
     const double azimuth = (double)atan2f(pty, ptx);
     double ce, se, caz, saz;
-    sincos(elevation, &se, &ce);
-    sincos(azimuth, &saz, &caz);
+    sincos_pi(elevation, &se, &ce);
+    sincos_pi(azimuth, &saz, &caz);
     // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
     const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
     const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
