@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Per-tick PMC counters of one GN-20 batch: lists the counter values of every k_nn_pruned / k_linearize dispatch in launch order.
+"""Per-tick PMC counters of one GN-20 batch: lists the counter values of every k_nn_pruned / k_nn_compact / k_linearize dispatch in launch order.
 usage: per_tick_pmc.py results.db"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select dispatch_id, kernel_name, grid_size_x, grid_size_y, counter_name, value from counters_collection "
-                  "where kernel_name like '%k_nn_pruned%' or kernel_name like '%k_linearize%' or kernel_name like '%knn_cov%' order by dispatch_id").fetchall()
+                  "where kernel_name like '%k_nn_pruned%' or kernel_name like '%k_nn_compact%' or kernel_name like '%k_linearize%' or kernel_name like '%knn_cov%' order by dispatch_id").fetchall()
 by = {}
 for d, k, gx, gy, c, v in rows:
     by.setdefault(d, [k.split("(")[0].replace("void apd::", ""), gx, gy, {}])[3][c] = v
