@@ -1251,9 +1251,11 @@ __device__ __forceinline__ unsigned long long wave_kth_window3(unsigned long lon
     } else if (eb) {
       const int l = __builtin_ctzll(eb);
       x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
-    } else {
+    } else if (ec) {
       const int l = __builtin_ctzll(ec);
       x = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(c >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)c, l);
+    } else {
+      return ~0ull;  // no key left between the bounds: cannot happen with unique keys; the caller's capacity check reports it, nothing spins
     }
     const int cnt = (int)(__popcll(__ballot(a <= x)) + __popcll(__ballot(b <= x)) + __popcll(__ballot(c <= x)));
     if (cnt < k) ea &= __ballot(a > x), eb &= __ballot(b > x), ec &= __ballot(c > x);

@@ -135,6 +135,26 @@ def test_cov_duplicate_points(reg):
     assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
 
 
+def test_cov_lists_overflow_many_times_bitwise_vs_brute_force(reg):
+    """The four-lanes-per-query k-NN (>= 100 000 points per launch) keeps at most 60 candidates per query and tightens a full
+    list to a key of rank k .. 40 by bisection.  Dense clusters (hundreds of points inside a query's first bound), exact
+    duplicates (equal distances, ordered by index) and a sparse background make lists overflow again and again; the
+    covariances must stay those of the brute-force kernel, bit for bit."""
+    rng = np.random.default_rng(11)
+    centres = rng.uniform(-40, 40, size=(300, 3)).astype(np.float32)
+    clusters = (centres[:, None, :] + rng.normal(0, 0.02, size=(300, 250, 3)).astype(np.float32)).reshape(-1, 3)   # 75 000
+    dup = np.repeat(rng.uniform(-40, 40, size=(1500, 3)).astype(np.float32), 10, axis=0)                           # 15 000, each point 10 times
+    back = rng.uniform(-60, 60, size=(20_000, 3)).astype(np.float32)
+    cloud = np.concatenate([clusters, dup, back])
+    cloud = cloud[rng.permutation(len(cloud))]
+    assert len(cloud) >= 100_000
+    for k in (20, 32):
+        a, b = _fresh(reg, "pruned", regularization=0, k_correspondences=k), _fresh(reg, "brute", regularization=0, k_correspondences=k)
+        a.setInputSource(cloud)
+        b.setInputSource(cloud)
+        assert np.array_equal(a.getSourceCovariances(), b.getSourceCovariances()), k
+
+
 # ------------------------------------------------------------------ linearize / compute_error (a7-a9)
 @pytest.mark.parametrize("tag,kw", (("default", {}), ("launch", LAUNCH)))
 def test_linearize_golden(reg, golden, tag, kw):
