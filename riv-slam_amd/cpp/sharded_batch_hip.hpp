@@ -62,9 +62,9 @@ inline std::vector<std::pair<int64_t, int64_t>> block_partition(int64_t n_pairs,
 
 class ShardedBatchAlignerHip {
  public:
-  /// devices: HIP device indices, one rank each (rank r = devices[r]); in_flight: batches kept in flight per device (1 .. 8)
+  /// devices: HIP device indices, one rank each (rank r = devices[r]); in_flight: batches kept in flight per device (Gauss-Newton: 1 .. 8 handles; pooled Levenberg-Marquardt: up to the pool's lanes, 16)
   ShardedBatchAlignerHip(const apdgicp_params* params, const std::vector<int>& devices, int in_flight = 4)
-      : devices_(devices), slots_(std::max(1, std::min(8, in_flight))) {
+      : devices_(devices), slots_(std::max(1, std::min(32, in_flight))) {
     const int D = (int)devices.size();
     apdgicp_params dflt;
     apdgicp_default_params(&dflt);
@@ -92,7 +92,12 @@ class ShardedBatchAlignerHip {
           error_ = std::string("apdgicp_batch_create: ") + apdgicp_last_error();
           return;
         }
-        if (r == 0 && h == 0) pooled_ = pooled_ && apdgicp_batch_is_pooled(b) == 1;  // (the library decides: APDGICP_LM_POOL=0 / brute-force search run LM one batch per handle)
+        if (r == 0 && h == 0) {  // (the library decides: APDGICP_LM_POOL=0 / brute-force search run LM one batch per handle)
+          const int lanes = apdgicp_batch_is_pooled(b);
+          pooled_ = pooled_ && lanes > 0;
+          if (pooled_) slots_ = std::min(slots_, lanes);  // the pool holds that many batches
+          else slots_ = std::min(slots_, 8);              // one handle per batch in flight
+        }
         k.handles.push_back(b);
       }
       if (!pooled_)

@@ -1356,6 +1356,8 @@ class Engine {
     const bool enabled = env_int("APDGICP_LM_POOL", 1) != 0;  // (0: the host-polled loop of run_align, the cross-check)
     return enabled && params.optimizer == APDGICP_OPT_LM && params.max_iterations > 0 && nn_pruned;
   }
+  // batches of one handle that may be in flight at once (8 / 12 / 16 / 24 / 32: 1.27 / 1.13 / 1.07 / 1.03 / 1.01 ms per 32 loop pairs)
+  static int pool_lanes_cfg() { return std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 16))); }
   PoolHdr* pool_hdr(uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing; }
   bool pool_busy() const {
     for (const PoolJob& j : pool.jobs)
@@ -1399,7 +1401,7 @@ class Engine {
     const int nmax = std::max(pool.nmax_src, nsrc);
     const size_t ns = ((size_t)nmax + 255) & ~(size_t)255, nblk = (nmax + LIN_BLK - 1) / LIN_BLK;
     const size_t per_pair = ns * 96 + nblk * (kRed + 1) * 8 + sizeof(PairState) + sizeof(PairDesc) + sizeof(Rigid) + 2 * sizeof(ResultRec) + 16;
-    int lanes = std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 8)));
+    int lanes = pool_lanes_cfg();
     while (lanes > 1 && (size_t)lanes * segcap * per_pair > ((size_t)16 << 30)) lanes--;
     const int cap = lanes * segcap;
     APD_TRY(pool.state.ensure((size_t)cap * sizeof(PairState)));

@@ -2575,11 +2575,11 @@ __device__ __forceinline__ void finalize_pair(const PairState* st, ResultRec* ou
 //   * pads the list with -1 (tick launches are sized by the host's upper bound of its length) and posts a header -- length,
 //     pairs left per lane, the device error flag (taken and reset) -- behind everything else in pinned memory.
 // The host never has to answer for the GPU to keep working: it keeps two chunks enqueued and reads the headers as they arrive.
-constexpr int kPoolLanes = 8, kPoolRing = 8;
+constexpr int kPoolLanes = 32, kPoolRing = 8;
 struct PoolHdr {
   int n_active, errflag;
   int lane_left[kPoolLanes];
-  int pad_[5];
+  int pad_[29];
   int seq;  // written last, system-scope release
 };
 struct PoolAdmit {

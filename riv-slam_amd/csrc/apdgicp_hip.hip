@@ -650,7 +650,7 @@ int apdgicp_batch_pump(apdgicp_batch* b) {
 
 int apdgicp_batch_is_pooled(apdgicp_batch* b) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
-  return b->eng.pool_eligible() ? 1 : 0;
+  return b->eng.pool_eligible() ? Engine::pool_lanes_cfg() : 0;
 }
 
 int apdgicp_batch_align_collect(apdgicp_batch* b, uint64_t ticket, void** d_results, apdgicp_result* host_results) {

@@ -595,7 +595,7 @@ class BatchAPDGICP:
         _check(self.L.apdgicp_batch_align_enqueue(self.b, arr, len(arr), C.byref(ticket)))
         self._keep_ticket[ticket.value], self._keep_new = self._keep_new, []
         # (Gauss-Newton: the last two tickets are collectable; pooled LM batches: as many as the pool has lanes -- the library decides)
-        self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 8 >= ticket.value}, ticket.value: len(arr)}
+        self._ticket_pairs = {**{k: v for k, v in getattr(self, "_ticket_pairs", {}).items() if k + 32 >= ticket.value}, ticket.value: len(arr)}
         return ticket.value
 
     def align_collect(self, ticket: int, device: bool = False):

@@ -127,14 +127,14 @@ def section_c4():
             return b.align(pairs4)
         ms = timed(c4, 10)
         res = c4()
-        # ONE handle, ONE host thread, eight batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
+        # ONE handle, ONE host thread, sixteen batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
         # (include/apdgicp_hip.h); GN batches: two record buffers, so two in flight
-        F4 = 8 if tag == "lm_launch" else 2
+        F4 = 16 if tag == "lm_launch" else 2
         b8 = reg.BatchAPDGICP(reg.default_params(**kw))
         pairs8 = [b8.make_pairs([(2 * P4 * f + s_, 2 * P4 * f + t_) for s_, t_ in pr4], gs4) for f in range(F4)]
         packed8 = b8.pack_clouds(cl4)
 
-        def c4_in_flight(count=24):
+        def c4_in_flight(count=48):
             tk, last = [None] * F4, None
             for s_i in range(count):
                 f = s_i % F4
@@ -148,7 +148,7 @@ def section_c4():
                     tk[s_i % F4] = None
             return last
         res8 = c4_in_flight(2 * F4)
-        ms_in_flight = timed(c4_in_flight, 4) / 24
+        ms_in_flight = timed(c4_in_flight, 4) / 48
         assert res8.tobytes() == res.tobytes()
         # the same batches kept in flight on three handles (the bench's regime), LM polls as it goes so handles alternate
         hs = [reg.BatchAPDGICP(reg.default_params(**kw)) for _ in range(4)]

@@ -100,9 +100,10 @@ def test_four_batches_in_flight_on_one_handle(reg, scene):
     assert b.align([(2 * i, 2 * i + 1) for i in range(sizes[5])], data[5][1]).tobytes() == want[5].tobytes()
 
 
-def test_more_batches_than_lanes_and_a_growing_pool(reg, scene):
+def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch):
     """Ten enqueues without a collect on eight lanes: the oldest batches give their lanes up (their tickets are void), the
     newest eight stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
+    monkeypatch.setenv("APDGICP_POOL_LANES", "8")   # (read when the pool is laid out; sixteen by default)
     data = loop_batches(scene, 10, 4, 800, 340)
     pair_idx = [(2 * i, 2 * i + 1) for i in range(4)]
     ref_b = reg.BatchAPDGICP(reg.default_params(**LM))

@@ -2,7 +2,7 @@
 """The C++ multi-device host path against the Python one on the same box and the same pairs: 32 pairs of
 8192 points per device per batch, clouds resident in HBM and re-registered every batch.
   gn: bench.py's step (odometry pairs, GN-20)      -- Python: four batch handles in flight; C++: ShardedBatchAlignerHip, 4 in flight
-  lm: SURVEY 8d's C4 shard (loop pairs from the identity, LM launch parameters) -- Python: one pooled handle, 8 in flight; C++: the same handle behind the aligner
+  lm: SURVEY 8d's C4 shard (loop pairs from the identity, LM launch parameters) -- Python: one pooled handle, 16 in flight; C++: the same handle behind the aligner
 Prints one JSON object; records of the C++ runs are checked against the Python handles byte for byte."""
 import importlib
 import json
@@ -39,10 +39,11 @@ for mode in ("gn", "lm"):
         guesses.append(g if mode == "gn" else np.eye(4, dtype=np.float32))
     path, rec = os.path.join(tmp, f"cppbench_{mode}.bin"), os.path.join(tmp, f"cppbench_{mode}.rec")
     T.write_batch_file(path, clouds, pairs, guesses)
-    F = 4 if mode == "gn" else 8
+    F = 4 if mode == "gn" else 16
+    STEPS = {"gn": 60, "lm": 128}   # (timed steps: several rounds over the batches in flight)
     best = None
     for rep in range(3):
-        r = subprocess.run([exe, path, mode, "60", "12", rec, str(F), "1"], capture_output=True, text=True, timeout=900,
+        r = subprocess.run([exe, path, mode, str(STEPS[mode]), str(2 * F), rec, str(F), "1"], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
         assert r.returncode == 0, r.stdout + r.stderr
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -87,14 +88,14 @@ for mode in ("gn", "lm"):
                     res = b.align_collect(tk[s % F])
                     tk[s % F] = None
             return res
-    run(12)
+    run(2 * F)
     ts = []
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = run(60)
+        res = run(STEPS[mode])
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) / 60 * 1e3)
+        ts.append((time.perf_counter() - t0) / STEPS[mode] * 1e3)
     out[mode] = {"cpp_ms_per_step": best["ms_per_step"], "python_ms_per_step": round(min(ts), 4), "cpp_over_python": round(best["ms_per_step"] / min(ts), 3),
                  "in_flight": F, "records_byte_equal": open(rec, "rb").read() == res.tobytes(), "cpp": best}
 print(json.dumps(out))
