@@ -100,11 +100,15 @@ def test_four_batches_in_flight_on_one_handle(reg, scene):
     assert b.align([(2 * i, 2 * i + 1) for i in range(sizes[5])], data[5][1]).tobytes() == want[5].tobytes()
 
 
-def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch):
-    """Ten enqueues without a collect on eight lanes: the oldest batches give their lanes up (their tickets are void), the
-    newest eight stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
-    monkeypatch.setenv("APDGICP_POOL_LANES", "8")   # (read when the pool is laid out; sixteen by default)
-    data = loop_batches(scene, 10, 4, 800, 340)
+@pytest.mark.parametrize("lanes", (8, 16))
+def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch, lanes):
+    """lanes + 2 enqueues without a collect: the oldest batches give their lanes up (their tickets are void), the newest
+    `lanes` stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
+    if lanes != 16:
+        monkeypatch.setenv("APDGICP_POOL_LANES", str(lanes))   # (read when the pool is laid out; sixteen by default)
+    else:
+        monkeypatch.delenv("APDGICP_POOL_LANES", raising=False)
+    data = loop_batches(scene, lanes + 2, 4, 800, 340)
     pair_idx = [(2 * i, 2 * i + 1) for i in range(4)]
     ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
     want = []
@@ -116,7 +120,9 @@ def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch):
     for s, (clouds, guesses) in enumerate(data):
         b.set_clouds(8 * s, clouds)
         tickets.append(b.align_enqueue([(8 * s + 2 * i, 8 * s + 2 * i + 1) for i in range(4)], guesses))
-    for s in (9, 4, 7, 2, 3, 5, 6, 8):
+    order = [lanes + 1, 4, 7, 2, 3, 5, 6, 8] + [s for s in range(9, lanes + 1)]
+    assert sorted(order) == list(range(2, lanes + 2))
+    for s in order:
         assert b.align_collect(tickets[s]).tobytes() == want[s].tobytes(), s
     for s in (0, 1):
         with pytest.raises(Exception, match="ticket"):
