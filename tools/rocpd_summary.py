@@ -19,7 +19,8 @@ rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(en
                   "from kernels group by name, grid_x, grid_y, grid_z order by 3 desc").fetchall()
 total = sum(r[2] for r in rows)
 print(f"# {title}\n")
-print("rocprofv3 kernel trace; durations in microseconds; one row per kernel and grid size (work-items)\n")
+print("rocprofv3 kernel trace; durations in microseconds; one row per kernel and grid size (work-items); vgpr / sgpr as rocprofv3 reports them "
+      "(its vgpr figure is half the compiler's allocation: k_nn_compact<4> 48 here = 96 registers, occupancy 5 -- tools/isa_stats.py has the compiler's)\n")
 print("| kernel | calls | total us | avg us | min us | max us | % | vgpr | sgpr | lds B | grid (x,y,z) | wg |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
