@@ -230,6 +230,7 @@ __device__ __forceinline__ void load_Tf(const Rigid& T, float Tf[12]) {
 }
 __device__ __forceinline__ float xf_row(const float* r, float x, float y, float z) { return ((r[0] * x + r[1] * y) + r[2] * z) + r[3]; }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sqdist1(float tx, float ty, float tz, float px, float py, float pz) {
   const float dx = tx - px, dy = ty - py, dz = tz - pz;
   float r = dx * dx;
@@ -869,10 +870,25 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       for (int jj = 0; jj < kChunk / 2; jj++) {
         const float4 A = txy[ch * (kChunk / 2) + jj];
         const float2 Z = tz[ch * (kChunk / 2) + jj];
+        // both targets at once, as 2-vectors (sqdist1's operations in sqdist1's order, per component): written as two scalar
+        // distances the compiler packed some of the operations and paid for it with register moves -- 17.5 vector
+        // instructions per pair of targets against 11
+        // (in the throughput kernel only -- GIVEN: packed operations take two passes through the vector unit, and the chain of a
+        // lone search wave got 1 us longer per odometry frame with them)
+        const v2f X = {A.x, A.y}, Y = {A.z, A.w}, ZZ = {Z.x, Z.y};
 #pragma unroll
         for (int s = 0; s < S; s++) {
-          const float d0 = sqdist1(A.x, A.z, Z.x, px[s], py[s], pz[s]);
-          const float d1 = sqdist1(A.y, A.w, Z.y, px[s], py[s], pz[s]);
+          float d0, d1;
+          if constexpr (GIVEN) {
+            const v2f dx = X - px[s], dy = Y - py[s], dz = ZZ - pz[s];
+            v2f r = dx * dx;
+            r = r + dy * dy;
+            r = r + dz * dz;
+            d0 = r.x, d1 = r.y;
+          } else {
+            d0 = sqdist1(A.x, A.z, Z.x, px[s], py[s], pz[s]);
+            d1 = sqdist1(A.y, A.w, Z.y, px[s], py[s], pz[s]);
+          }
           m2[s] = fminf(m2[s], __builtin_amdgcn_fmed3f(m[s], d0, d1));
           m[s] = fminf(fminf(m[s], d0), d1);
         }
@@ -1123,7 +1139,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
 // as few waves as they fill (still consecutive on the curve, i.e. compact) and only those waves search -- each on its own,
 // with its own LDS, exactly like a one-wave block of k_nn_pruned.  Which wave searches for a point never changes a result.
 template <int W>
-__global__ __launch_bounds__(64 * W) void k_nn_compact(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_nn_compact(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
   __shared__ float4 txy[W][kGroupPts / 2];
   __shared__ float2 tz[W][kGroupPts / 2];
   __shared__ float cbl[W][6 * kGroupChunks];
