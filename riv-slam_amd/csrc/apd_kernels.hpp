@@ -1655,6 +1655,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
       d1 = G(c.pts)[min(j1, n - 1)];
       gcur = g;
     };
+    v2f cx, cy, cz;  // the two candidates of this lane, component-wise: every step's distances are packed operations on these
     auto take = [&]() {  // d -> c (the sorted points carry their original index in .w)
       c0 = d0, c1 = d1, o0 = __float_as_uint(d0.w), o1 = __float_as_uint(d1.w);
       if ((gb0 + gcur + 1) * kGroupPts > n) {  // (uniform) only the last group of a cloud can reach beyond it
@@ -1662,6 +1663,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
         if (j0 >= n) c0 = make_float4(inf, inf, inf, 0.f), o0 = 0xFFFFFFFFu;
         if (j1 >= n) c1 = make_float4(inf, inf, inf, 0.f), o1 = 0xFFFFFFFFu;
       }
+      cx = v2f{c0.x, c1.x}, cy = v2f{c0.y, c1.y}, cz = v2f{c0.z, c1.z};
     };
         // L >= 8 (one or two clouds per launch, every wave resident: the launch lasts as long as its slowest wave): nearest groups
     // first, by the lower bound to the wave's middle query, so that tau is tight before the far groups are reached and the
@@ -1712,8 +1714,12 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
 #endif
         unsigned long long tk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_hi, qq) << 32) |
                                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tau_lo, qq);  // readlane returns int: no sign extension
-        const unsigned long long k0 = ((unsigned long long)__float_as_uint(sqdist1(c0.x, c0.y, c0.z, qx, qy, qz)) << 32) | o0;
-        const unsigned long long k1 = ((unsigned long long)__float_as_uint(sqdist1(c1.x, c1.y, c1.z, qx, qy, qz)) << 32) | o1;
+        const v2f ddx = cx - qx, ddy = cy - qy, ddz = cz - qz;  // (sqdist1's operations in sqdist1's order, per candidate)
+        v2f dd = ddx * ddx;
+        dd = dd + ddy * ddy;
+        dd = dd + ddz * ddz;
+        const unsigned long long k0 = ((unsigned long long)__float_as_uint(dd.x) << 32) | o0;
+        const unsigned long long k1 = ((unsigned long long)__float_as_uint(dd.y) << 32) | o1;
         unsigned long long* row = lst + (qq / L) * KQ_STRIDE;
         unsigned long long m0 = __ballot(k0 <= tk), m1 = __ballot(k1 <= tk);
         if ((m0 | m1) == 0) continue;  // the box passed the test, none of its 128 points does
