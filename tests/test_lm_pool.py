@@ -214,3 +214,16 @@ def test_pool_list_longer_than_one_poll_round(reg, scene):
         want = polled_align(ref_b, *batches[k])
         assert len(g) == sizes[k] and g.tobytes() == want.tobytes(), k
     assert len(set(int(x) for x in got[1]["n_linearize"])) > 3
+
+
+def test_is_pooled_reports_the_number_of_batches_a_handle_keeps_in_flight(reg, monkeypatch):
+    """include/apdgicp_hip.h: > 0 = the pool's lanes (16 unless APDGICP_POOL_LANES says otherwise, at most 32), 0 = no pool
+    (Gauss-Newton: two record buffers per handle)."""
+    monkeypatch.delenv("APDGICP_POOL_LANES", raising=False)
+    lm = reg.BatchAPDGICP(reg.default_params(**LM))
+    assert lm.L.apdgicp_batch_is_pooled(lm.b) == 16
+    gn = reg.BatchAPDGICP(reg.default_params(optimizer=1, **LM))
+    assert gn.L.apdgicp_batch_is_pooled(gn.b) == 0
+    for env, want in (("8", 8), ("64", 32), ("0", 1)):
+        monkeypatch.setenv("APDGICP_POOL_LANES", env)
+        assert lm.L.apdgicp_batch_is_pooled(lm.b) == want
