@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define APDGICP_ABI_VERSION 3   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots */
+#define APDGICP_ABI_VERSION 4   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots;
+                                   4: T*p is summed pairwise by default (Eigen >= 3.3), APDGICP_FLAG_XF_LINEAR_CHAIN selects the former order */
 
 typedef enum {
   APDGICP_OK = 0,
@@ -56,7 +57,14 @@ typedef enum {
 /* apdgicp_params.flags.  PLAIN_GICP: drop the range-dependent polar noise covariance (cov_dist, A:167-184), which turns the
  * cost into upstream fast_gicp::FastGICP (gicp/impl/fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T) -- the FAST_GICP branch of
  * select_registration_method() (registrations.cpp:28-37). */
-enum { APDGICP_FLAG_PLAIN_GICP = 1 };
+/* XF_LINEAR_CHAIN: the fp32 summation order of `pt = trans_f * p.getVector4fMap()` (A:137,149), the one fp32 operation of the path
+ * whose order belongs to Eigen, not to the reference.  Default (flag clear): (r0 x + r1 y) + (r2 z + t) -- Eigen >= 3.3, whose
+ * coefficient-based product sums the four terms of a row with redux_novec_unroller (halving), i.e. the Eigen 3.3.4 / 3.3.7 of the
+ * platforms the reference names (README.md:5-7).  Flag set: ((r0 x + r1 y) + r2 z) + t -- Eigen 3.2's product_coeff_impl, and
+ * what ABI versions <= 3 evaluated.  The two differ in the last ulp of a transformed coordinate: enough to resolve a
+ * nearest-neighbour near-tie the other way (poses move by <= 1e-5 m, an LM run may stop one iteration earlier or later).
+ * INTEGRATION.md section 7 holds a 30-line probe that tells which order an installed Eigen produces. */
+enum { APDGICP_FLAG_PLAIN_GICP = 1, APDGICP_FLAG_XF_LINEAR_CHAIN = 2 };
 
 /* fast_gicp::LSQ_OPTIMIZER_TYPE, gicp/lsq_registration.hpp:13 (reference default: LM, L:17) */
 typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;

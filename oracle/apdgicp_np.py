@@ -16,7 +16,8 @@ Third-party arithmetic restated here (not vendored by the reference, versions un
     i = 0,1,2 accumulated in fp32, no FMA (reference builds with -msse4.2 only,
     fast_apdgicp/CMakeLists.txt:11-16); exact k-NN.  Ties are broken towards the LOWER index here
     (FLANN's choice depends on tree layout and is not specified).
-  * Eigen Isometry3f * Vector4f: row_i = ((m_i0*x + m_i1*y) + m_i2*z) + m_i3*w in fp32.
+  * Eigen Isometry3f * Vector4f: row_i = (m_i0*x + m_i1*y) + (m_i2*z + m_i3*w) in fp32 as Eigen >= 3.3 sums it (the linear
+    chain of Eigen 3.2 with Params.flags bit 1).
   * Eigen JacobiSVD of a symmetric PSD 3x3 == symmetric eigendecomposition, values descending.
   * Eigen Matrix4d::inverse() of blkdiag(C,1) == blkdiag(inv(C),1).
   * Eigen LDLT<6x6>::solve == any backward-stable SPD solve (agreement ~1e-12 relative).
@@ -44,7 +45,7 @@ class Params:
     lm_max_iterations: int = 10
     optimizer: int = OPT_LM
     regularization: int = REG_PLANE
-    flags: int = 0   # bit 0: plain GICP (cov_dist omitted), gicp/impl/fast_gicp_impl.hpp
+    flags: int = 0   # bit 0: plain GICP (cov_dist omitted), gicp/impl/fast_gicp_impl.hpp; bit 1: T*p as a linear chain (Eigen 3.2)
     max_correspondence_distance: float = float(np.finfo(np.float32).max)
     transformation_epsilon: float = 5e-4
     rotation_epsilon: float = 2e-3
@@ -55,17 +56,18 @@ class Params:
 
 
 # ----------------------------------------------------------------------------- fp32 geometry
-def transform_points_f32(T: np.ndarray, pts: np.ndarray) -> np.ndarray:
-    """pt = trans.cast<float>() * p  (gicp/impl/fast_apdgicp_impl.hpp:137,149), fp32, no FMA."""
+def transform_points_f32(T: np.ndarray, pts: np.ndarray, linear_chain: bool = False) -> np.ndarray:
+    """pt = trans.cast<float>() * p  (gicp/impl/fast_apdgicp_impl.hpp:137,149), fp32, no FMA.  The summation order is Eigen's:
+    pairwise (r0 x + r1 y) + (r2 z + t) for Eigen >= 3.3 (redux_novec_unroller halves the four products of a row), the linear
+    chain ((r0 x + r1 y) + r2 z) + t for Eigen 3.2 (Params.flags bit 1); see oracle/apdgicp_ref.cpp:xf_row."""
     Tf = np.asarray(T, dtype=np.float64).astype(F32)
     x, y, z = pts[:, 0].astype(F32), pts[:, 1].astype(F32), pts[:, 2].astype(F32)
     out = np.empty((pts.shape[0], 3), dtype=F32)
     for r in range(3):
-        acc = Tf[r, 0] * x
-        acc = acc + Tf[r, 1] * y
-        acc = acc + Tf[r, 2] * z
-        acc = acc + Tf[r, 3]
-        out[:, r] = acc
+        a = Tf[r, 0] * x
+        a = a + Tf[r, 1] * y
+        c = Tf[r, 2] * z
+        out[:, r] = (a + c) + Tf[r, 3] if linear_chain else a + (c + Tf[r, 3])
     return out
 
 
@@ -210,7 +212,7 @@ class FastAPDGICP:
     # :133-194
     def update_correspondences(self, T: np.ndarray):
         p = self.p
-        pt = transform_points_f32(T, self.source)
+        pt = transform_points_f32(T, self.source, bool(p.flags & 2))
         idx, sq = nn1(pt, self.target)
         thr2 = float(p.max_correspondence_distance) * float(p.max_correspondence_distance)
         corr = np.where(sq.astype(np.float64) < thr2, idx, -1).astype(np.int32)  # :156

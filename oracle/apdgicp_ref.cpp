@@ -16,7 +16,8 @@
 //
 // Third-party arithmetic restated (un-vendored, un-pinned in the reference): FLANN L2_Simple<float>
 // (fp32 (a-b)^2 accumulation over x,y,z, exact k-NN; ties -> lower index here), Eigen
-// Isometry3f*Vector4f (((m0*x+m1*y)+m2*z)+m3, fp32, no FMA: reference is built -msse4.2 only),
+// Isometry3f*Vector4f ((m0*x+m1*y)+(m2*z+m3) as Eigen >= 3.3 sums it, or the linear chain of Eigen 3.2: see xf_row; fp32, no
+// FMA: reference is built -msse4.2 only),
 // Eigen JacobiSVD of a symmetric PSD 3x3 (== symmetric eigen-decomposition, descending),
 // Matrix4d::inverse of blkdiag(C,1), LDLT<6x6> (diagonal-pivoted), Quaterniond::toRotationMatrix.
 //
@@ -41,7 +42,8 @@ struct RefParams {  // independent mirror of include/apdgicp_hip.h:apdgicp_param
   int32_t lm_max_iterations;
   int32_t optimizer;       // 0 = LevenbergMarquardt, 1 = GaussNewton (L:17, lsq_registration.hpp:13)
   int32_t regularization;  // gicp_settings.hpp:6 NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS
-  int32_t flags;           // bit 0: plain GICP (no cov_dist), gicp/impl/fast_gicp_impl.hpp update_correspondences
+  int32_t flags;           // bit 0: plain GICP (no cov_dist), gicp/impl/fast_gicp_impl.hpp update_correspondences;
+                           // bit 1: T*p summed as a linear chain (Eigen 3.2) instead of pairwise (Eigen >= 3.3), see xf_row
   double max_correspondence_distance;
   double transformation_epsilon;
   double rotation_epsilon;
@@ -408,21 +410,29 @@ void load_T(const double Tcm[16], M4& T) {
 }
 
 // A:149: `pt = trans.cast<float>() * input_->at(i).getVector4fMap()` -- an Isometry3f times a Vector4f whose 4th coefficient is 1.
-// Which fp32 operation order Eigen 3.3 emits for this 4x4 * 4x1 product cannot be read off here (no Eigen in the image): order 0,
-// ((r0 x + r1 y) + r2 z) + t, is its coefficient-based lazy product and what the GPU kernels evaluate.  The other orders exist
-// ONLY for tests/measure/transform_order_sensitivity.py, which quantifies how far the registered pose moves if the reference's
-// build summed differently (packet code with or without FMA, other associations): the one place where an unpinned oracle could
-// differ from the reference by more than rounding of sums -- a nearest-neighbour tie or near-tie resolved the other way.
+// The fp32 operation order of this product belongs to Eigen (un-vendored, un-pinned), not to the reference:
+//   * Eigen >= 3.3 (the 3.3.4 / 3.3.7 of the platforms README.md:5-7 names): Transform::operator* -> transform_right_product_impl
+//     -> `T.affine() * other`, a 3x4 * 4x1 product -> CoeffBasedProductMode (3 rows are not a multiple of a Packet4f, a row of a
+//     column-major block has inner stride 4: no packet path) -> coeff(i) = (lhs.row(i).transpose().cwiseProduct(rhs)).sum() ->
+//     redux_novec_unroller<.., 0, 4>, which HALVES the range: (p0 + p1) + (p2 + p3) = (r0 x + r1 y) + (r2 z + t * 1).   [default]
+//   * Eigen 3.2: product_coeff_impl<DefaultTraversal, 3> accumulates from the left: ((r0 x + r1 y) + r2 z) + t.    [flags bit 1]
+// No FMA in either (the reference is built with -msse4.2 only, fast_apdgicp/CMakeLists.txt:11-13).  Read from the Eigen sources
+// as remembered, not compiled here: tools/eigen_order_probe.cpp lets an integrator check it against THEIR Eigen.
+// g_xf_order != 0 exists ONLY for tests/measure/transform_order_sensitivity.py, which quantifies how far the registered pose
+// moves under still other orders (packet code with FMA, other associations).
 int g_xf_order = 0;
-inline float xf_row(const float* r, const F3& a) {
+inline float xf_row(const float* r, const F3& a, bool linear_chain) {
   switch (g_xf_order) {
     case 1: return std::fmaf(r[2], a.z, std::fmaf(r[1], a.y, r[0] * a.x)) + r[3];              // packet pmadd chain, translation added last
     case 2: return r[0] * a.x + (r[1] * a.y + (r[2] * a.z + r[3]));                            // accumulated from the last column
-    case 3: return (r[0] * a.x + r[1] * a.y) + (r[2] * a.z + r[3]);                            // pairwise
+    case 3: return (r[0] * a.x + r[1] * a.y) + (r[2] * a.z + r[3]);                            // pairwise (forced)
     case 4: return std::fmaf(r[0], a.x, std::fmaf(r[1], a.y, std::fmaf(r[2], a.z, r[3])));     // fully fused, from the last column
     case 5: return std::fmaf(r[2], a.z, std::fmaf(r[1], a.y, std::fmaf(r[0], a.x, r[3])));     // fully fused, translation first
-    default: return ((r[0] * a.x + r[1] * a.y) + r[2] * a.z) + r[3];
+    case 6: return ((r[0] * a.x + r[1] * a.y) + r[2] * a.z) + r[3];                            // linear chain (forced)
+    default: break;
   }
+  if (linear_chain) return ((r[0] * a.x + r[1] * a.y) + r[2] * a.z) + r[3];
+  return (r[0] * a.x + r[1] * a.y) + (r[2] * a.z + r[3]);
 }
 
 // A:133-194
@@ -446,7 +456,8 @@ void update_correspondences(Ref& r, const M4& T) {
   for (int i = 0; i < n; i++) {
     const F3& a = r.src.pts[i];
     F3 pt;  // A:149
-    pt.x = xf_row(Tf[0], a), pt.y = xf_row(Tf[1], a), pt.z = xf_row(Tf[2], a);
+    const bool lin = (r.p.flags & 2) != 0;
+    pt.x = xf_row(Tf[0], a, lin), pt.y = xf_row(Tf[1], a, lin), pt.z = xf_row(Tf[2], a, lin);
     static thread_local std::vector<Cand> heap;
     heap.clear();
     heap.reserve(2);

@@ -96,6 +96,14 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   /// upstream fast_gicp::FastGICP cost (no APD covariance): the FAST_GICP branch of the factory (registrations.cpp:28-37)
   void setPlainGICP(bool on) { params_.flags = on ? (params_.flags | APDGICP_FLAG_PLAIN_GICP) : (params_.flags & ~APDGICP_FLAG_PLAIN_GICP); }
 
+  /// fp32 summation order of `trans_f * p.getVector4fMap()` (fast_apdgicp_impl.hpp:149), which belongs to the Eigen the reference
+  /// is built against, not to the reference: EIGEN_PAIRWISE (default; Eigen >= 3.3) or EIGEN_LINEAR_CHAIN (Eigen 3.2).
+  /// tools/eigen_order_probe.cpp prints which one an installed Eigen produces.
+  enum TransformOrder { EIGEN_PAIRWISE = 0, EIGEN_LINEAR_CHAIN = 1 };
+  void setTransformOrder(TransformOrder o) {
+    params_.flags = o == EIGEN_LINEAR_CHAIN ? (params_.flags | APDGICP_FLAG_XF_LINEAR_CHAIN) : (params_.flags & ~APDGICP_FLAG_XF_LINEAR_CHAIN);
+  }
+
   // ---- cache management (fast_apdgicp_impl.hpp:68-108)
   virtual void swapSourceAndTarget() {
     input_.swap(target_);

@@ -958,7 +958,11 @@ class Engine {
   Span whole() const { return Span{0, npairs, stream}; }
   // what the tick launches run over: the batch set up by setup_pairs, or (inside pool_enqueue_chunk) the pair pool
   bool in_pool = false;
-  const Work& t_work() const { return in_pool ? pool.work : work; }
+  Work t_work() const {
+    Work w = in_pool ? pool.work : work;
+    w.xf_linear = (params.flags & APDGICP_FLAG_XF_LINEAR_CHAIN) ? 1 : 0;  // (read at launch time: set_params may come between aligns)
+    return w;
+  }
   const PairDesc* t_pairs() const { return in_pool ? pool.pairs.as<PairDesc>() : d_pairs.as<PairDesc>(); }
   PairState* t_state() const { return in_pool ? pool.state.as<PairState>() : d_state.as<PairState>(); }
   int t_npairs() const { return in_pool ? pool.cap : npairs; }

@@ -161,6 +161,7 @@ struct Work {
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
   int coop_search;             // k_nn_compact: a block with at most 64 points left searches them with all of its waves
+  int xf_linear;               // fp32 summation order of T * p (A:149), see xf_row: 0 = pairwise (Eigen >= 3.3), 1 = linear chain (Eigen 3.2)
   const PollPost* post;        // non-null (k_error only): this launch is the last of a one-pair poll and writes the result record itself
                                // (post_result).  Not in k_linearize: with the record code in its last block the register allocator
                                // moved that kernel's spills into the per-point pass (32.6 -> 45.0 us per batch launch)
@@ -228,7 +229,16 @@ __device__ __forceinline__ void load_Tf(const Rigid& T, float Tf[12]) {
 #pragma unroll
   for (int i = 0; i < 12; i++) Tf[i] = (float)T.m[i];  // trans.cast<float>(), A:137
 }
-__device__ __forceinline__ float xf_row(const float* r, float x, float y, float z) { return ((r[0] * x + r[1] * y) + r[2] * z) + r[3]; }
+// One row of `trans_f * p.getVector4fMap()` (A:149; the fourth coefficient of the point is 1, so the last product is t itself).
+// Two fp32 summation orders exist in the Eigen releases the reference can be built against:
+//   pairwise (default)  (r0 x + r1 y) + (r2 z + t)    Eigen >= 3.3: coefficient-based lazy product, the 4 products summed by
+//                                                      redux_novec_unroller, which halves the range
+//   linear chain        ((r0 x + r1 y) + r2 z) + t    Eigen 3.2: product_coeff_impl accumulates from the left
+// `linear` is Work::xf_linear (APDGICP_FLAG_XF_LINEAR_CHAIN), uniform over the launch.  No FMA either way (-ffp-contract=off).
+__device__ __forceinline__ float xf_row(const float* r, float x, float y, float z, int linear) {
+  const float a = r[0] * x + r[1] * y, c = r[2] * z;
+  return linear ? (a + c) + r[3] : a + (c + r[3]);
+}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sqdist1(float tx, float ty, float tz, float px, float py, float pz) {
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(NN_BLK) void k_nn_partial(const CloudDesc* clouds, 
   for (int s = 0; s < S; s++) {
     const int i = base + s * NN_BLK + tid;
     const float4 p = src.pts[i < N ? i : N - 1];
-    const float x = xf_row(Tf + 0, p.x, p.y, p.z), y = xf_row(Tf + 4, p.x, p.y, p.z), z = xf_row(Tf + 8, p.x, p.y, p.z);
+    const float x = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), y = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), z = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
     if (s & 1) px[s / 2].y = x, py[s / 2].y = y, pz[s / 2].y = z;
     else px[s / 2].x = x, py[s / 2].x = y, pz[s / 2].x = z;
   }
@@ -709,7 +719,7 @@ __device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, co
   const float inf = __builtin_inff();
   NNStart o;
   const float4 p = G(src.pts)[ii];
-  o.px = xf_row(Tf + 0, p.x, p.y, p.z), o.py = xf_row(Tf + 4, p.x, p.y, p.z), o.pz = xf_row(Tf + 8, p.x, p.y, p.z);
+  o.px = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), o.py = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), o.pz = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
   o.best = w.cap, o.bestc = kNoChunk, o.kept = false;
   const float4 t = w.nnpt[(size_t)pair * w.nstride + ii];
   const int hint = cold ? -1 : __float_as_int(t.w);
@@ -2249,7 +2259,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     }
     float Tf[12];
     load_Tf(T, Tf);
-    const float ptx = xf_row(Tf + 0, p.x, p.y, p.z), pty = xf_row(Tf + 4, p.x, p.y, p.z), ptz = xf_row(Tf + 8, p.x, p.y, p.z);
+    const float ptx = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), pty = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), ptz = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
     linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];

@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libapdgicp_hip.so")
 REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = 0, 1, 2, 3, 4
 OPT_LM, OPT_GN = 0, 1
 FLAG_PLAIN_GICP = 1  # upstream fast_gicp::FastGICP cost (no APD covariance)
+FLAG_XF_LINEAR_CHAIN = 2  # T*p summed ((r0 x + r1 y) + r2 z) + t like Eigen 3.2 instead of pairwise like Eigen >= 3.3 (include/apdgicp_hip.h)
 SOURCE, TARGET = 0, 1
 
 

@@ -8,7 +8,10 @@ which must agree with each other before a vector is written:
   * covariances: <= 1e-12 absolute; M, H, b, cost: <= 5e-6 relative (the only systematic difference is
     the fp32 atan2 implementation used for the APD angles, fast_apdgicp_impl.hpp:168,172-173);
   * final transforms: <= 1e-5 m / 1e-5 rad.
-The values stored are the C++ restatement's.  Run:  python tests/golden/make_golden.py
+The values stored are the C++ restatement's.  Every vector that depends on the fp32 order of `T * p`
+(fast_apdgicp_impl.hpp:149; oracle/apdgicp_ref.cpp:xf_row) exists twice: the plain key holds the default order
+(pairwise, Eigen >= 3.3), the key suffixed `_xflin` the linear chain of Eigen 3.2 (flags bit 1,
+APDGICP_FLAG_XF_LINEAR_CHAIN); inputs (clouds, poses, guesses) are shared.  Run:  python tests/golden/make_golden.py
 """
 import importlib
 import os
@@ -25,6 +28,9 @@ import ref as R  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "apdgicp_golden.npz")
 LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)  # launch:91-101
+
+
+XF = (("", 0), ("_xflin", 2))   # key suffix, params.flags
 
 
 def np_params(**kw):
@@ -54,7 +60,9 @@ def main():
     src, tgt, T_true, guess = scene.make_pair(2048, 2048, scene.pair_seed(1, 1), "odometry")
     g["lin_source"], g["lin_target"], g["lin_T_true"], g["lin_guess"] = src, tgt, T_true, guess
     poses = [np.eye(4), guess.astype(np.float64), T_true]
-    for tag, kw in (("default", {}), ("launch", LAUNCH)):
+    for tag, kw0, sfx, fl in [(t, k, s_, f) for t, k in (("default", {}), ("launch", LAUNCH)) for s_, f in XF]:
+        kw = dict(kw0, flags=fl)
+        tag = tag + sfx
         r = R.RefAPDGICP(R.default_params(**kw))
         n = O.FastAPDGICP(np_params(**kw))
         for o in (r, n):
@@ -88,11 +96,15 @@ def main():
         "gn20": dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300),
         "lm_loop": dict(max_correspondence_distance=2.5),   # loop-closure style: identity guess
     }
-    for tag, kw in runs.items():
+    for tag, kw0, sfx, fl in [(t, k, s_, f) for t, k in runs.items() for s_, f in XF]:
+        kw = dict(kw0, flags=fl)
         if tag == "lm_loop":
             s, t, Tt, gs = scene.make_pair(2048, 2048, scene.pair_seed(1, 2), "loop")
         else:
             s, t, Tt, gs = src, tgt, T_true, guess
+        if tag == "lm_loop":  # the other runs reuse lin_source / lin_target / lin_guess
+            g[f"{tag}_source"], g[f"{tag}_target"], g[f"{tag}_guess"] = s, t, gs
+        tag = tag + sfx
         r = R.RefAPDGICP(R.default_params(**kw))
         n = O.FastAPDGICP(np_params(**kw))
         for o in (r, n):
@@ -103,8 +115,6 @@ def main():
         assert te < 1e-5 and re_ < 1e-5, (tag, te, re_)
         assert (r.converged, r.nr_iterations, r.n_linearize, r.n_compute_error) == (
             n.converged, n.nr_iterations, n.trace.n_linearize, n.trace.n_compute_error), tag
-        if tag == "lm_loop":  # the other runs reuse lin_source / lin_target / lin_guess
-            g[f"{tag}_source"], g[f"{tag}_target"], g[f"{tag}_guess"] = s, t, gs
         g[f"{tag}_T"] = Tr
         g[f"{tag}_info"] = np.array([r.converged, r.nr_iterations, r.n_linearize, r.n_compute_error], dtype=np.int32)
         g[f"{tag}_final_hessian"] = r.final_hessian()
@@ -124,21 +134,28 @@ def main():
     t[0] = (30.05, 0.02, 0.01)
     t[1] = (55.02, 0.01, 0.0)
     s[2] = (10.0, 60.0, 40.0)  # nothing within 2 m: unmatched
-    kw = dict(max_correspondence_distance=2.0)
-    r = R.RefAPDGICP(R.default_params(**kw))
-    n = O.FastAPDGICP(np_params(**kw))
-    for o in (r, n):
-        o.setInputSource(s)
-        o.setInputTarget(t)
-    n.source_covs, n.target_covs = O.calculate_covariances(s), O.calculate_covariances(t)
-    cr, Hr, br = r.linearize(np.eye(4))
-    cn, Hn, bn = n.linearize(np.eye(4))
-    corr, sqd = r.correspondences()
-    assert np.array_equal(corr, n.correspondences) and corr[2] == -1 and corr[0] == 0 and corr[1] == 1
-    assert rel(Hr, Hn) < 5e-6 and rel(br, bn) < 5e-6
     g["deg_source"], g["deg_target"] = s, t
-    g["deg_corr"], g["deg_sqd"], g["deg_H"], g["deg_b"], g["deg_cost"] = corr, sqd, Hr, br, cr
-    g["deg_maha128"] = r.mahalanobis()[:128]
+    # a pose that is NOT the identity (under the identity both summation orders return the point itself)
+    Tdeg = scene.make_transform(np.array([0.013, -0.007, 0.004]), np.deg2rad(0.11), np.deg2rad(0.02), np.deg2rad(-0.03))
+    g["deg_T"] = Tdeg
+    for sfx, fl in XF:
+        kw = dict(max_correspondence_distance=2.0, flags=fl)
+        r = R.RefAPDGICP(R.default_params(**kw))
+        n = O.FastAPDGICP(np_params(**kw))
+        for o in (r, n):
+            o.setInputSource(s)
+            o.setInputTarget(t)
+        n.source_covs, n.target_covs = O.calculate_covariances(s), O.calculate_covariances(t)
+        for ptag, Tp in (("", np.eye(4)), ("_moved", Tdeg)):
+            cr, Hr, br = r.linearize(Tp)
+            cn, Hn, bn = n.linearize(Tp)
+            corr, sqd = r.correspondences()
+            assert np.array_equal(corr, n.correspondences) and np.array_equal(sqd, n.sq_distances)
+            assert corr[2] == -1 and corr[0] == 0 and corr[1] == 1
+            assert rel(Hr, Hn) < 5e-6 and rel(br, bn) < 5e-6
+            k_ = f"deg{ptag}{sfx}"
+            g[f"{k_}_corr"], g[f"{k_}_sqd"], g[f"{k_}_H"], g[f"{k_}_b"], g[f"{k_}_cost"] = corr, sqd, Hr, br, cr
+            g[f"{k_}_maha128"] = r.mahalanobis()[:128]
 
     # (b) LM rejection (rho < 0, L:156-164) and the "lm not converged" failure path (L:71-74,172).
     #     On radar-range data LM never rejects a step (scanned: thousands of iterations), so these use
@@ -153,16 +170,20 @@ def main():
         Tt = scene.make_transform(rng.normal(size=3) * 0.5, np.deg2rad(yaw), 0, 0)
         Ti = np.linalg.inv(Tt)
         s = ((t.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]) + rng.normal(size=(nn_, 3)) * 0.02).astype(np.float32)
-        r = R.RefAPDGICP(R.default_params())
-        r.setInputSource(s)
-        r.setInputTarget(t)
-        r.align(None)
-        if r.n_compute_error == r.n_linearize or not r.converged:
-            continue
         ok = True
+        for sfx, fl in XF:
+            r = R.RefAPDGICP(R.default_params(flags=fl))
+            r.setInputSource(s)
+            r.setInputTarget(t)
+            r.align(None)
+            ok &= not (r.n_compute_error == r.n_linearize or not r.converged)
+        if not ok:
+            continue
         stash = {}
         # "fail": same clouds, lm_max_iterations=1 -> the first rejected step ends the run (L:71-74,172)
-        for tag, kw in (("rej", {}), ("fail", dict(lm_max_iterations=1))):
+        for tag, kw0, sfx, fl in [(t_, k_, s_, f) for t_, k_ in (("rej", {}), ("fail", dict(lm_max_iterations=1))) for s_, f in XF]:
+            kw = dict(kw0, flags=fl)
+            base_tag, tag = tag, tag + sfx
             r = R.RefAPDGICP(R.default_params(**kw))
             n = O.FastAPDGICP(np_params(**kw))
             for o in (r, n):
@@ -175,7 +196,7 @@ def main():
             if not same or te > 1e-6 * rr or re_ > 1e-6:
                 ok = False
                 break
-            if tag == "fail" and (r.converged or r.nr_iterations >= 63):
+            if base_tag == "fail" and (r.converged or r.nr_iterations >= 63):
                 ok = False
                 break
             stash[f"{tag}_T"] = Tr

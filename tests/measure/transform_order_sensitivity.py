@@ -18,8 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ref as R  # noqa
 scene = importlib.import_module("riv-slam_amd.scene")
 
-ORDERS = {0: "((r0 x + r1 y) + r2 z) + t   [reference order assumed]", 1: "fma(r2,z, fma(r1,y, r0 x)) + t", 2: "r0 x + (r1 y + (r2 z + t))",
-          3: "(r0 x + r1 y) + (r2 z + t)", 4: "fma(r0,x, fma(r1,y, fma(r2,z, t)))", 5: "fma(r2,z, fma(r1,y, fma(r0,x, t)))"}
+ORDERS = {0: "(r0 x + r1 y) + (r2 z + t)   [default: Eigen >= 3.3]", 6: "((r0 x + r1 y) + r2 z) + t   [APDGICP_FLAG_XF_LINEAR_CHAIN: Eigen 3.2]",
+          1: "fma(r2,z, fma(r1,y, r0 x)) + t", 2: "r0 x + (r1 y + (r2 z + t))", 4: "fma(r0,x, fma(r1,y, fma(r2,z, t)))", 5: "fma(r2,z, fma(r1,y, fma(r0,x, t)))"}
 LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
 LM_TIGHT = dict(max_correspondence_distance=2.0, transformation_epsilon=1e-4, azimuth_variance_deg=1.0)
 GN = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(reg):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/apdgicp_hip.h but not exported"
     assert sorted(reg.SYMBOLS) == declared
-    assert L.apdgicp_abi_version() == 3
+    assert L.apdgicp_abi_version() == 4
 
 
 def test_default_params_match_reference_defaults(reg):

@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
 REGS = (("none", 0), ("min_eig", 1), ("norm_min_eig", 2), ("plane", 3), ("frobenius", 4))
 T_TOL, R_TOL = 1e-3, 1e-4
+# The fp32 summation order of T * p (A:149) is Eigen's: pairwise for Eigen >= 3.3 (default), a linear chain for Eigen 3.2
+# (APDGICP_FLAG_XF_LINEAR_CHAIN).  Golden keys of the second carry the suffix; oracle and product take the same flag.
+XF = (pytest.param("", 0, id="xf_pairwise"), pytest.param("_xflin", 2, id="xf_linear"))
 
 
 @pytest.fixture(scope="module")
@@ -156,9 +159,11 @@ def test_cov_lists_overflow_many_times_bitwise_vs_brute_force(reg):
 
 
 # ------------------------------------------------------------------ linearize / compute_error (a7-a9)
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("tag,kw", (("default", {}), ("launch", LAUNCH)))
-def test_linearize_golden(reg, golden, tag, kw):
-    g = reg.FastAPDGICP(reg.default_params(**kw))
+def test_linearize_golden(reg, golden, tag, kw, sfx, flags):
+    g = reg.FastAPDGICP(reg.default_params(flags=flags, **kw))
+    tag = tag + sfx
     g.setInputSource(golden["lin_source"])
     g.setInputTarget(golden["lin_target"])
     for k in range(3):
@@ -192,20 +197,37 @@ def test_linearize_with_injected_covariances_is_tight(reg, golden):
     assert np.abs(g.getSourceCovariances()[:, :3, :3] - golden["lin_source_cov"]).max() <= 1e-15  # upper triangle is stored
 
 
-def test_degenerate_golden(reg, golden):
-    g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0))
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_degenerate_golden(reg, golden, sfx, flags):
+    g = reg.FastAPDGICP(reg.default_params(max_correspondence_distance=2.0, flags=flags))
     g.setInputSource(golden["deg_source"])
     g.setInputTarget(golden["deg_target"])
-    cost, H, b = g.linearize(np.eye(4))
-    corr, sqd = g.correspondences()
-    assert np.array_equal(corr, golden["deg_corr"]) and corr[2] == -1
-    assert np.array_equal(sqd.view(np.uint32), golden["deg_sqd"].view(np.uint32))
-    assert rel_err(H, golden["deg_H"]) < 5e-6 and rel_err(b, golden["deg_b"]) < 5e-6
-    M = g.mahalanobis()
-    assert np.all(M[2] == 0)
-    # the +x-axis points carry the APD blow-up: compare those two matrices entry by entry, loosely
-    assert rel_err(M[:2], golden["deg_maha128"][:2]) < 1e-3
-    assert rel_err(M[3:128], golden["deg_maha128"][3:128]) < 5e-6
+    for ptag, T in (("", np.eye(4)), ("_moved", golden["deg_T"])):  # (under the identity both orders return the point itself)
+        k = f"deg{ptag}{sfx}"
+        cost, H, b = g.linearize(T)
+        corr, sqd = g.correspondences()
+        assert np.array_equal(corr, golden[f"{k}_corr"]) and corr[2] == -1
+        assert np.array_equal(sqd.view(np.uint32), golden[f"{k}_sqd"].view(np.uint32))
+        assert rel_err(H, golden[f"{k}_H"]) < 5e-6 and rel_err(b, golden[f"{k}_b"]) < 5e-6
+        M = g.mahalanobis()
+        assert np.all(M[2] == 0)
+        # the +x-axis points carry the APD blow-up: compare those two matrices entry by entry, loosely
+        assert rel_err(M[:2], golden[f"{k}_maha128"][:2]) < 1e-3
+        assert rel_err(M[3:128], golden[f"{k}_maha128"][3:128]) < 5e-6
+
+
+def test_the_two_transform_orders_are_two_different_searches(reg, golden):
+    """The flag reaches every kernel that transforms a point: at a non-trivial pose the fp32 distances of the two modes differ in
+    the last bit for many points (and each mode matches ITS golden vector bit for bit, test_linearize_golden)."""
+    out = []
+    for flags in (0, reg.FLAG_XF_LINEAR_CHAIN):
+        g = reg.FastAPDGICP(reg.default_params(flags=flags, **LAUNCH))
+        g.setInputSource(golden["lin_source"])
+        g.setInputTarget(golden["lin_target"])
+        g.linearize(golden["lin_launch_1_T"])
+        out.append(g.correspondences()[1].view(np.uint32).copy())
+    want = int((golden["lin_launch_1_sqd"].view(np.uint32) != golden["lin_launch_xflin_1_sqd"].view(np.uint32)).sum())
+    assert want > 100 and int((out[0] != out[1]).sum()) == want
 
 
 def test_all_unmatched_is_not_an_error(reg, golden):
@@ -227,14 +249,16 @@ RUNS = {
 }
 
 
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("host_loop", (False, True))
 @pytest.mark.parametrize("tag", list(RUNS))
-def test_align_golden(reg, golden, scene, tag, host_loop):
+def test_align_golden(reg, golden, scene, tag, host_loop, sfx, flags):
     pre = "lm_loop" if tag == "lm_loop" else "lin"
-    g = reg.FastAPDGICP(reg.default_params(**RUNS[tag]))
+    g = reg.FastAPDGICP(reg.default_params(flags=flags, **RUNS[tag]))
     g.setInputSource(golden[f"{pre}_source"])
     g.setInputTarget(golden[f"{pre}_target"])
     T = g.align(golden[f"{pre}_guess"], host_loop=host_loop)
+    tag = tag + sfx
     assert info_of(g) == list(golden[f"{tag}_info"])
     te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
     assert te <= T_TOL and re_ <= R_TOL
@@ -244,17 +268,18 @@ def test_align_golden(reg, golden, scene, tag, host_loop):
     assert g.hasConverged() == bool(golden[f"{tag}_info"][0])
 
 
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("tag,kw", (("rej", {}), ("fail", dict(lm_max_iterations=1))))
-def test_lm_rejection_and_failure_paths(reg, golden, scene, tag, kw):
+def test_lm_rejection_and_failure_paths(reg, golden, scene, tag, kw, sfx, flags):
     """rho < 0 -> lambda *= nu (L:156-164) and the 'lm not converged' exit (L:71-74,172)."""
-    g = reg.FastAPDGICP(reg.default_params(**kw))
+    g = reg.FastAPDGICP(reg.default_params(flags=flags, **kw))
     g.setInputSource(golden["rej_source"])
     g.setInputTarget(golden["rej_target"])
     for host_loop in (False, True):
         T = g.align(None, host_loop=host_loop)
-        assert info_of(g) == list(golden[f"{tag}_info"])
+        assert info_of(g) == list(golden[f"{tag}{sfx}_info"])
         assert g.result.n_compute_error > g.result.n_linearize or tag == "fail"
-        te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+        te, re_ = scene.pose_error(golden[f"{tag}{sfx}_T"], T)
         assert te <= T_TOL and re_ <= R_TOL
         assert bool(g.result.lm_failed) == (tag == "fail")
 
@@ -267,11 +292,12 @@ def test_max_iterations_zero_returns_guess(reg, golden):
     assert np.array_equal(T[:3], golden["lin_guess"][:3]) and not g.hasConverged() and g.result.n_linearize == 0
 
 
-def test_align_seeded_pairs_vs_oracle(reg, scene):
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_align_seeded_pairs_vs_oracle(reg, scene, sfx, flags):
     """Seeded pairs the golden file does not hold: odometry + loop closure, launch parameters."""
     for idx, (kind, n, m) in enumerate((("odometry", 3000, 2500), ("loop", 1500, 4097), ("odometry", 4096, 4096))):
         src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(3, idx), kind)
-        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0, flags=flags)
         g, o = both(reg, src, tgt, **kw)
         T, To = g.align(guess), o.align(guess)
         assert info_of(g) == [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error]
@@ -282,12 +308,13 @@ def test_align_seeded_pairs_vs_oracle(reg, scene):
         assert np.array_equal(cg, co)
 
 
-def test_full_size_8k_pair(reg, scene):
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_full_size_8k_pair(reg, scene, sfx, flags):
     """BASELINE configs[1]: 8k x 8k, GN-20; correspondences at the guess bit-exact, final pose within the
     north-star tolerance, plus size-independent properties."""
     src, tgt, _, guess = scene.make_pair(8192, 8192, scene.pair_seed(2, 0), "odometry")
     kw = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
-              max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+              max_correspondence_distance=2.0, azimuth_variance_deg=1.0, flags=flags)
     g, o = both(reg, src, tgt, **kw)
     c1, H1, b1 = g.linearize(guess.astype(np.float64))
     c2, H2, b2 = o.linearize(guess.astype(np.float64))
@@ -721,12 +748,14 @@ def _fresh(reg, mode, **kw):
                 os.environ[k] = v
 
 
-def test_pruned_search_is_bitwise_the_brute_force_search(reg, scene):
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_pruned_search_is_bitwise_the_brute_force_search(reg, scene, sfx, flags):
     """The Z-curve/bounding-box pruning only skips work: covariances, correspondences, distances, H, b and
-    the final pose must be IDENTICAL to the LDS-tiled brute-force kernels (north_star's formulation)."""
+    the final pose must be IDENTICAL to the LDS-tiled brute-force kernels (north_star's formulation) -- under both
+    summation orders of T * p."""
     for idx, (n, m, kind) in enumerate(((2048, 2048, "odometry"), (3000, 5000, "loop"), (8192, 8192, "odometry"))):
         src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(6, idx), kind)
-        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0)
+        kw = dict(max_correspondence_distance=2.5, azimuth_variance_deg=1.0, flags=flags)
         a, b = _fresh(reg, "pruned", **kw), _fresh(reg, "brute", **kw)
         for h in (a, b):
             h.setInputSource(src)
@@ -758,14 +787,14 @@ def _handle_with_env(reg, cls, env, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ("odometry", "loop"))
-def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind):
+@pytest.mark.parametrize("kind,flags", (("odometry", 0), ("loop", 0), ("loop", 2)))
+def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind, flags):
     """Neighbour keeping (nn_search: a point whose previous neighbour is PROVEN to still be the nearest skips the search)
     must not change a single bit: GN-20 and LM runs with the skin on (several settings), off, and with the brute-force
     search; the counters must show that points really were kept."""
     gn = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0,
-              azimuth_variance_deg=1.0)
-    lm = dict(max_correspondence_distance=2.0, transformation_epsilon=1e-4, azimuth_variance_deg=1.0)
+              azimuth_variance_deg=1.0, flags=flags)
+    lm = dict(max_correspondence_distance=2.0, transformation_epsilon=1e-4, azimuth_variance_deg=1.0, flags=flags)
     clouds, pairs, guesses = [], [], []
     for i in range(6):
         n = (8192, 4100, 2048, 3000, 8192, 1500)[i]

@@ -54,9 +54,15 @@ def test_kdtree_ties_pick_lowest_index():
     assert list(idx) == [24, 25, 26]
 
 
+# fp32 summation order of T * p (A:149): pairwise (Eigen >= 3.3, default) | linear chain (Eigen 3.2, flags bit 1)
+XF = (pytest.param("", 0, id="xf_pairwise"), pytest.param("_xflin", 2, id="xf_linear"))
+
+
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("tag,kw", (("default", {}), ("launch", LAUNCH)))
-def test_linearize_golden_cpp(golden, tag, kw):
-    r = R.RefAPDGICP(R.default_params(**kw))
+def test_linearize_golden_cpp(golden, tag, kw, sfx, flags):
+    r = R.RefAPDGICP(R.default_params(flags=flags, **kw))
+    tag = tag + sfx
     r.setInputSource(golden["lin_source"])
     r.setInputTarget(golden["lin_target"])
     for k in range(3):
@@ -74,19 +80,40 @@ def test_linearize_golden_cpp(golden, tag, kw):
         assert abs(cost_only - cost) < 1e-12 * cost
 
 
-def test_linearize_golden_numpy(golden):
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_linearize_golden_numpy(golden, sfx, flags):
     """Independent restatement: exact on the discrete outputs, 5e-6 on the smooth ones (fp32 atan2)."""
-    n = O.FastAPDGICP(O.Params(**LAUNCH))
+    n = O.FastAPDGICP(O.Params(flags=flags, **LAUNCH))
     n.setInputSource(golden["lin_source"])
     n.setInputTarget(golden["lin_target"])
     n.source_covs, n.target_covs = golden["lin_source_cov"], golden["lin_target_cov"]
     k = 1
-    cost, H, b = n.linearize(golden[f"lin_launch_{k}_T"])
-    assert np.array_equal(n.correspondences, golden[f"lin_launch_{k}_corr"])
-    assert np.array_equal(n.sq_distances, golden[f"lin_launch_{k}_sqd"])
-    assert rel_err(H, golden[f"lin_launch_{k}_H"]) < 5e-6
-    assert rel_err(b, golden[f"lin_launch_{k}_b"]) < 5e-6
-    assert abs(cost - golden[f"lin_launch_{k}_cost"]) < 5e-6 * cost
+    cost, H, b = n.linearize(golden[f"lin_launch{sfx}_{k}_T"])
+    assert np.array_equal(n.correspondences, golden[f"lin_launch{sfx}_{k}_corr"])
+    assert np.array_equal(n.sq_distances, golden[f"lin_launch{sfx}_{k}_sqd"])
+    assert rel_err(H, golden[f"lin_launch{sfx}_{k}_H"]) < 5e-6
+    assert rel_err(b, golden[f"lin_launch{sfx}_{k}_b"]) < 5e-6
+    assert abs(cost - golden[f"lin_launch{sfx}_{k}_cost"]) < 5e-6 * cost
+
+
+def test_transform_orders_by_hand():
+    """The two orders on a case small enough to evaluate by hand in fp32: pairwise (a + b) + (c + t), chain ((a + b) + c) + t."""
+    f = np.float32
+    T = np.eye(4)
+    T[0, :] = [1.0, 2.0 ** -12, 2.0 ** -24, 2.0 ** -24]
+    p = np.array([[1.0, 1.0, 1.0]], dtype=f)
+    # row 0: a = 1, b = 2^-12, c = 2^-24, t = 2^-24:  (a + b) = 1 + 2^-12 exactly; + c rounds back (half an ulp of 2^-23, ties to
+    # even), + t again -> 1 + 2^-12; pairwise: c + t = 2^-23 = one ulp -> 1 + 2^-12 + 2^-23
+    chain = O.transform_points_f32(T, p, True)[0, 0]
+    pair = O.transform_points_f32(T, p, False)[0, 0]
+    assert chain == f(1.0) + f(2.0 ** -12) and pair == f(f(1.0) + f(2.0 ** -12)) + f(2.0 ** -23) and pair != chain
+    for flags, want in ((0, pair), (2, chain)):  # the C++ restatement evaluates the same two values
+        r = R.RefAPDGICP(R.default_params(flags=flags, k_correspondences=1))
+        tgt = np.array([[0.0, 1.0, 1.0]], dtype=f)
+        r.setInputSource(p), r.setInputTarget(tgt)
+        r.linearize(T)
+        d = r.correspondences()[1][0]
+        assert d == f(want * want)   # (dy = dz = 0: the squared distance is the transformed x, squared)
 
 
 def test_serial_and_threaded_sums_agree(golden):
@@ -107,13 +134,15 @@ RUNS = {
 }
 
 
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("tag", list(RUNS))
-def test_align_golden_cpp(golden, scene, tag):
-    r = R.RefAPDGICP(R.default_params(**RUNS[tag]))
+def test_align_golden_cpp(golden, scene, tag, sfx, flags):
+    r = R.RefAPDGICP(R.default_params(flags=flags, **RUNS[tag]))
     pre = "lm_loop" if tag == "lm_loop" else "lin"
     r.setInputSource(golden[f"{pre}_source"])
     r.setInputTarget(golden[f"{pre}_target"])
     T = r.align(golden[f"{pre}_guess"])
+    tag = tag + sfx
     info = golden[f"{tag}_info"]
     assert [int(r.converged), r.nr_iterations, r.n_linearize, r.n_compute_error] == list(info)
     te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
@@ -121,39 +150,46 @@ def test_align_golden_cpp(golden, scene, tag):
     assert rel_err(r.final_hessian(), golden[f"{tag}_final_hessian"]) < 1e-9
 
 
-def test_align_golden_numpy_launch(golden, scene):
-    n = O.FastAPDGICP(O.Params(**LAUNCH))
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_align_golden_numpy_launch(golden, scene, sfx, flags):
+    n = O.FastAPDGICP(O.Params(flags=flags, **LAUNCH))
     n.setInputSource(golden["lin_source"])
     n.setInputTarget(golden["lin_target"])
     T = n.align(golden["lin_guess"])
-    assert [int(n.converged), n.nr_iterations, n.trace.n_linearize, n.trace.n_compute_error] == list(golden["lm_launch_info"])
-    te, re_ = scene.pose_error(golden["lm_launch_T"], T)
+    assert [int(n.converged), n.nr_iterations, n.trace.n_linearize, n.trace.n_compute_error] == list(golden[f"lm_launch{sfx}_info"])
+    te, re_ = scene.pose_error(golden[f"lm_launch{sfx}_T"], T)
     assert te < 1e-5 and re_ < 1e-5
 
 
-def test_degenerate_golden_cpp(golden):
-    r = R.RefAPDGICP(R.default_params(max_correspondence_distance=2.0))
+@pytest.mark.parametrize("sfx,flags", XF)
+def test_degenerate_golden_cpp(golden, sfx, flags):
+    r = R.RefAPDGICP(R.default_params(max_correspondence_distance=2.0, flags=flags))
     r.setInputSource(golden["deg_source"])
     r.setInputTarget(golden["deg_target"])
+    cost, H, b = r.linearize(golden["deg_T"])
+    corr, sqd = r.correspondences()
+    assert np.array_equal(corr, golden[f"deg_moved{sfx}_corr"]) and np.array_equal(sqd, golden[f"deg_moved{sfx}_sqd"])
+    assert rel_err(H, golden[f"deg_moved{sfx}_H"]) < 1e-10
     cost, H, b = r.linearize(np.eye(4))
     corr, sqd = r.correspondences()
-    assert np.array_equal(corr, golden["deg_corr"]) and corr[2] == -1
-    assert rel_err(H, golden["deg_H"]) < 1e-10 and rel_err(b, golden["deg_b"]) < 1e-10
+    assert np.array_equal(corr, golden[f"deg{sfx}_corr"]) and corr[2] == -1
+    assert rel_err(H, golden[f"deg{sfx}_H"]) < 1e-10 and rel_err(b, golden[f"deg{sfx}_b"]) < 1e-10
     M = r.mahalanobis()
     assert np.all(M[2] == 0)
     # +x-axis point: APD sigma_y,z ~ dist*sin(var)/cos(AoA) is huge -> tiny information in y/z
     assert M[0][1, 1] < 1e-3 * M[0][0, 0] or M[0][1, 1] < 1e-2
 
 
+@pytest.mark.parametrize("sfx,flags", XF)
 @pytest.mark.parametrize("tag,kw", (("rej", {}), ("fail", dict(lm_max_iterations=1))))
-def test_lm_rejection_paths_cpp(golden, scene, tag, kw):
-    r = R.RefAPDGICP(R.default_params(**kw))
+def test_lm_rejection_paths_cpp(golden, scene, tag, kw, sfx, flags):
+    r = R.RefAPDGICP(R.default_params(flags=flags, **kw))
     r.setInputSource(golden["rej_source"])
     r.setInputTarget(golden["rej_target"])
     T = r.align(None)
-    assert [int(r.converged), r.nr_iterations, r.n_linearize, r.n_compute_error] == list(golden[f"{tag}_info"])
-    assert (golden[f"{tag}_trace_rho"] < 0).any()
-    te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
+    assert [int(r.converged), r.nr_iterations, r.n_linearize, r.n_compute_error] == list(golden[f"{tag}{sfx}_info"])
+    assert (golden[f"{tag}{sfx}_trace_rho"] < 0).any()
+    te, re_ = scene.pose_error(golden[f"{tag}{sfx}_T"], T)
     assert te < 1e-6 and re_ < 1e-8
     if tag == "fail":
         assert not r.converged and r.nr_iterations < 63
