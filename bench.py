@@ -19,6 +19,7 @@ recorded on the handles' own streams (`timing.event_ms_per_step`).  Rank 0 print
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
 import socket
@@ -59,6 +60,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed executed-flops / brute-force legs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank (self-test of the N>1 path)")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="every rank uses GPU 0: exercises the N > 1 loop (late gather, barrier, MAX over ranks) on a one-GPU box; needs "
+                         "--dist-backend gloo (RCCL refuses two ranks on one device).  A self-test, not a scaling measurement")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl = RCCL over xGMI, records gathered from device memory (the measured configuration); gloo: the 96-byte records "
+                         "travel as CPU tensors through the same gather / barrier / all_reduce(MAX) code")
+    ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered records of the last step (uint8 [pairs, 96]) to this .npy file")
     return ap.parse_args()
 
 
@@ -94,6 +102,25 @@ def spawn_ranks(args) -> int:
             return rc or 124
         time.sleep(0.05)
     return rc
+
+
+def load_pmc(path=None, stamp=None):
+    """The committed PMC profile (profiles/pmc_nn_latest.json), or (None, reason): counters belong to the kernels they were
+    collected from, so a file whose source stamp (tools/pmc_nn_json.py: hash of riv-slam_amd/csrc/*) differs from the sources
+    this run was built from is refused -- the line then prints null for every PMC-derived field and says why."""
+    path = path or os.path.join(ROOT, "profiles", "pmc_nn_latest.json")
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+    except Exception as e:  # noqa: BLE001
+        return None, f"{os.path.relpath(path, ROOT)}: {type(e).__name__}"
+    if stamp is None:
+        stamp = importlib.import_module("riv-slam_amd.build").source_stamp()
+    have = pmc.get("source_stamp")
+    if have != stamp:
+        return None, (f"{os.path.relpath(path, ROOT)} was collected from kernel sources {have or '(unstamped)'}, this run is built from {stamp}: "
+                      "re-run tools/refresh_evidence.sh and commit the file")
+    return pmc, None
 
 
 def percentiles(xs):
@@ -138,6 +165,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    gloo = args.dist_backend == "gloo"
+    if args.ranks_share_gpu:
+        if world > 1 and not gloo:
+            raise SystemExit("--ranks-share-gpu needs --dist-backend gloo: RCCL refuses two ranks on one device")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     rccl_version = None
@@ -197,7 +229,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if gloo:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -207,7 +242,7 @@ def main():
                 os.dup2(saved_fd, 1)
                 os.close(saved_fd)
         try:
-            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            rccl_version = None if gloo else ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             rccl_version = "unknown"
     # slot s % H of the schedule: (handle, first cloud slot, pair table)
@@ -245,10 +280,13 @@ def main():
         ev = gather_done.get(h)
         if ev is not None:
             ev.synchronize()
-        local = bh.align_collect(ticket, device=True)        # zero-copy view of that step's records on the device
+        if gloo:   # (self-test backend: the records leave as a CPU tensor; the collective is complete when gather returns)
+            local = torch.from_numpy(bh.align_collect(ticket, device=False).view(np.uint8).reshape(-1, sharded.RESULT_BYTES))
+        else:
+            local = bh.align_collect(ticket, device=True)    # zero-copy view of that step's records on the device
         lat.append(time.perf_counter() - t_submit)
         out = aligner.gather(local, total_pairs, wait=False)
-        if use_dist:
+        if use_dist and not gloo:
             if ev is None:
                 ev = gather_done[h] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -301,7 +339,7 @@ def main():
         host_s.append(time.perf_counter() - t0)
         event_ms.append(max(ev0[r].elapsed_time(e) for e in ev1[r][:len(hstreams) + 1]))
     nn_ms, nn_launches, nn_pairs = nn_acc
-    host_t = torch.tensor(host_s, dtype=torch.float64, device="cuda")
+    host_t = torch.tensor(host_s, dtype=torch.float64, device="cpu" if gloo else "cuda")
     if use_dist:
         dist.all_reduce(host_t, op=dist.ReduceOp.MAX)     # per repetition: the slowest rank
     host_s = [float(v) for v in host_t.cpu()]
@@ -333,11 +371,8 @@ def main():
         n_err = float(recs["n_compute_error"].mean())
         b_reg = 40.0 * (2 * n) + n_lin * (108.0 * n + 16.0 * n) + n_err * 56.0 * n
         hbm_gbs = b_reg * P / (ms_per_step * 1e-3) / 1e9
-        pmc, traffic, issue = None, None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_nn_latest.json")))
-        except Exception:
-            pass
+        traffic, issue = None, None
+        pmc, pmc_rejected = load_pmc()
         # PMC numbers come from a separate committed profiling run (rocprofv3 --pmc passes cannot run inside this process):
         # reported only when that run had this launch shape, and tagged with where they come from
         step_issue = None
@@ -382,6 +417,7 @@ def main():
                        "kind": args.kind, "nn_mode": nn_mode, "nn_sources_per_lane": nn_S, "nn_target_splits": nn_T,
                        "ticks": ticks, "steps_in_flight": H, "batch_handles": len(batches)},
             "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": rccl_version,
+            "dist_backend": (args.dist_backend if use_dist else None), "ranks_share_gpu": bool(args.ranks_share_gpu),
             "timing": {"repeats": R, "steps_per_repeat": K, "statistic": "median over repeats (each: K steps, barrier + sync both sides, max over ranks)",
                        "host_ms_per_step": percentiles([t / K * 1e3 for t in host_s]),
                        "event_ms_per_step": percentiles([t / K for t in event_ms]),
@@ -410,6 +446,7 @@ def main():
                                  "`traffic` (PMC, committed profile) also carries the warm-start hints and neighbour-keeping records: 2.2 x the algorithmic bytes"},
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
+            "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,
                                   "note": "whole step: B_reg x pairs / ms_per_step; B_reg = 40(N+M) + L(108N+16M) + E 56N with the run's mean L, E"},
@@ -585,6 +622,8 @@ def main():
                 out["parity"] = {"pairs_checked": checked, "max_t_err_m": worst_t, "max_r_err_rad": worst_r, "tolerance": "1e-3 m / 1e-4 rad",
                                  "oracle": "parity unpinned (restatement; the reference cannot be built in this image)"}
                 assert worst_t <= 1e-3 and worst_r <= 1e-4, (worst_t, worst_r)
+        if args.dump_records:
+            np.save(args.dump_records, gathered.detach().cpu().numpy())
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -13,6 +13,19 @@ DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os
 FLAGS = [*os.environ.get("APD_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
+def source_stamp() -> str:
+    """Fingerprint of the kernel sources (csrc/*.hip, *.hpp): profiles/pmc_nn_latest.json carries the stamp of the sources its
+    counters were collected from (tools/pmc_nn_json.py), and bench.py reports PMC-derived numbers only when it equals this one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode() + b"\0")
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

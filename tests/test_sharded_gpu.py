@@ -162,3 +162,44 @@ def test_two_ranks_share_one_gpu_with_the_product_engine(tmp_path, scene, n_pair
     single.set_clouds(0, clouds)
     want = single.align([(2 * i, 2 * i + 1) for i in range(n_pairs)], guesses)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ("gn", "lm"))
+def test_bench_timed_loop_with_two_ranks_on_one_gpu(tmp_path, scene, optimizer):
+    """bench.py's OWN N > 1 loop -- rank spawn, steps kept in flight, the gather of a step waited for one round later,
+    barrier + synchronise around the timed region, all_reduce(MAX) of the repetition times -- with world size 2 on the one
+    GPU there is (`--ranks-share-gpu --dist-backend gloo`; the 8-GPU run goes through exactly this code with RCCL).  One JSON
+    line, world_size 2, and the gathered records of both ranks' blocks equal those of a single handle."""
+    import importlib
+    import json
+    import numpy as np
+    reg = importlib.import_module("riv-slam_amd.registration")
+    sys.path.insert(0, ROOT)
+    import bench
+    P, n = 4, 2048
+    dump = tmp_path / "records.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-share-gpu", "--dist-backend", "gloo", "--steps", "5",
+                        "--warmup", "2", "--repeats", "2", "--pairs-per-gpu", str(P), "--points", str(n), "--optimizer", optimizer,
+                        "--kind", "loop" if optimizer == "lm" else "odometry", "--no-cpu-baseline", "--no-diagnostics", "--dump-records", str(dump)],
+                       capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["world_size"] == 2 and d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["ranks_share_gpu"] is True
+    assert d["config"]["pairs_per_gpu"] == P and d["timing"]["repeats"] == 2 and d["value"] > 0
+    assert abs(d["value"] - 2 * P / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]   # whole job: both ranks' pairs per step
+    got = np.frombuffer(np.load(dump).tobytes(), dtype=reg.RESULT_DTYPE)
+    assert len(got) == 2 * P
+    # the same 2 P pairs (bench.py seeds pair p of the JOB with pair_seed(2, p)) on one handle
+    kind = "loop" if optimizer == "lm" else "odometry"
+    single = reg.BatchAPDGICP(bench.bench_params(reg, optimizer))
+    clouds, guesses = [], []
+    for p in range(2 * P):
+        s_, t_, _, g = scene.make_pair(n, n, scene.pair_seed(2, p), kind)
+        clouds += [s_, t_]
+        guesses.append(np.eye(4, dtype=np.float32) if kind == "loop" else g)
+    single.set_clouds(0, clouds)
+    want = single.align([(2 * i, 2 * i + 1) for i in range(2 * P)], guesses)
+    assert got.tobytes() == want.tobytes()

@@ -2,10 +2,17 @@
 """Per-launch PMC numbers of the bench's kernels (batch launches only) from separate rocprofv3 --pmc passes: writes
 profiles/pmc_nn_latest.json, which bench.py reports as roofline.traffic / roofline_issue when the launch shape matches its own.
 usage: pmc_nn_json.py out.json points kind pass1.db [pass2.db ...]
-FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (it reports half of a wide coalesced read)."""
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (it reports half of a wide coalesced read).
+The file is stamped with a hash of riv-slam_amd/csrc/* (build.source_stamp): bench.py refuses a file whose stamp is not that of
+the sources it runs, so counters of an older kernel can never be divided by the launch times of a newer one."""
+import importlib
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+source_stamp = importlib.import_module("riv-slam_amd.build").source_stamp()   # the sources the profiled library was built from
 
 out_path, points, kind = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
@@ -26,7 +33,7 @@ nn = [key for key in per_kernel if key[0].startswith("k_nn_")]
 assert len(nn) == 1, f"expected exactly one batch instantiation of the search kernel, found {nn}"
 kernel, gx, gy, wg = nn[0]
 vals = per_kernel[nn[0]]
-out = {"kernel": kernel, "grid": [gx, gy, 1], "workgroup": wg, "points": points, "pairs_per_launch": gy, "kind": kind, "nn_mode": "pruned",
+out = {"source_stamp": source_stamp, "kernel": kernel, "grid": [gx, gy, 1], "workgroup": wg, "points": points, "pairs_per_launch": gy, "kind": kind, "nn_mode": "pruned",
        "source": "profiles/pmc_nn_latest.json (tools/pmc_nn_json.py over the rocprofv3 --pmc passes of tools/refresh_evidence.sh)",
        "dispatches": {k: v[1] for k, v in vals.items()}}
 for k, v in vals.items():
