@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "apdgicp_hip.h"
@@ -54,6 +55,9 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
  protected:
   using Base::converged_;
   using Base::corr_dist_threshold_;
+  using Base::force_no_recompute_;
+  using Base::target_cloud_updated_;
+  using Base::tree_;
   using Base::final_transformation_;
   using Base::input_;
   using Base::max_iterations_;
@@ -131,12 +135,40 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
         apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
       report("setInputTarget");
   }
+  /// What PCL itself does inside align(): pcl::Registration::initCompute() rebuilds the BASE class's own search tree
+  /// (`tree_->setInputCloud(target_)`, a FLANN kd-tree, single-threaded on the CPU) for every NEW target -- ~1 ms at 8k points,
+  /// tens of ms for a submap -- in front of a GPU align that takes 0.1 ms.  Nothing on this class's path reads that tree; it only
+  /// serves the base-class getFitnessScore() / getSearchMethodTarget() (scan_matching_odometry_nodelet.cpp:697-707,
+  /// loop_detector.cpp:229).  on = true hands the tree back with force_no_recompute (pcl/registration/registration.h
+  /// setSearchMethodTarget), so initCompute() leaves it alone: getFitnessScore() / getSearchMethodTarget() then answer about
+  /// whatever cloud the tree was last built from (or none) and MUST be replaced by fitnessScore() / inlierFraction() below or
+  /// LoopVerifierHip, which run on the device against the real target.  on = false restores PCL's behaviour.
+  void setSkipBaseSearchTree(bool on) {
+    if (on) {
+      Base::setSearchMethodTarget(tree_, true);
+    } else {
+      force_no_recompute_ = false;   // (the setter can only turn the flag on; it is a protected member)
+      target_cloud_updated_ = true;
+    }
+    skip_base_tree_ = on;
+  }
+  bool skipsBaseSearchTree() const { return skip_base_tree_; }
+  /// pcl::Registration::getFitnessScore(max_range) at the last pose, on the device against the REAL target (also a device target)
+  double fitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double s = std::numeric_limits<double>::max();
+    if (!handle_ || apdgicp_fitness_score(handle_, result_.T, max_range, &s, nullptr) != 0) report("fitnessScore");
+    return s;
+  }
+
   /// scan-to-map mode: the target already lives in device memory (apdgicp_submap_points, 16-byte stride), so the
   /// setInputTarget(keyframe_cloud_s2m) of scan_matching_odometry_nodelet.cpp:615 needs no host cloud.  PCL's align()
-  /// insists on a non-null target_, which gets a one-point placeholder; nothing on this path reads it.
+  /// insists on a non-null target_, which gets a ONE-POINT PLACEHOLDER far outside any scene (1e18 on every axis): the
+  /// base-class getFitnessScore() / getSearchMethodTarget() would answer about that placeholder -- an absurd 3e36, or DBL_MAX
+  /// with a max_range, never a plausible number -- so after this call use fitnessScore() / inlierFraction() instead.
   void setInputTargetDevice(const float* device_xyz, std::size_t n, std::size_t stride_bytes) {
     typename PointCloudTarget::Ptr placeholder(new PointCloudTarget());
     placeholder->resize(1);
+    placeholder->at(0).x = placeholder->at(0).y = placeholder->at(0).z = 1e18f;
     Base::setInputTarget(placeholder);
     if (handle_ && n && apdgicp_set_target(handle_, device_xyz, (int64_t)n, (int64_t)stride_bytes, 1, ++device_epoch_) != 0)
       report("setInputTargetDevice");
@@ -259,6 +291,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   apdgicp_result result_{};
   Eigen::Matrix<double, 6, 6> final_hessian_ = Eigen::Matrix<double, 6, 6>::Identity();
   std::size_t host_transform_max_ = 65536;
+  bool skip_base_tree_ = false;
 };
 
 }  // namespace fast_gicp

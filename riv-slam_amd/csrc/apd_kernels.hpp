@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
     }
   }
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
-  if (w.stats && (GIVEN && W > 1 ? lane == 0 : tid == 0)) {  // (a cooperating block: every wave reports its share and counts as a wave)
+  if (w.stats && lane == 0) {  // (W > 1: every wave of the block scanned its own share of the groups, reports it and counts as a wave)
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
     atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull), atomicAdd(w.stats + 5, (unsigned long long)n_batches);
     if (tstat) atomicAdd(w.stats + 10, (unsigned long long)tcy[0]), atomicAdd(w.stats + 11, (unsigned long long)tcy[1]), atomicAdd(w.stats + 12, (unsigned long long)tcy[2]), atomicAdd(w.stats + 14, 1ull);

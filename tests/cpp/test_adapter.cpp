@@ -120,6 +120,65 @@ static int run_protocols(const float* s, int ns, const float* t, int nt, const f
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// What PCL's align() adds in front of the GPU path: initCompute() rebuilds the base class's search tree for every NEW target
+// (tests/pcl_shim models it: KdTree::n_builds).  Default: one build per new target, none for a pointer-equal one, and the
+// base-class getFitnessScore() agrees with the device's fitnessScore().  setSkipBaseSearchTree(true): no build at all, the
+// base-class score goes stale (it still answers about the last tree), the device score follows the real target.
+static int run_base_tree(const float* s, int ns, const float* t, int nt, const float* guess) {
+  using Reg = fast_gicp::FastAPDGICPHip<PointT, PointT>;
+  auto registration = select_registration_method_hip();
+  Reg& reg = *dynamic_cast<Reg*>(registration.get());
+  std::vector<float> shifted(t, t + 3 * (size_t)nt);
+  for (int i = 0; i < nt; i++) shifted[3 * i + 1] += 0.7f;
+  pcl::PointCloud<PointT>::ConstPtr A = make_cloud(t, nt), B = make_cloud(t, nt), D = make_cloud(shifted.data(), nt), E = make_cloud(t, nt);
+  pcl::PointCloud<PointT>::ConstPtr source = make_cloud(s, ns);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  pcl::Registration<PointT, PointT>::Matrix4 g;
+  for (int i = 0; i < 16; i++) g.data()[i] = guess[i];
+  auto builds = [&]() { return registration->getSearchMethodTarget()->n_builds; };
+  registration->setInputSource(source);
+  registration->setInputTarget(A), registration->align(*aligned, g);
+  const int b1 = builds();
+  registration->setInputTarget(A), registration->align(*aligned, g);   // pointer-equal keyframe: cached on both sides
+  const int b2 = builds();
+  registration->setInputTarget(B), registration->align(*aligned, g);   // a new target object: PCL rebuilds its tree
+  const int b3 = builds();
+  const double f_pcl = registration->getFitnessScore(4.0), f_dev = reg.fitnessScore(4.0);
+  reg.setSkipBaseSearchTree(true);
+  registration->setInputTarget(D), registration->align(*aligned, g);   // new target, shifted by 0.7 m: no build
+  const int b4 = builds();
+  const int conv_skip = registration->hasConverged() ? 1 : 0;
+  const double f_pcl_stale = registration->getFitnessScore(4.0), f_dev_skip = reg.fitnessScore(4.0);
+  const bool tree_is_stale = registration->getSearchMethodTarget()->getInputCloud() == B;
+  reg.setSkipBaseSearchTree(false);
+  registration->setInputTarget(E), registration->align(*aligned, g);
+  const int b5 = builds();
+  const double f_pcl_back = registration->getFitnessScore(4.0), f_dev_back = reg.fitnessScore(4.0);
+  // a device-resident target: the base class only ever sees the far-away one-point placeholder
+  apdgicp_submap* sm = nullptr;
+  double f_pcl_placeholder = -1.0, f_pcl_placeholder_unbounded = -1.0, f_dev_device_target = -1.0;
+  if (apdgicp_submap_create(0, nullptr, &sm) == 0) {
+    const void* xyz[1] = {&E->at(0).x};
+    const int64_t cnt[1] = {(int64_t)E->size()};
+    int64_t m = 0;
+    const float* dev = nullptr;
+    if (apdgicp_submap_assemble(sm, 1, xyz, cnt, sizeof(PointT), 16, 0, nullptr, nullptr, &m) == 0 && apdgicp_submap_points(sm, &dev, &m) == 0) {
+      reg.setInputTargetDevice(dev, (std::size_t)m, 16);
+      registration->align(*aligned, g);
+      f_pcl_placeholder = registration->getFitnessScore(4.0), f_pcl_placeholder_unbounded = registration->getFitnessScore();
+      f_dev_device_target = reg.fitnessScore(4.0);
+    }
+    apdgicp_submap_destroy(sm);
+  }
+  std::printf("{\"builds\": [%d, %d, %d, %d, %d], \"f_pcl\": %.12g, \"f_dev\": %.12g, \"f_pcl_stale\": %.12g, \"f_dev_skip\": %.12g, "
+              "\"tree_is_stale\": %d, \"converged_with_skip\": %d, \"f_pcl_back\": %.12g, \"f_dev_back\": %.12g, \"f_pcl_placeholder\": %.6g, "
+              "\"f_pcl_placeholder_unbounded\": %.6g, \"f_dev_device_target\": %.12g}\n",
+              b1, b2, b3, b4, b5, f_pcl, f_dev, f_pcl_stale, f_dev_skip, tree_is_stale ? 1 : 0, conv_skip, f_pcl_back, f_dev_back, f_pcl_placeholder,
+              f_pcl_placeholder_unbounded, f_dev_device_target);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("compile-only\n");
@@ -134,6 +193,7 @@ int main(int argc, char** argv) {
   if (std::fread(s.data(), 4, s.size(), f) != s.size() || std::fread(t.data(), 4, t.size(), f) != t.size()) return 2;
   std::fclose(f);
   if (argc > 2 && std::string(argv[2]) == "--protocol") return run_protocols(s.data(), n[0], t.data(), n[1], guess);
+  if (argc > 2 && std::string(argv[2]) == "--base-tree") return run_base_tree(s.data(), n[0], t.data(), n[1], guess);
 
   auto registration = select_registration_method_hip();
   auto source = make_cloud(s.data(), n[0]);

@@ -6,6 +6,7 @@
 #pragma once
 #include <cfloat>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -71,9 +72,47 @@ struct PointCloud {
   void resize(std::size_t n) { points.resize(n); }
 };
 
+namespace search {
+// pcl::search::KdTree as pcl::Registration uses it (tree_): setInputCloud is where real PCL builds a FLANN kd-tree on the CPU,
+// O(n log n), single-threaded -- counted here (n_builds) so that a test can see WHEN the base class does it.  The search itself is
+// a linear scan: the shim is test infrastructure for scan-sized clouds.
+template <typename PointT>
+class KdTree {
+ public:
+  using Ptr = std::shared_ptr<KdTree<PointT>>;
+  using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
+  void setInputCloud(const PointCloudConstPtr& cloud) {
+    input_ = cloud;
+    n_builds++;
+  }
+  PointCloudConstPtr getInputCloud() const { return input_; }
+  int nearestKSearch(const PointT& p, int k, std::vector<int>& idx, std::vector<float>& d2) const {
+    if (!input_ || input_->empty() || k != 1) return 0;
+    float best = std::numeric_limits<float>::infinity();
+    int bi = -1;
+    for (std::size_t i = 0; i < input_->size(); i++) {
+      const PointT& q = input_->at(i);
+      const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+      float d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      if (d < best) best = d, bi = (int)i;
+    }
+    idx.assign(1, bi), d2.assign(1, best);
+    return 1;
+  }
+  int n_builds = 0;
+
+ private:
+  PointCloudConstPtr input_;
+};
+}  // namespace search
+
 template <typename PointSource, typename PointTarget, typename Scalar = float>
 class Registration {
  public:
+  using KdTree = search::KdTree<PointTarget>;
+  using KdTreePtr = typename KdTree::Ptr;
   using Matrix4 = Eigen::ShimMatrix<Scalar, 4, 4>;
   using PointCloudSource = PointCloud<PointSource>;
   using PointCloudSourcePtr = typename PointCloudSource::Ptr;
@@ -83,10 +122,39 @@ class Registration {
   using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
   using Ptr = std::shared_ptr<Registration<PointSource, PointTarget, Scalar>>;
 
-  Registration() { final_transformation_.setIdentity(); }
+  Registration() : tree_(new KdTree()) { final_transformation_.setIdentity(); }
   virtual ~Registration() {}
   virtual void setInputSource(const PointCloudSourceConstPtr& cloud) { input_ = cloud; }
-  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) { target_ = cloud; }
+  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) {  // registration.hpp: keeps the pointer, flags the tree as stale
+    if (!cloud || cloud->empty()) return;
+    target_ = cloud;
+    target_cloud_updated_ = true;
+  }
+  // registration.h: a tree handed over with force_no_recompute is never rebuilt by initCompute (the flag only ever turns on here)
+  void setSearchMethodTarget(const KdTreePtr& tree, bool force_no_recompute = false) {
+    tree_ = tree;
+    if (force_no_recompute) force_no_recompute_ = true;
+    target_cloud_updated_ = true;
+  }
+  KdTreePtr getSearchMethodTarget() const { return tree_; }
+  // registration.hpp getFitnessScore(max_range): mean squared 1-NN distance of the transformed input in tree_ over the points
+  // with SQUARED distance <= max_range; answers about whatever cloud tree_ was last built from
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double sum = 0.0;
+    int nr = 0;
+    std::vector<int> idx(1);
+    std::vector<float> d2(1);
+    const Scalar* T = final_transformation_.data();
+    for (std::size_t i = 0; input_ && i < input_->size(); i++) {
+      PointTarget p;
+      const PointSource& a = input_->at(i);
+      p.x = T[0] * a.x + T[4] * a.y + T[8] * a.z + T[12];
+      p.y = T[1] * a.x + T[5] * a.y + T[9] * a.z + T[13];
+      p.z = T[2] * a.x + T[6] * a.y + T[10] * a.z + T[14];
+      if (tree_->nearestKSearch(p, 1, idx, d2) == 1 && d2[0] <= max_range) sum += d2[0], nr++;
+    }
+    return nr > 0 ? sum / nr : std::numeric_limits<double>::max();
+  }
   void setMaximumIterations(int n) { max_iterations_ = n; }
   void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
   void setMaxCorrespondenceDistance(double d) { corr_dist_threshold_ = d; }
@@ -94,7 +162,8 @@ class Registration {
   bool hasConverged() const { return converged_; }
   Matrix4 getFinalTransformation() const { return final_transformation_; }
   void align(PointCloudSource& output) { align(output, Matrix4::Identity()); }
-  void align(PointCloudSource& output, const Matrix4& guess) {  // pcl::Registration::align: reset, then the virtual
+  void align(PointCloudSource& output, const Matrix4& guess) {  // pcl::Registration::align: initCompute, reset, then the virtual
+    if (!initCompute()) return;
     converged_ = false;
     nr_iterations_ = 0;
     final_transformation_ = guess;
@@ -103,7 +172,19 @@ class Registration {
   }
 
  protected:
+  // registration.hpp initCompute: "Only update target kd-tree if a new target cloud was set" -- a CPU kd-tree build per NEW target
+  bool initCompute() {
+    if (!target_) return false;
+    if (target_cloud_updated_ && !force_no_recompute_) {
+      tree_->setInputCloud(target_);
+      target_cloud_updated_ = false;
+    }
+    return (bool)input_;
+  }
   virtual void computeTransformation(PointCloudSource& output, const Matrix4& guess) = 0;
+  KdTreePtr tree_;
+  bool target_cloud_updated_ = true;
+  bool force_no_recompute_ = false;
   std::string reg_name_;
   PointCloudSourceConstPtr input_;
   PointCloudTargetConstPtr target_;

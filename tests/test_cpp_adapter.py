@@ -78,3 +78,31 @@ def test_adapter_protocol_timing_mode(scene, tmp_path):
     assert d["converged"] == 1 and 0.0 < d["inlier_fraction"] <= 1.0
     for k in ("align_cpp_single_ms", "align_cpp_100_times_per_call_ms", "align_cpp_100_times_reuse_per_call_ms", "odometry_frame_ms"):
         assert 0.0 < d[k]["p10"] <= d[k]["median"] <= d[k]["p90"] < 50.0, (k, d[k])
+
+
+@pytest.mark.gpu
+def test_what_pcl_align_adds_and_the_opt_out(golden, tmp_path):
+    """pcl::Registration::align() -> initCompute() rebuilds the BASE class's kd-tree on the CPU for every new target (the shim
+    counts the builds).  Default: one build per new target object, none for a pointer-equal one, base-class getFitnessScore ==
+    device fitnessScore.  setSkipBaseSearchTree(true): no builds, the registration is unaffected, the base-class score is stale
+    (documented: use fitnessScore() / inlierFraction()), the device score follows the real target.  A device-resident target
+    leaves the base class with a far-away placeholder: its score is DBL_MAX / absurd, never plausible."""
+    import json
+    exe = build_exe()
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    path = tmp_path / "pair.bin"
+    with open(path, "wb") as f:
+        np.array([len(src), len(tgt)], dtype=np.int32).tofile(f)
+        np.asfortranarray(guess).T.astype(np.float32).tofile(f)
+        src.astype(np.float32).tofile(f)
+        tgt.astype(np.float32).tofile(f)
+    out = subprocess.run([exe, str(path), "--base-tree"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["builds"] == [1, 1, 2, 2, 3]
+    assert abs(d["f_pcl"] - d["f_dev"]) <= 1e-5 * d["f_dev"] and 0 < d["f_dev"] < 4.0
+    assert d["converged_with_skip"] == 1 and d["tree_is_stale"] == 1
+    assert abs(d["f_pcl_stale"] - d["f_dev_skip"]) > 0.05 * d["f_dev_skip"]     # the base class answers about the PREVIOUS target
+    assert abs(d["f_pcl_back"] - d["f_dev_back"]) <= 1e-5 * d["f_dev_back"]
+    assert d["f_pcl_placeholder"] > 1e300 and d["f_pcl_placeholder_unbounded"] > 1e30
+    assert abs(d["f_dev_device_target"] - d["f_dev_back"]) <= 1e-9 * d["f_dev_back"]

@@ -966,11 +966,12 @@ def test_large_cloud_generic_sort_path(reg, scene):
     assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
 
 
-def test_c5_dense_submap_correspondences(reg, scene):
-    """BASELINE configs[4]: 100k-point source against a 500k-point accumulated map (generic sort path,
-    many group-box batches).  One linearize + 2 GN iterations against the CPU oracle."""
+def test_c5_dense_submap_gn20(reg, scene):
+    """BASELINE configs[4] as SURVEY 8d states it: 100k-point source against a 500k-point accumulated map (generic sort path,
+    super boxes, many group-box batches), 20 Gauss-Newton iterations, against the CPU oracle: correspondences and fp32
+    distances at the guess bit-exact, H / b / cost 5e-6, exactly 20 linearisations, final pose inside the north-star tolerance."""
     src, tgt, _, guess = scene.make_pair(100_000, 500_000, scene.pair_seed(5, 0), "odometry")
-    kw = dict(optimizer=1, max_iterations=2, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
+    kw = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300,
               max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
     g, o = both(reg, src, tgt, **kw)
     c1, H1, b1 = g.linearize(guess.astype(np.float64))
@@ -981,8 +982,13 @@ def test_c5_dense_submap_correspondences(reg, scene):
     assert np.array_equal(cg, co)
     assert rel_err(H1, H2) < 5e-6 and rel_err(b1, b2) < 5e-6 and abs(c1 - c2) < 5e-6 * c2
     T, To = g.align(guess), o.align(guess)
+    assert g.result.n_linearize == 20 == o.n_linearize and g.result.iterations == 19 == o.nr_iterations
     te, re_ = scene.pose_error(To, T)
+    print("C5 GN-20 pose difference vs oracle", te, re_)
     assert te <= T_TOL and re_ <= R_TOL
+    cg, sg = g.correspondences()      # after the 20th linearize: the same correspondences as the oracle's last update
+    co, so = o.correspondences()
+    assert np.mean(cg == co) > 0.9999
 
 
 # ------------------------------------------------------------------ SURVEY 8f rows
