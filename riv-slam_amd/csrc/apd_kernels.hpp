@@ -607,6 +607,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float readlane_f63(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63)); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, off, 64), hi = __shfl_xor((unsigned)(v >> 32), off, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
 // wave-wide min / max through DPP (row_shr 1,2,4,8, row_bcast 15/31; lanes without a source keep their own value),
 // result read from lane 63 into an SGPR: uniform, no LDS traffic
 template <bool MAX>
@@ -1054,10 +1064,38 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   // re-scan used to run in every wave of k_linearize that held a single point without the bit, i.e. in nearly all of them
   // even when nine points in ten had kept their neighbour.  (Equal minima in several chunks -- kTieBit -- stay with
   // k_linearize's scan of the whole target.)
+  // Equal minima in several chunks (kTieBit: two different targets at exactly the same fp32 distance, or duplicates -- about one
+  // point search in four million on radar scans).  The wave settles it here, together: every lane looks at a 64th of the target
+  // for the lowest original index at that distance, about 10 us.  (Until round 4 the bit travelled to k_linearize, where the ONE
+  // lane that held the point walked the whole target: 1.1 ms for 8192 targets, during which its launch -- and with it the tick
+  // of every pair of a pooled batch -- stood still: one tie per batch of 32 loop-closure pairs was 1.03 -> 1.9 ms per batch.)
   if (wid == 0) {
 #pragma unroll
     for (int s = 0; s < S; s++) {
-      const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & kTieBit);
+      unsigned long long tmask = __ballot(pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && (bestc[s] & kTieBit) != 0);
+      while (tmask) {
+        const int l = __builtin_ctzll(tmask);
+        tmask &= tmask - 1;
+        const float qx = readlane_f(px[s], l), qy = readlane_f(py[s], l), qz = readlane_f(pz[s], l), qb = readlane_f(best[s], l);
+        unsigned long long key = ~0ull;  // (original index << 32 | sorted index) of the best candidate this lane has seen
+#pragma unroll 4
+        for (int g = lane; g < M; g += 64) {
+          const float4 t = G(tgt.pts)[g];
+          const unsigned long long k_ = ((unsigned long long)__float_as_uint(t.w) << 32) | (unsigned)g;  // (.w: the original index, >= 0)
+          if (sqdist1(t.x, t.y, t.z, qx, qy, qz) == qb && k_ < key) key = k_;
+        }
+        key = wave_min_u64(key);
+        if (lane == l && key != ~0ull) {
+          const int j = (int)(unsigned)key;
+          const float4 tq = G(tgt.pts)[j];
+          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+          bestc[s] = (unsigned)(j / kChunk) | kKeptBit;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & (kTieBit | kKeptBit));
       if (resolve) {
         const int c0 = (int)(bestc[s] & kChunkMask) * kChunk;
         int j = -1, jorig = 0x7fffffff;
@@ -1253,15 +1291,6 @@ __device__ __forceinline__ unsigned long long wave_sort_u64(unsigned long long v
   }
   return v;
 }
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)v, off, 64), hi = __shfl_xor((unsigned)(v >> 32), off, 64);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    v = o < v ? o : v;
-  }
-  return v;
-}
 // A threshold tk with k <= #{keys <= tk} <= keep_max among the up-to-3 keys per lane (~0ull = absent; the keys are unique and more
 // than keep_max of them are present): bisection by rank with the keys themselves as probes -- the key in the lowest lane still
 // between the bounds, its rank counted with two or three ballots; a probe outside [k, keep_max] becomes the new lower or upper
@@ -1315,7 +1344,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 
 __device__ __forceinline__ unsigned long long dist_key(float d, int orig) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)orig; }
 

@@ -950,6 +950,20 @@ def test_exact_ties_resolve_to_the_lowest_original_index(reg):
         assert np.array_equal(cg, co), mode
         assert np.array_equal(sg.view(np.uint32), so.view(np.uint32)), mode
         assert np.abs(g.getTargetCovariances()[:, :3, :3] - o.covariances("target")).max() <= 1e-10, mode
+    # every shape of the search kernel settles the ties itself (nn_search: the wave looks through the target together), and
+    # identically: the batch records of a short Gauss-Newton run -- its first tick sees all 64 ties -- are byte-equal to those
+    # of the brute-force kernels, whose ties k_linearize resolves
+    gn = dict(optimizer=1, max_iterations=3, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=3.0)
+    want = None
+    for env, one_group in (({"APDGICP_NN_MODE": "brute"}, False), ({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "2"}, False),
+                           ({"APDGICP_NN_W": "4"}, False), ({"APDGICP_NN_W": "8"}, False), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True)):
+        b = _handle_with_env(reg, reg.BatchAPDGICP, env, **gn)
+        if one_group:
+            b.set_pair_groups(1)
+        b.set_clouds(0, [src, tgt, src, tgt])
+        got = b.align([(0, 1), (2, 3)]).tobytes()
+        want = want or got
+        assert got == want, env
 
 
 def test_large_cloud_generic_sort_path(reg, scene):

@@ -58,7 +58,9 @@ def _worker(rank, world, port, n_pairs, n_pts, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     sh = importlib.import_module("riv-slam_amd.sharded")
 
     class OracleEngine:

@@ -103,7 +103,9 @@ CHILD2 = textwrap.dedent("""
     scene = importlib.import_module("riv-slam_amd.scene")
     sharded = importlib.import_module("riv-slam_amd.sharded")
     rank, world, P = int(os.environ["RANK"]), 2, int(os.environ["APD_PAIRS"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import datetime
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     params = reg.default_params(max_correspondence_distance=2.0, transformation_epsilon=0.01, azimuth_variance_deg=1.0)
     b = reg.BatchAPDGICP(params, device=0)
 

@@ -18,7 +18,7 @@ _ge.build()
 reg = importlib.import_module("riv-slam_amd.registration")
 scene = importlib.import_module("riv-slam_amd.scene")
 
-LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0, flags=int(os.environ.get("FLAGS", 0)))
 P, N = int(os.environ.get("PAIRS", 32)), int(os.environ.get("POINTS", 8192))
 REPS = int(os.environ.get("REPS", 24))
 clouds, guesses = [], []
