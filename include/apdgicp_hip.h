@@ -230,7 +230,9 @@ int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream);              /* s
  *   still run, pairs leave as they converge and the pairs of the next batch join between two ticks, so a batch is never held
  *   by the slowest pair of another one and the GPU never waits for the host (ticks are enqueued two chunks ahead by whichever
  *   call of the handle is running; collect pumps until its batch is done).  A ticket stays collectable until its lane is
- *   needed again: the sixteenth enqueue after its own at the latest.  A cloud slot referenced by a batch in flight must not be
+ *   needed again: the sixteenth enqueue after its own at the latest (a batch with more pairs or larger clouds than any before makes
+ *   the pool lay itself out anew; the device record pointer of an EARLIER ticket collected after that is a copy of its
+ *   host records, not a view of the pool).  A cloud slot referenced by a batch in flight must not be
  *   replaced -- set_cloud(s) on such a slot first waits for that batch -- so callers that want overlap give consecutive batches
  *   disjoint slot ranges (keyframe clouds that stay registered are shared freely).  If a covariance launch raises the device
  *   error flag, every batch in flight at that moment fails at its collect; the handle stays usable.

@@ -16,8 +16,9 @@
 // batches queued.  Gauss-Newton batches run on `in_flight` handles with one pair group each (bench.py's schedule);
 // Levenberg-Marquardt batches -- the reference's default -- run on ONE handle whose pair pool merges the batches in flight
 // (include/apdgicp_hip.h), each in its own range of cloud slots.  A worker that fails -- bad cloud, HIP error, device error
-// flag -- still takes part in the collective with a zeroed block and reports the error at collect(): no rank is left
-// waiting in ncclAllGather (every rank calls the collectives in ticket order).
+// flag, even a failed allocation of its record buffers (preallocated fallback buffers) -- still takes part in the collective
+// with a zeroed block and reports the error at collect(): no rank is left waiting in ncclAllGather (every rank calls the
+// collectives in ticket order; when a rank truly cannot, the communicators are aborted and every collect() fails).
 //
 // Needs <hip/hip_runtime_api.h> and <rccl/rccl.h> (link amdhip64 + rccl + pthread).  Header-only.
 #ifndef FAST_GICP_SHARDED_BATCH_HIP_HPP
@@ -27,6 +28,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -119,6 +121,11 @@ class ShardedBatchAlignerHip {
           error_ = "event creation failed";
           return;
         }
+      if (hipMalloc((void**)&k.fb_send, kFallbackBytes) != hipSuccess || hipMalloc((void**)&k.fb_recv, kFallbackBytes * (size_t)D) != hipSuccess ||
+          hipMemset(k.fb_send, 0, kFallbackBytes) != hipSuccess) {
+        error_ = "fallback gather buffers: allocation failed on device " + std::to_string(devices[(size_t)r]);
+        return;
+      }
     }
     for (int r = 0; r < D; r++) ranks_[(size_t)r]->th = std::thread([this, r]() { worker(r); });
   }
@@ -143,6 +150,8 @@ class ShardedBatchAlignerHip {
         if (s.stage) (void)hipHostFree(s.stage);
         if (s.gathered) (void)hipEventDestroy(s.gathered);
       }
+      if (k.fb_send) (void)hipFree(k.fb_send);
+      if (k.fb_recv) (void)hipFree(k.fb_recv);
       if (k.gstream) (void)hipStreamDestroy(k.gstream);
     }
     for (ncclComm_t c : comms_)
@@ -156,6 +165,8 @@ class ShardedBatchAlignerHip {
   int in_flight() const { return slots_; }
   /// with ONE device the all-gather is a copy; RCCL is still called by default (the path the multi-GPU job takes)
   void set_gather_when_alone(bool on) { gather_when_alone_ = on; }
+  /// test hook: the next batch's first rank to start behaves as if the allocation of its record buffers had failed
+  void debug_fail_next_record_allocation() { fail_alloc_.store(true); }
 
   /// Hands the batch to the workers and returns its ticket (> 0) in *ticket; 0 or a negative apdgicp_status.  pairs[i] =
   /// (source cloud, target cloud, guess) with indices into `clouds`.  Nothing waits unless `in_flight` batches are already
@@ -249,6 +260,7 @@ class ShardedBatchAlignerHip {
   const void* gathered_on(int r, uint64_t ticket) const { return ranks_[(size_t)r]->slots[(size_t)(ticket % (uint64_t)slots_)].recv; }
 
  private:
+  static constexpr size_t kFallbackBytes = 64 << 10;  // 682 records per rank: any practical batch
   struct Job {
     uint64_t seq = 0;
     int64_t per = 0, begin = 0, end = 0;
@@ -281,6 +293,8 @@ class ShardedBatchAlignerHip {
     bool stop = false, dead = false;
     uint64_t want = 0;
     hipStream_t gstream = nullptr;  // the all-gathers
+    char* fb_send = nullptr;        // kFallbackBytes of zeros / world x kFallbackBytes: what a rank whose record buffers could not be
+    char* fb_recv = nullptr;        // allocated gathers with instead, so that it still ENTERS the collective (finish)
     std::vector<apdgicp_batch*> handles;
     std::vector<Slot> slots;
     int cloud_cap = 64;  // pooled mode: cloud slots per batch in flight (grows; the descriptor table the handle uploads is as long as the highest slot)
@@ -299,6 +313,15 @@ class ShardedBatchAlignerHip {
     auto fail = [&](int code, const char* what) { s.start_rc = code, s.start_msg = std::string(what) + ": " + apdgicp_last_error(); };
     if (hipSetDevice(devices_[(size_t)r]) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipSetDevice");
     const size_t rec = sizeof(apdgicp_result), D = (size_t)world();
+    if (fail_alloc_.exchange(false)) {  // (debug_fail_next_record_allocation: what a failed hipMalloc below leaves behind)
+      (void)hipEventSynchronize(s.gathered);
+      if (s.send) (void)hipFree(s.send);
+      if (s.recv) (void)hipFree(s.recv);
+      if (s.stage) (void)hipHostFree(s.stage);
+      s.send = s.recv = s.stage = nullptr, s.send_cap = s.recv_cap = 0;
+      s.start_rc = APDGICP_ERR_HIP, s.start_msg = "hipMalloc: forced failure (debug_fail_next_record_allocation)";
+      return;
+    }
     if ((size_t)job.per * rec > s.send_cap || (size_t)job.per * rec * D > s.recv_cap) {  // (first batches only)
       if (hipEventSynchronize(s.gathered) != hipSuccess) return fail(APDGICP_ERR_HIP, "hipEventSynchronize");
       if (s.send) (void)hipFree(s.send);
@@ -347,6 +370,10 @@ class ShardedBatchAlignerHip {
     const size_t rec = sizeof(apdgicp_result);
     const size_t mine = (size_t)(s.s_end - s.s_begin) * rec, block = (size_t)s.s_per * rec;
     bool gather_ok = s.send && s.recv && s.stage && block <= s.send_cap;
+    if (aborted_.load()) {  // the communicators are gone (abort_all): nothing to enter, the batch fails
+      if (rc == 0) rc = APDGICP_ERR_HIP, msg = "the record gather was aborted";
+      gather_ok = false;
+    }
     // The block's records come home with the batch's last poll (pinned memory): they go from the slot's own pinned staging
     // buffer into its send buffer by an asynchronous copy IN FRONT of the gather on the gather stream.  Nothing here waits
     // for the device -- on a busy GPU even a 3 KB copy kernel on a side stream waits a few hundred microseconds for a free
@@ -370,6 +397,18 @@ class ShardedBatchAlignerHip {
         gather_ok = false;
       }
     }
+    if (!gather_ok && block) {
+      // This rank's record buffers are missing (start() could not allocate them) or the copy into them failed -- but the other
+      // ranks are in, or on their way into, this batch's ncclAllGather and a rank that skipped it would leave them there for
+      // good, with every later collective of the communicator paired with the wrong batch.  So the collective IS called, on
+      // the rank's preallocated fallback buffers (zeros out, a scratch area in), and the batch fails with this rank's error.
+      // Only a block larger than the fallback leaves no way to take part: then the communicators are aborted and every
+      // rank is marked dead, so that collect() returns an error everywhere instead of waiting.
+      bool entered = (world() == 1 && !gather_when_alone_) || aborted_.load();
+      if (!entered && block <= kFallbackBytes && k.fb_send && k.fb_recv)
+        entered = ncclAllGather(k.fb_send, k.fb_recv, block, ncclChar, comms_[(size_t)r], k.gstream) == ncclSuccess;
+      if (!entered) abort_all("rank " + std::to_string(r) + ": could not enter the record gather");
+    }
     if (!gather_ok && rc == 0) rc = APDGICP_ERR_HIP, msg = "record gather failed";
     (void)hipEventRecord(s.gathered, k.gstream);
     s.busy = false;
@@ -381,6 +420,22 @@ class ShardedBatchAlignerHip {
     k.t_collect += std::chrono::duration<double, std::milli>(tf1 - tf0).count();
     k.t_post += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count();
     k.n_fin++;
+  }
+
+  // last resort (see finish): no rank may wait for a collective that one of them cannot enter
+  void abort_all(const std::string& why) {
+    std::lock_guard<std::mutex> ga(abort_mu_);
+    if (aborted_.exchange(true)) return;
+    std::fprintf(stderr, "[ShardedBatchAlignerHip] %s: aborting the communicators\n", why.c_str());
+    for (ncclComm_t& c : comms_)
+      if (c) (void)ncclCommAbort(c), c = nullptr;
+    for (auto& kp : ranks_) {
+      {
+        std::lock_guard<std::mutex> g(kp->mu);
+        kp->dead = true;
+      }
+      kp->cv.notify_all();
+    }
   }
 
   void worker(int r) {
@@ -450,6 +505,9 @@ class ShardedBatchAlignerHip {
   std::vector<ncclComm_t> comms_;
   uint64_t seq_ = 0;
   std::string error_, error_text_;
+  std::mutex abort_mu_;
+  std::atomic<bool> aborted_{false};
+  std::atomic<bool> fail_alloc_{false};
 };
 
 }  // namespace fast_gicp

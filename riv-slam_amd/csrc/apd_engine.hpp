@@ -362,6 +362,7 @@ class Engine {
     for (PoolJob& j : pool.jobs) {
       if (j.ev_pro) e = hipEventDestroy(j.ev_pro);
       if (j.pin) e = hipHostFree(j.pin);
+      j.d_recs.release();
     }
     for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.active, &pool.nactive, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
                       &pool.nnpt, &pool.nnaux, &pool.sqd, &pool.maha, &pool.blkpart, &pool.errpart})
@@ -1331,10 +1332,13 @@ class Engine {
     hipEvent_t ev_pro = nullptr;      // behind the preparation of its clouds (cloud stream)
     char* pin = nullptr;              // staging of the lane's pair descriptors and guesses
     size_t pin_cap = 0;
+    int layout_gen = 0;               // Pool::layout_gen when the batch was enqueued: where its device records are
+    DevBuf d_recs;                    // device copy of `recs` for a collect that comes after the pool was laid out anew
   };
   struct Pool {
     bool on = false;
     bool layout_valid = false;
+    int layout_gen = 0;  // counts the layouts: a new one moves (or frees) the record segments of every earlier batch
     int lanes = 0, segcap = 0, cap = 0, nmax_src = 0, nmax_tgt = 0;
     hipStream_t cstream = nullptr;
     DevBuf state, pairs, guess, active, nactive, results, ticket, nnpart, corr, nnpt, nnaux, sqd, maha, blkpart, errpart;
@@ -1457,6 +1461,7 @@ class Engine {
     w.active = pool.active.as<int>();
     nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)
     pool.lanes = lanes, pool.segcap = segcap, pool.cap = cap, pool.nmax_src = nmax;
+    pool.layout_gen++;  // (the batches that finished under the old layout keep their host records; pool_collect knows by this number)
     pool.ub = 0, pool.seq_seen = pool.seq_enq;  // (nothing is in flight; headers of older chunks were wiped)
     for (int& a : pool.adm) a = 0;
     pool.layout_valid = true;
@@ -1688,6 +1693,7 @@ class Engine {
     for (int id : need) pool.cloud_busy[id]++;
     j.cloud_ids = need;
     j.state = PoolJob::PENDING, j.ticket = ++align_seq, j.np = (int)n, j.collected = false, j.err = 0, j.errmsg.clear(), j.admit_seq = 0;
+    j.layout_gen = pool.layout_gen;
     pool.last_lane = lane;
     *ticket = j.ticket;
     return pool_pump(false);
@@ -1706,7 +1712,19 @@ class Engine {
     j->collected = true;
     last_ticks = (int)std::min<long long>(pool.n_ticks, 1 << 30);
     if (j->err) return fail(j->err, j->errmsg);
-    if (d_out) *d_out = pool.results.as<ResultRec>() + (size_t)(j - pool.jobs) * pool.segcap;
+    if (d_out) {
+      if (j->layout_gen == pool.layout_gen) {
+        *d_out = pool.results.as<ResultRec>() + (size_t)(j - pool.jobs) * pool.segcap;
+      } else {
+        // A later batch had more pairs or larger clouds than the pool was laid out for: the layout (segment size, possibly the
+        // number of lanes, the record buffer itself) is another one now and this batch's segment is gone.  Its records survive
+        // on the host (taken when the batch completed): the caller gets a device copy of those, the job's own, valid until
+        // the lane is reused like any other device record pointer.
+        APD_TRY(j->d_recs.ensure((size_t)j->np * sizeof(ResultRec)));
+        APD_HIP(hipMemcpy(j->d_recs.p, j->recs.data(), (size_t)j->np * sizeof(ResultRec), hipMemcpyHostToDevice));
+        *d_out = j->d_recs.p;
+      }
+    }
     if (host_out) memcpy(host_out, j->recs.data(), (size_t)j->np * sizeof(ResultRec));
     return 0;
   }

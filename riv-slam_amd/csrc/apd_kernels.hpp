@@ -311,8 +311,7 @@ __global__ void k_export_corr(const int* corr, const float* sqd, const int* perm
 //            ~1.5 k entries); on overflow tau is tightened from the list and the sweep repeats.
 //   select : k rounds of lexicographic (d, idx) min-extraction; accumulate sums in fp64.
 //   KNN_CAP: list entries per query -- 64 for k <= 32; 128 for 32 < k <= 64 (setCorrespondenceRandomness takes any k, A:45-47;
-//   the launch file ships 20).  Beyond 32 the class minima give no bound (tau starts at +inf) and every overflow restart keeps
-//   about k / KNN_CAP of the candidates: correct, a sweep per restart, the slow path of a setting nobody ships.
+//   the launch file ships 20), where sweep 1 runs twice for 64 classes: the slow path of a setting nobody ships.
 constexpr int KNN_BLK = 128, KNN_NC = 32, KNN_TILE = 1024;
 __host__ __device__ constexpr int knn_lds_bytes_brute(int cap) { return KNN_TILE * 16 + cap * KNN_BLK * 8; }
 
@@ -342,6 +341,8 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
 
   // ---- sweep 1
   float cm[KNN_NC];
+  float tau_d = inf;
+  if constexpr (KNN_CAP <= 64) {
 #pragma unroll
   for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
   for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
@@ -375,10 +376,50 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
       }
     }
   }
-  float tau_d = inf;
 #pragma unroll
   for (int s = 0; s < KNN_NC; s++)
     if (s == k - 1) tau_d = cm[s];
+  } else {
+    // 32 < k <= 64: SIXTY-FOUR index-strided classes (two passes of 32 register minima, parked in the still empty list rows),
+    // tau = the k-th smallest class minimum.  (Until round 4 this path started from tau = +inf and on overflow kept the first
+    // 128 candidates in curve order -- not a sample: the candidate set shrank so slowly that clouds beyond ~16k points ran
+    // into the restart guard, error flag 1 and garbage covariances on a supported setting.)
+    constexpr int NCL2 = 2 * KNN_NC;
+    static_assert(KNN_TILE % NCL2 == 0 && KNN_CAP >= NCL2, "class layout");
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+      for (int s = 0; s < KNN_NC; s++) cm[s] = inf;
+      for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+        __syncthreads();
+        knn_load_tile(tile, c.pts, t0, n, tid);   // (padded with +inf up to the tile size, a multiple of 64)
+        __syncthreads();
+        const int cnt = min(KNN_TILE, (n - t0 + NCL2 - 1) / NCL2 * NCL2);
+        for (int jj = 0; jj < cnt; jj += NCL2) {
+#pragma unroll
+          for (int s = 0; s < KNN_NC; s++) {
+            const float4 t = tile[jj + KNN_NC * pass + s];
+            cm[s] = fminf(cm[s], sqdist1(t.x, t.y, t.z, q.x, q.y, q.z));
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < KNN_NC; s++) lst_d[(KNN_NC * pass + s) * KNN_BLK + tid] = cm[s];   // (this thread's own column: no barrier needed)
+    }
+    float last_d = -1.f;
+    int last_a = -1;
+    for (int r = 0; r < k; r++) {  // k-th smallest of the 64 minima: (value, class) in lexicographic order, one per round
+      float bd = inf;
+      int ba = 0x7fffffff;
+      for (int a = 0; a < NCL2; a++) {
+        const float d = lst_d[a * KNN_BLK + tid];
+        const bool gt = d > last_d || (d == last_d && a > last_a);
+        const bool lt = d < bd || (d == bd && a < ba);
+        if (gt && lt) bd = d, ba = a;
+      }
+      last_d = bd, last_a = ba;
+    }
+    tau_d = last_d;
+  }
   int tau_i = 0x7fffffff;
 
   // ---- sweep 2 (+ tightening restarts)
@@ -434,7 +475,7 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
     }
     need = ovf;
     if (!__syncthreads_or(ovf ? 1 : 0)) break;
-    if (round >= 32) {  // cannot happen: every restart strictly shrinks the candidate set
+    if (round >= 4096) {  // cannot happen: of the KNN_CAP stored candidates only k survive a restart, so each one removes at least KNN_CAP - k
       if (tid == 0) atomicExch(err_flag, 1);
       break;
     }

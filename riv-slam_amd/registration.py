@@ -507,8 +507,12 @@ class BatchAPDGICP:
             if ps is not None:
                 _check(self.L.apdgicp_batch_wait_producer(self.b, ps))
         self._keep_new.append(keep)
-        if len(self._keep_new) > 64:   # callers that never reach a sync point (long-lived resident inputs) must not pin tensors without bound
-            del self._keep_new[:-64]
+        if len(self._keep_new) > 64:
+            # A caller that sets clouds again and again without ever reaching a sync point (enqueue / align / synchronize) must not
+            # pin tensors without bound -- but a tensor may only be let go once the pack kernel that reads it has run, or torch's
+            # caching allocator hands its memory to somebody else under the kernel's feet.  So: wait for the handle, then drop all.
+            _check(self.L.apdgicp_batch_synchronize(self.b))
+            del self._keep_new[:-1]
 
     def wait_producer(self, stream_ptr: int = 0):
         """Orders the batch behind everything queued so far on the given hipStream_t (0: the legacy default stream)."""

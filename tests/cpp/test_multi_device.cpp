@@ -140,6 +140,12 @@ int main(int argc, char** argv) {
     bad_clouds[(size_t)pairs[0].source_cloud].xyz = poisoned.data();
     errors_ok = errors_ok && sharded.enqueue(bad_clouds, pairs, &t) == 0 && sharded.collect(t, &res) < 0;
     errors_ok = errors_ok && sharded.align(clouds, pairs, &res) == 0 && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
+    // a rank whose record buffers could not be allocated still enters the batch's all-gather (fallback buffers): its batch
+    // fails at collect -- which RETURNS -- and the next batch finds the communicator paired up and its buffers allocated anew
+    sharded.debug_fail_next_record_allocation();
+    errors_ok = errors_ok && sharded.enqueue(clouds, pairs, &t) == 0 && sharded.collect(t, &res) < 0 &&
+                sharded.last_error_text().find("forced failure") != std::string::npos;
+    errors_ok = errors_ok && sharded.align(clouds, pairs, &res) == 0 && std::memcmp(res.data(), single.data(), (size_t)np * sizeof(apdgicp_result)) == 0;
   }
   // ---- candidate selection: every pair whose target is the target of pair 0 is a candidate of that keyframe
   fast_gicp::LoopVerifierHip verifier(&prm, 0);

@@ -76,6 +76,18 @@ def test_cov_k_values(reg, golden):
         assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10, k
 
 
+@pytest.mark.parametrize("n,k", ((16384, 33), (16384, 64), (30000, 48), (110_000, 64), (64, 64), (100, 40)))
+def test_cov_k_beyond_32_at_scan_and_submap_sizes(reg, scene, n, k):
+    """32 < k <= 64 goes through the brute-force covariance kernel with 128-entry lists, whose bound comes from 64 class minima.
+    (it used to start unbounded and ran into its restart guard -- error flag, garbage -- from ~16k points on.)"""
+    src, _, _, _ = scene.make_pair(n, 32, scene.pair_seed(7, n + k), "odometry")
+    g = reg.FastAPDGICP(reg.default_params(k_correspondences=k, regularization=0))
+    g.setInputSource(src)
+    o = R.RefAPDGICP(R.default_params(k_correspondences=k, regularization=0))
+    o.setInputSource(src)
+    assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
+
+
 @pytest.mark.parametrize("n", (2000, 8192))   # (8192: host clouds read by the sort from pinned memory, bounding box from the host)
 def test_non_finite_points_fail_loudly(reg, scene, n):
     """The preprocessing nodelet removes NaNs before registration (preprocessing_nodelet.cpp); a cloud that still carries
@@ -511,6 +523,18 @@ def test_temporary_device_tensors_are_safe(reg, scene):
             assert b.align_collect(tickets.pop(0)).tobytes() == want_b
         del junk
     assert b.align_collect(tickets.pop(0)).tobytes() == want_b
+    # many set_cloud calls with temporaries and no sync point in between: the handle lets a tensor go only after
+    # waiting for the pack kernel that reads it
+    big = torch.zeros(64 << 20, device="cuda")
+    for rep_ in range(70):
+        big.add_(1.0)
+        b.set_cloud(0, torch.from_numpy(s).cuda() + big[: s.size].view(s.shape) * 0.0)
+        junk = torch.full(s.shape, 7e5, device="cuda")
+        del junk
+    b.set_cloud(1, torch.from_numpy(t).cuda() * 1.0)
+    assert len(b._keep_new) <= 65
+    assert b.align([(0, 1)], [guess]).tobytes() == want_b
+    del big
 
 
 # ------------------------------------------------------------------ batched registrations (8e / C3)

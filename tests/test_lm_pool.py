@@ -132,6 +132,12 @@ def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch, lan
     got = b.align([(2 * i, 2 * i + 1) for i in range(9)], guesses)
     ref_b.set_clouds(0, clouds)
     assert got.tobytes() == polled_align(ref_b, [(2 * i, 2 * i + 1) for i in range(9)], guesses).tobytes()
+    # the pool has laid itself out anew for that batch (larger segments): the DEVICE records of a ticket from before are a copy
+    # of its host records now, not a pointer into the old layout
+    newest = lanes + 1
+    dev = b.align_collect(tickets[newest], device=True)
+    assert bytes(dev.cpu().numpy().tobytes()) == want[newest].tobytes()
+    assert b.align_collect(tickets[newest]).tobytes() == want[newest].tobytes()
 
 
 def test_a_failing_batch_fails_alone_and_the_handle_stays_usable(reg, scene):
