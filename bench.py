@@ -374,7 +374,19 @@ def main():
         b_reg = 40.0 * (2 * n) + n_lin * (108.0 * n + 16.0 * n) + n_err * 56.0 * n
         hbm_gbs = b_reg * P / (ms_per_step * 1e-3) / 1e9
         traffic, issue = None, None
-        pmc, pmc_rejected = load_pmc()
+        pmc, pmc_rejected = load_pmc(os.path.join(ROOT, "profiles", "pmc_lm_loop.json") if lm else None)
+        if lm and pmc and pmc.get("points") == n and pmc.get("kind") == args.kind and pmc.get("kernel", "").replace(" ", "") == batch.last_nn_kernel().replace(" ", ""):
+            # pooled LM ticks: launches differ in size, the committed counters are per listed pair slot (tools/pmc_lm_json.py)
+            ps = pmc["per_slot"][pmc["kernel"]]
+            if pmc.get("hbm_bytes_per_slot"):
+                traffic = int(round(pmc["hbm_bytes_per_slot"] * pairs_per_launch))
+            if ps.get("SQ_INSTS_VALU") and avg_nn_ms > 0:
+                valu_rate = ps["SQ_INSTS_VALU"] * pairs_per_launch / (avg_nn_ms * 1e-3)
+                issue = {"bound": "valu-issue", "achieved": round(valu_rate / 1e9, 2), "peak": round(VALU_WAVE_INSTR_PEAK / 1e9, 2),
+                         "unit": "G wave-instructions/s", "frac": round(valu_rate / VALU_WAVE_INSTR_PEAK, 4),
+                         "peak_theoretical": round(VALU_WAVE_INSTR_THEORETICAL / 1e9, 1), "frac_of_theoretical": round(valu_rate / VALU_WAVE_INSTR_THEORETICAL, 4),
+                         "valu_instructions_per_pair": ps["SQ_INSTS_VALU"], "source": pmc.get("source"),
+                         "note": "VALU wave-instructions per listed pair (PMC, committed profile of the same workload) x pairs per timed launch / the launch time"}
         # PMC numbers come from a separate committed profiling run (rocprofv3 --pmc passes cannot run inside this process):
         # reported only when that run had this launch shape, and tagged with where they come from
         step_issue = None

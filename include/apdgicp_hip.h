@@ -271,7 +271,9 @@ int apdgicp_batch_copy_results(apdgicp_batch* b, void* dst, int64_t n_pairs, int
 int apdgicp_batch_set_profiling(apdgicp_batch* b, int enable);
 int apdgicp_batch_last_nn_time(apdgicp_batch* b, double* total_ms, int64_t* launches);
 /* same, plus the number of pairs the timed launches covered (a launch covers one pair group; only every 10th tick is
- * timed, with a phase rotating from align to align, because timing every launch costs ~5 % of a step) */
+ * timed, with a phase rotating from align to align, because timing every launch costs ~5 % of a step).  Pooled LM batches:
+ * the timed launches (the first tick of every 10th chunk, per list slice) belong to no single batch -- the call returns what
+ * has been harvested since the previous call and resets it; pairs_covered counts the pairs really on the list, not the slots */
 int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered);
 int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_lane, int* nn_target_splits);
 /* name of the nearest-neighbour kernel the last launch used (e.g. "k_nn_compact<4>", "(k_nn_pruned<1, 8>)", "k_nn_partial<4>") */

@@ -359,6 +359,7 @@ class Engine {
     if (pool.cstream) e = hipStreamSynchronize(pool.cstream);
     for (hipEvent_t ev_ : pool.ev)
       if (ev_) e = hipEventDestroy(ev_);
+    for (Pool::Timed& c : pool.timed) e = hipEventDestroy(c.e0), e = hipEventDestroy(c.e1);
     for (PoolJob& j : pool.jobs) {
       if (j.ev_pro) e = hipEventDestroy(j.ev_pro);
       if (j.pin) e = hipHostFree(j.pin);
@@ -975,7 +976,9 @@ class Engine {
     dim3 grid((unsigned)src_blocks, nn_pruned ? (unsigned)sp.np : (unsigned)t_work().T, nn_pruned ? 1u : (unsigned)sp.np);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = profile_nn && !in_pool && ((cur_tick + profile_phase) % profile_stride == 0);
-    if (timed) {
+    if (in_pool && pool.cur_timed) {
+      e0 = pool.cur_timed->e0, e1 = pool.cur_timed->e1;
+    } else if (timed) {
       nn_pairs_acc += sp.np;
       if (nn_events_used == nn_events.size()) {
         hipEvent_t a, b;
@@ -1358,6 +1361,19 @@ class Engine {
     int last_lane = -1;
     long long n_chunks = 0, n_ticks = 0, n_pair_ticks = 0;  // statistics (apdgicp_batch_last_ticks)
     std::vector<int> cloud_busy;
+    // Timed search launches (profile_nn): the first tick of every profile_stride-th chunk carries its own start / stop events.  The
+    // pairs such a launch really covered are known when the chunk's header arrives (n_active: the list length its ticks ran over,
+    // the rest of the launch's slots held -1), its duration once the NEXT header has arrived (the poll behind the chunk's ticks).
+    struct Timed {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      uint64_t seq = 0;
+      int p0 = 0, p1 = 0, n_active = -1;
+      bool busy = false;
+    };
+    std::vector<Timed> timed;
+    Timed* cur_timed = nullptr;      // set around the launch_nn that is to be timed
+    double nn_ms = 0;                // harvested since the last read (apdgicp_batch_last_nn_profile)
+    long long nn_launches = 0, nn_pairs = 0;
   } pool;
 
   bool pool_eligible() const {
@@ -1381,6 +1397,7 @@ class Engine {
       for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&pool.ev[i], hipEventDisableTiming));
       for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
       pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 2)));
+      profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 10));
 
     }
     cstream = pool.cstream;
@@ -1462,6 +1479,7 @@ class Engine {
     nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)
     pool.lanes = lanes, pool.segcap = segcap, pool.cap = cap, pool.nmax_src = nmax;
     pool.layout_gen++;  // (the batches that finished under the old layout keep their host records; pool_collect knows by this number)
+    for (Pool::Timed& c : pool.timed) c.busy = false;
     pool.ub = 0, pool.seq_seen = pool.seq_enq;  // (nothing is in flight; headers of older chunks were wiped)
     for (int& a : pool.adm) a = 0;
     pool.layout_valid = true;
@@ -1528,7 +1546,24 @@ class Engine {
         if (p1 <= p0) continue;
         const int nt = pool.ticks_per_chunk;
         cur_active = p1 - p0;
-        for (int t = 0; t < nt; t++) APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+        for (int t = 0; t < nt; t++) {
+          pool.cur_timed = nullptr;
+          if (profile_nn && t == 0 && (int)((seq + (uint64_t)profile_phase) % (uint64_t)profile_stride) == 0) {
+            Pool::Timed* slot = nullptr;
+            for (Pool::Timed& c : pool.timed)
+              if (!c.busy) slot = &c;
+            if (!slot && pool.timed.size() < 64) {
+              pool.timed.emplace_back();
+              slot = &pool.timed.back();
+              APD_HIP(hipEventCreate(&slot->e0));
+              APD_HIP(hipEventCreate(&slot->e1));
+            }
+            if (slot) slot->busy = true, slot->seq = seq, slot->p0 = p0, slot->p1 = p1, slot->n_active = -1, pool.cur_timed = slot;
+          }
+          const int rc_t = launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]});
+          pool.cur_timed = nullptr;
+          APD_TRY(rc_t);
+        }
         pool.n_pair_ticks += (long long)nt * (p1 - p0);
       }
       for (int g = 1; g < G; g++) {
@@ -1545,6 +1580,18 @@ class Engine {
     std::atomic_thread_fence(std::memory_order_acquire);
     const PoolHdr h = *pool_hdr(seq);
     pool.seq_seen = seq;
+    for (Pool::Timed& c : pool.timed) {
+      if (!c.busy) continue;
+      if (c.seq == seq) c.n_active = h.n_active;
+      if (c.seq < seq) {  // its chunk's ticks ran in front of this poll: the events have fired
+        float ms = 0.f;
+        if (c.n_active >= 0 && hipEventElapsedTime(&ms, c.e0, c.e1) == hipSuccess) {
+          const int covered = std::max(0, std::min(c.p1, c.n_active) - c.p0);
+          if (covered > 0) pool.nn_ms += ms, pool.nn_launches++, pool.nn_pairs += covered;
+        }
+        c.busy = false;
+      }
+    }
     int ub = h.n_active;
     for (uint64_t c = seq + 1; c <= pool.seq_enq; c++) ub += pool.adm[c % kPoolRing];
     pool.ub = ub;

@@ -806,6 +806,13 @@ int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]) {
 
 int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  if (b->eng.pool.on) {  // pooled LM batches: the timed launches harvested since the last call (they belong to no single batch)
+    if (total_ms) *total_ms = b->eng.pool.nn_ms;
+    if (launches) *launches = b->eng.pool.nn_launches;
+    if (pairs_covered) *pairs_covered = b->eng.pool.nn_pairs;
+    b->eng.pool.nn_ms = 0, b->eng.pool.nn_launches = 0, b->eng.pool.nn_pairs = 0;
+    return 0;
+  }
   if (total_ms) *total_ms = b->eng.last_nn_ms;
   if (launches) *launches = b->eng.last_nn_launches;
   if (pairs_covered) *pairs_covered = b->eng.last_nn_pairs;

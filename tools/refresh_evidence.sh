@@ -1,48 +1,71 @@
 #!/bin/bash
-# Regenerates the judged evidence on the GPU box into gpurun_out/ev/ (copy the *.md / *.json you want judged into profiles/,
-# named per round).   usage: gpurun -- 'bash tools/refresh_evidence.sh r03'
+# Regenerates the judged evidence on the GPU box into gpurun_out/ev/; afterwards, HERE, `bash tools/refresh_evidence.sh --collect rNN`
+# copies the summaries into profiles/ (named per round; pmc_nn_latest.json / pmc_lm_loop.json under their fixed names).
+#   usage: gpurun --timeout 2400 -- 'bash tools/refresh_evidence.sh r04'
 #   kernel_stats.md      rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
 #   bench_profiled.json  the JSON line printed by that same profiled run (its roofline.avg_launch_ms must agree with the table)
 #   pmc_*.md             separate --pmc passes (never combined with other trace domains): HBM bytes and the issue-side SQ counters
 #   pmc_nn_latest.json   per-launch PMC numbers of the batch's nearest-neighbour launches (bench.py's roofline.traffic / roofline_issue)
-#   bench.json           the un-profiled default run
-tag=${1:-r03}
+#   pmc_lm_loop.json     the same per listed pair slot for the pooled LM ticks (bench.py --kind loop --optimizer lm)
+#   bench.json           the un-profiled default run; bench_lm_loop.json: the reference's optimiser on the C4 shard
+if [ "$1" == "--collect" ]; then
+  tag=$2; ev=gpurun_out/ev
+  for f in kernel_stats.md kernel_stats_lm_loop.md pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
+           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json; do
+    [ -s $ev/$f ] && cp $ev/$f profiles/${tag}_$f
+  done
+  for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
+  ls -la profiles | grep "${tag}_\|pmc_" ; exit 0
+fi
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-ev=gpurun_out/ev; mkdir -p $ev
+ev=gpurun_out/ev; rm -rf $ev; mkdir -p $ev
 DRV="python3 bench.py --gpus 1 --steps 20 --warmup 5"
 PMC="python3 bench.py --gpus 1 --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-diagnostics"
+LMC="python3 bench.py --kind loop --optimizer lm --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-diagnostics"
 # (APDGICP_PROFILE_STRIDE=1: bench.py's own timing brackets EVERY search launch in this run, like the trace does, so the two
 # averages cover the same launches; the default run samples one tick in ten)
 export APDGICP_PROFILE_STRIDE=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks -o k -- $DRV --no-cpu-baseline > $ev/bench_profiled.json 2> $ev/ks.err
 unset APDGICP_PROFILE_STRIDE
 python3 tools/rocpd_summary.py $(find $ev/ks -name "*.db" | head -1) "$tag: '$DRV --no-cpu-baseline' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats.md
-pass() {  # name, counters...
-  name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $ev/p_$name -o k -- $PMC > $ev/p_$name.log 2>&1
+pass() {  # name, command, counters...
+  name=$1; cmd=$2; shift; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $ev/p_$name -o k -- $cmd > $ev/p_$name.log 2>&1
   db=$(find $ev/p_$name -name "*.db" | head -1)
-  if [ -n "$db" ]; then python3 tools/rocpd_summary.py $db "$tag PMC pass '$name': $* ('$PMC')" > $ev/pmc_$name.md; else echo "pass $name produced no db"; tail -5 $ev/p_$name.log; fi
+  if [ -n "$db" ]; then python3 tools/rocpd_summary.py $db "$tag PMC pass '$name': $* ('$cmd')" > $ev/pmc_$name.md; else echo "pass $name produced no db"; tail -5 $ev/p_$name.log; fi
 }
-pass fetch FETCH_SIZE
-pass write WRITE_SIZE
-pass insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES
-pass busy SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT
-pass occ GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64
+INSTS="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+BUSY="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"
+pass fetch "$PMC" FETCH_SIZE
+pass write "$PMC" WRITE_SIZE
+pass insts "$PMC" $INSTS
+pass busy "$PMC" $BUSY
+pass occ "$PMC" GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64
 dbs=$(for n in fetch write insts busy; do find $ev/p_$n -name "*.db" | head -1; done)
 python3 tools/pmc_nn_json.py $ev/pmc_nn_latest.json 8192 odometry $dbs > /dev/null && cp $ev/pmc_nn_latest.json profiles/pmc_nn_latest.json
+# the loop-closure regime (pooled LM ticks from the identity): the same passes
+pass lm_fetch "$LMC" FETCH_SIZE
+pass lm_write "$LMC" WRITE_SIZE
+pass lm_insts "$LMC" $INSTS
+pass lm_busy "$LMC" $BUSY
+dbs=$(for n in lm_fetch lm_write lm_insts lm_busy; do find $ev/p_$n -name "*.db" | head -1; done)
+python3 tools/pmc_lm_json.py $ev/pmc_lm_loop.json 8192 $dbs > /dev/null && cp $ev/pmc_lm_loop.json profiles/pmc_lm_loop.json
 timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
-# the reference's optimiser on the C4 shard (bench.py --kind loop --optimizer lm): the JSON line and its kernel table
+# the reference's optimiser on the C4 shard (bench.py --kind loop --optimizer lm): the JSON line, its kernel table, its streams
 timeout 600 python3 bench.py --kind loop --optimizer lm --no-cpu-baseline > $ev/bench_lm_loop.json 2> $ev/bench_lm.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks_lm -o k -- python3 bench.py --kind loop --optimizer lm --no-cpu-baseline --repeats 3 > /dev/null 2> $ev/ks_lm.err
 python3 tools/rocpd_summary.py $(find $ev/ks_lm -name "*.db" | head -1) "$tag: 'python3 bench.py --kind loop --optimizer lm' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats_lm_loop.md
-python3 tools/rocpd_pool_ticks.py $(find $ev/ks_lm -name "*.db" | head -1) 20 > $ev/lm_pool_ticks.txt
+python3 tools/rocpd_streams.py $(find $ev/ks_lm -name "*.db" | head -1) 0.5 > $ev/lm_pool_streams.txt
 find $ev/ks_lm -type f ! -name "*.db" -delete
+# bench.py's own N > 1 loop with two ranks on the one GPU (gloo): a self-test of that code path, not a scaling point
+timeout 600 python3 bench.py --gpus 2 --ranks-share-gpu --dist-backend gloo --no-cpu-baseline --no-diagnostics > $ev/bench_2ranks_gloo.json 2> $ev/bench_2ranks.err
 # the other BASELINE configs, the odometry protocol through the C++ adapter, the C++ multi-device path against the Python one
 timeout 900 python3 tests/measure/bench_configs.py > $ev/other_configs.json 2> $ev/other_configs.err
 timeout 600 python3 tests/measure/odometry_protocol.py > $ev/odometry_protocol.json 2> $ev/odometry.err
 timeout 900 python3 tools/cpp_vs_python.py 2> $ev/cpp_vs_python.err | tail -1 > $ev/cpp_vs_python.json
 timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
-for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ; do rm -rf $d; done
+for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ $ev/p_lm_fetch $ev/p_lm_write $ev/p_lm_insts $ev/p_lm_busy $ev/ks_lm; do rm -rf $d; done
 find $ev/ks -type f ! -name "*.db" -delete
 head -c 1500 $ev/bench.json; echo
 head -14 $ev/kernel_stats.md
