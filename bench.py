@@ -447,6 +447,7 @@ def main():
                                                 " (brute-force fp32 nearest neighbour, LDS-tiled)"),
                          "bound": "hbm", "achieved": round(nn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_over_algorithmic": (round(traffic / bytes_per_launch, 3) if traffic and bytes_per_launch else None),
                          "binding_roof": "instruction issue (vector + scalar), not HBM: see roofline_issue; the HBM fraction is the north star's extra",
                          "kernel_ms_per_step": round(avg_nn_ms * (ticks if not lm else n_lin), 4),
                          "kernel_time_check": "kernel_ms_per_step (average launch x launches per step) <= timing.step_latency_ms: the launches of one step overlap with "
@@ -457,7 +458,7 @@ def main():
                          "note": "achieved = SURVEY 8d's algorithmic bytes per launch (16(N+M) + 8N = 40N per pair) / the kernel's average duration in "
                                  "the timed region (HIP events on the launching stream).  The working set is MALL/L2 resident and the kernel "
                                  "is issue/latency bound, so the HBM fraction is small by construction; roofline_issue is the roof that binds.  "
-                                 "`traffic` (PMC, committed profile) also carries the warm-start hints and neighbour-keeping records: 2.2 x the algorithmic bytes"},
+                                 "`traffic` (PMC, committed profile of the same sources) also carries the warm-start hints and neighbour-keeping records: see traffic_over_algorithmic"},
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
             "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),

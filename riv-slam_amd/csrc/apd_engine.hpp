@@ -1025,6 +1025,7 @@ class Engine {
     } else if (nn_S == 2) APD_NN_LAUNCH(k_nn_partial<2>, NN_BLK);
     else APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
 #undef APD_NN_LAUNCH
+    if (in_pool && pool.cur_timed) pool.timed_kernel = last_nn_kernel;
     return 0;
   }
 
@@ -1372,6 +1373,7 @@ class Engine {
     };
     std::vector<Timed> timed;
     Timed* cur_timed = nullptr;      // set around the launch_nn that is to be timed
+    const char* timed_kernel = "";   // the search kernel of the last timed launch
     double nn_ms = 0;                // harvested since the last read (apdgicp_batch_last_nn_profile)
     long long nn_launches = 0, nn_pairs = 0;
   } pool;
@@ -1548,7 +1550,8 @@ class Engine {
         cur_active = p1 - p0;
         for (int t = 0; t < nt; t++) {
           pool.cur_timed = nullptr;
-          if (profile_nn && t == 0 && (int)((seq + (uint64_t)profile_phase) % (uint64_t)profile_stride) == 0) {
+          // (which tick of the chunk: in turn -- the first one alone would over-represent the cold searches of pairs just admitted)
+          if (profile_nn && (int)(seq % (uint64_t)profile_stride) == 0 && t == (int)((seq / (uint64_t)profile_stride) % (uint64_t)nt)) {
             Pool::Timed* slot = nullptr;
             for (Pool::Timed& c : pool.timed)
               if (!c.busy) slot = &c;

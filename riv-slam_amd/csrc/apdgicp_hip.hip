@@ -821,7 +821,8 @@ int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* l
 
 int apdgicp_batch_last_nn_kernel(apdgicp_batch* b, char* name, int capacity) {
   if (!b || !name || capacity < 1) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
-  snprintf(name, (size_t)capacity, "%s", b->eng.last_nn_kernel);
+  // (pooled LM batches: the kernel of the launches that were timed -- the last launch of all is a few-pair tail of another shape)
+  snprintf(name, (size_t)capacity, "%s", b->eng.pool.on && b->eng.pool.timed_kernel[0] ? b->eng.pool.timed_kernel : b->eng.last_nn_kernel);
   return 0;
 }
 
