@@ -461,7 +461,7 @@ def main():
                                  "`traffic` (PMC, committed profile of the same sources) also carries the warm-start hints and neighbour-keeping records: see traffic_over_algorithmic"},
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
-            "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),
+            "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_lm_loop.json" if lm else "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,
                                   "note": "whole step: B_reg x pairs / ms_per_step; B_reg = 40(N+M) + L(108N+16M) + E 56N with the run's mean L, E"},

@@ -1025,7 +1025,7 @@ class Engine {
     } else if (nn_S == 2) APD_NN_LAUNCH(k_nn_partial<2>, NN_BLK);
     else APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
 #undef APD_NN_LAUNCH
-    if (in_pool && pool.cur_timed) pool.timed_kernel = last_nn_kernel;
+    if (in_pool && pool.cur_timed && sp.np >= 8) pool.timed_kernel = last_nn_kernel;  // (not the few-pair tail of a draining pool: another block shape)
     return 0;
   }
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""How much could "parity unpinned" bite?  The one fp32 operation whose ORDER the restatement had to assume is
-`pt = trans.cast<float>() * input_->at(i).getVector4fMap()` (fast_apdgicp_impl.hpp:149): the oracle and the HIP kernels evaluate
-((r0 x + r1 y) + r2 z) + t (Eigen's coefficient-based product).  This script re-runs the CPU oracle with five other plausible
-orders (FMA packet code, other associations; oracle/apdgicp_ref.cpp:xf_row) on seeded pairs and reports, against order 0:
-the fraction of points whose transformed position differs in at least one bit, the number of correspondences that change at
-the first linearize, and the change of the registered pose.  CPU only (no GPU, no reference).  Prints one JSON object."""
+"""How much could "parity unpinned" bite?  The one fp32 operation whose ORDER belongs to a third party is
+`pt = trans.cast<float>() * input_->at(i).getVector4fMap()` (fast_apdgicp_impl.hpp:149): Eigen >= 3.3 sums a row pairwise, (r0 x + r1 y) + (r2 z + t) -- the
+default of the oracle and of the HIP kernels -- Eigen 3.2 as a linear chain (APDGICP_FLAG_XF_LINEAR_CHAIN); DESIGN.md section 5.  This script re-runs the CPU
+oracle with the other order and with four FMA / re-associated ones (oracle/apdgicp_ref.cpp:xf_row) on seeded pairs and reports, against the default:
+the number of correspondences that change at the first linearize, iteration-count changes, and the change of the registered pose.
+CPU only (no GPU, no reference).  Prints one JSON object."""
 import importlib
 import json
 import os

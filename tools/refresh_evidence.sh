@@ -12,7 +12,7 @@ if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
   for f in kernel_stats.md kernel_stats_lm_loop.md pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
            bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json; do
-    [ -s $ev/$f ] && cp $ev/$f profiles/${tag}_$f
+    [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
   done
   for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
   ls -la profiles | grep "${tag}_\|pmc_" ; exit 0
@@ -56,7 +56,8 @@ timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
 timeout 600 python3 bench.py --kind loop --optimizer lm --no-cpu-baseline > $ev/bench_lm_loop.json 2> $ev/bench_lm.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks_lm -o k -- python3 bench.py --kind loop --optimizer lm --no-cpu-baseline --repeats 3 > /dev/null 2> $ev/ks_lm.err
 python3 tools/rocpd_summary.py $(find $ev/ks_lm -name "*.db" | head -1) "$tag: 'python3 bench.py --kind loop --optimizer lm' under rocprofv3 --kernel-trace --stats" > $ev/kernel_stats_lm_loop.md
-python3 tools/rocpd_streams.py $(find $ev/ks_lm -name "*.db" | head -1) 0.5 > $ev/lm_pool_streams.txt
+# stream occupancy of the pool in steady state: the continuous loop of tools/lm_loop_bench.py (bench.py drains the pool between repetitions)
+bash tools/lm_trace.sh ev > /dev/null 2>&1; cp gpurun_out/lt_ev.streams.txt $ev/lm_pool_streams.txt
 find $ev/ks_lm -type f ! -name "*.db" -delete
 # bench.py's own N > 1 loop with two ranks on the one GPU (gloo): a self-test of that code path, not a scaling point
 timeout 600 python3 bench.py --gpus 2 --ranks-share-gpu --dist-backend gloo --no-cpu-baseline --no-diagnostics > $ev/bench_2ranks_gloo.json 2> $ev/bench_2ranks.err
