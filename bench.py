@@ -214,6 +214,9 @@ def main():
             bh.set_pair_groups(max(1, args.groups))
         batches.append(bh)
     batch = batches[0]
+    if lm:   # batches one handle keeps in flight: the pool's lanes; without the pool (APDGICP_LM_POOL=0, brute-force search) two record buffers
+        lanes = int(batch.L.apdgicp_batch_is_pooled(batch.b))
+        H = max(1, min(H, lanes if lanes > 0 else 2))
     # The process group comes AFTER the handles: the runtime deals streams onto its hardware queues in creation order, and RCCL
     # creates streams of its own -- behind the handles' they leave every handle's tick stream a queue to itself (the C++ aligner:
     # 1.01 -> 0.83 ms per step with the communicator created after the handles; here, with torch's lazily created streams, the

@@ -11,6 +11,7 @@ reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.im
 import ref as R  # noqa
 
 NP = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+XF = int(os.environ.get("XF_FLAGS", 0))   # 2: the linear-chain order of T * p (APDGICP_FLAG_XF_LINEAR_CHAIN), oracle and product alike
 CONFIGS = {
     "lm_default": dict(),
     "lm_launch": dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0),
@@ -22,6 +23,7 @@ rng = np.random.default_rng(123)
 out = {}
 t0 = time.time()
 for tag, kw in CONFIGS.items():
+    kw = dict(kw, flags=kw.get("flags", 0) | XF)
     st = dict(pairs=0, max_t_err_m=0.0, max_r_err_rad=0.0, info_equal=0, corr_equal=0, sqd_bit_equal=0, max_rel_H=0.0, max_rel_b=0.0, max_rel_cost=0.0)
     for i in range(NP):
         n, m = int(rng.integers(300, 4000)), int(rng.integers(300, 4000))
@@ -50,6 +52,7 @@ for tag, kw in (("batch_8k_gn20", dict(optimizer=1, max_iterations=20, transform
                                        azimuth_variance_deg=1.0)),
                 ("batch_8k_lm_launch", dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0))):
     PB = max(8, NP // 4)
+    kw = dict(kw, flags=XF)
     clouds, pairs, guesses, host = [], [], [], []
     for i in range(PB):
         src, tgt, _, guess = scene.make_pair(8192, 8192, scene.pair_seed(60, i), "odometry" if i % 2 else "loop")
@@ -68,6 +71,7 @@ for tag, kw in (("batch_8k_gn20", dict(optimizer=1, max_iterations=20, transform
         st["pairs"] += 1
     out[tag] = st
 out["seconds"] = round(time.time() - t0, 1)
+out["transform_order"] = "linear chain (APDGICP_FLAG_XF_LINEAR_CHAIN, Eigen 3.2)" if XF & 2 else "pairwise (default, Eigen >= 3.3)"
 out["note"] = ("GPU (libapdgicp_hip.so through the C ABI) vs oracle/apdgicp_ref.cpp; info = (converged, iterations, n_linearize, n_compute_error); "
                "a differing iteration count on an ill-conditioned LM run is possible (fp32 atan2f ulp, summation order) and is not a parity failure "
                "as long as the pose bars hold")
