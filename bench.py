@@ -204,8 +204,8 @@ def main():
     # underfed (32 pairs: three groups of latency-bound tick kernels); with several steps at different phases one handle's
     # covariance kernels fill the gaps of the others' ticks.  Every handle registers its own copy of the step's clouds.
     # Levenberg-Marquardt (--optimizer lm): ONE handle; its pair pool merges the H batches in flight, each in its own range of
-    # cloud slots (include/apdgicp_hip.h), H = 16 by default.
-    H = args.handles if args.handles > 0 else (16 if lm else 4)   # r02 (lazy group streams: every handle's stream on a hardware queue of its own): 3 / 4 / 5 / 6 handles 1.00 / 0.92 / 0.99 / 0.99 ms per step; with a process group 1.00 / 0.96 / 1.14
+    # cloud slots (include/apdgicp_hip.h), H = 24 by default.
+    H = args.handles if args.handles > 0 else (24 if lm else 4)   # r02 (lazy group streams: every handle's stream on a hardware queue of its own): 3 / 4 / 5 / 6 handles 1.00 / 0.92 / 0.99 / 0.99 ms per step; with a process group 1.00 / 0.96 / 1.14
     batches = []
     for _ in range(1 if lm else H):
         bh = reg.BatchAPDGICP(params, device=local_rank)
@@ -543,8 +543,8 @@ def main():
             if not lm and not args.no_diagnostics:
                 # ---- second object: SURVEY 8d's C4 shard -- 32 loop-closure candidates at 8192 points, aligned
                 # from the identity (loop_detector.cpp:225) by Levenberg-Marquardt with the launch parameters, both clouds fresh every
-                # batch -- on ONE handle and ONE host thread, 16 batches in flight in the handle's pair pool
-                F4, P4 = 16, 32
+                # batch -- on ONE handle and ONE host thread, 24 batches in flight in the handle's pair pool (two pair lists on two streams)
+                F4, P4 = 24, 32
                 lm_clouds, lm_host = [], []
                 for p_ in range(P4):
                     s_, t_, _, _ = scene.make_pair(n, n, scene.pair_seed(4, p_), "loop")

@@ -225,12 +225,12 @@ int apdgicp_batch_get_stream(apdgicp_batch* b, void** stream);              /* s
  * *d_results (device, n_pairs x sizeof(apdgicp_result)) and/or host_results (either may be NULL).  Collecting is optional.
  *   Gauss-Newton (the run length is known): every tick and the final poll are enqueued at once; TWO batches may be in flight, the
  *   next batch may reuse the same cloud slots (stream order), and a ticket stays collectable until the SECOND enqueue after its own.
- *   Levenberg-Marquardt (the reference's default, L:17; the run length is data dependent, L:64-76): the pairs of up to SIXTEEN
+ *   Levenberg-Marquardt (the reference's default, L:17; the run length is data dependent, L:64-76): the pairs of up to TWENTY-FOUR
  *   batches (APDGICP_POOL_LANES, at most 32; apdgicp_batch_is_pooled reports the number) share one pool of pair slots on the device; every optimiser tick is one launch over the pairs of all batches that
  *   still run, pairs leave as they converge and the pairs of the next batch join between two ticks, so a batch is never held
  *   by the slowest pair of another one and the GPU never waits for the host (ticks are enqueued two chunks ahead by whichever
  *   call of the handle is running; collect pumps until its batch is done).  A ticket stays collectable until its lane is
- *   needed again: the sixteenth enqueue after its own at the latest (a batch with more pairs or larger clouds than any before makes
+ *   needed again: the twenty-fourth enqueue after its own at the latest (a batch with more pairs or larger clouds than any before makes
  *   the pool lay itself out anew; the device record pointer of an EARLIER ticket collected after that is a copy of its
  *   host records, not a view of the pool).  A cloud slot referenced by a batch in flight must not be
  *   replaced -- set_cloud(s) on such a slot first waits for that batch -- so callers that want overlap give consecutive batches
@@ -244,7 +244,7 @@ int apdgicp_batch_align_enqueue(apdgicp_batch* b, const apdgicp_pair* pairs, int
  * does not run out of enqueued ticks.  No-op for Gauss-Newton handles and when nothing is in flight. */
 int apdgicp_batch_pump(apdgicp_batch* b);
 /* > 0 when apdgicp_batch_align_enqueue runs batches through the pair pool with the handle's current parameters (Levenberg-Marquardt,
- * pruned search, APDGICP_LM_POOL != 0): the number of batches that may be in flight on this one handle (16 unless
+ * pruned search, APDGICP_LM_POOL != 0): the number of batches that may be in flight on this one handle (24 unless
  * APDGICP_POOL_LANES says otherwise); 0: two record buffers, one batch at a time per handle for LM.  For callers that choose their
  * pipelining accordingly (ShardedBatchAlignerHip). */
 int apdgicp_batch_is_pooled(apdgicp_batch* b);

@@ -64,7 +64,7 @@ inline std::vector<std::pair<int64_t, int64_t>> block_partition(int64_t n_pairs,
 
 class ShardedBatchAlignerHip {
  public:
-  /// devices: HIP device indices, one rank each (rank r = devices[r]); in_flight: batches kept in flight per device (Gauss-Newton: 1 .. 8 handles; pooled Levenberg-Marquardt: up to the pool's lanes, 16)
+  /// devices: HIP device indices, one rank each (rank r = devices[r]); in_flight: batches kept in flight per device (Gauss-Newton: 1 .. 8 handles; pooled Levenberg-Marquardt: up to the pool's lanes, 24)
   ShardedBatchAlignerHip(const apdgicp_params* params, const std::vector<int>& devices, int in_flight = 4)
       : devices_(devices), slots_(std::max(1, std::min(32, in_flight))) {
     const int D = (int)devices.size();

@@ -357,15 +357,16 @@ class Engine {
     if (ev_main) e = hipEventDestroy(ev_main);
     if (ev_producer) e = hipEventDestroy(ev_producer);
     if (pool.cstream) e = hipStreamSynchronize(pool.cstream);
-    for (hipEvent_t ev_ : pool.ev)
-      if (ev_) e = hipEventDestroy(ev_);
+    for (Pool::List& li : pool.L)
+      for (hipEvent_t ev_ : li.ev)
+        if (ev_) e = hipEventDestroy(ev_);
     for (Pool::Timed& c : pool.timed) e = hipEventDestroy(c.e0), e = hipEventDestroy(c.e1);
     for (PoolJob& j : pool.jobs) {
       if (j.ev_pro) e = hipEventDestroy(j.ev_pro);
       if (j.pin) e = hipHostFree(j.pin);
       j.d_recs.release();
     }
-    for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.active, &pool.nactive, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
+    for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.L[0].active, &pool.L[0].nactive, &pool.L[1].active, &pool.L[1].nactive, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
                       &pool.nnpt, &pool.nnaux, &pool.sqd, &pool.maha, &pool.blkpart, &pool.errpart})
       b->release();
     if (pool.host) e = hipHostFree(pool.host);
@@ -962,6 +963,7 @@ class Engine {
   bool in_pool = false;
   Work t_work() const {
     Work w = in_pool ? pool.work : work;
+    if (in_pool) w.active = pool.L[pool.cur].active.as<int>();
     w.xf_linear = (params.flags & APDGICP_FLAG_XF_LINEAR_CHAIN) ? 1 : 0;  // (read at launch time: set_params may come between aligns)
     return w;
   }
@@ -1327,6 +1329,7 @@ class Engine {
     State state = FREE;
     uint64_t ticket = 0, admit_seq = 0;
     int np = 0;
+    int list = 0;                     // the pair list (tick stream) the batch runs on
     bool collected = false;
     int err = 0;
     std::string errmsg;
@@ -1345,20 +1348,33 @@ class Engine {
     int layout_gen = 0;  // counts the layouts: a new one moves (or frees) the record segments of every earlier batch
     int lanes = 0, segcap = 0, cap = 0, nmax_src = 0, nmax_tgt = 0;
     hipStream_t cstream = nullptr;
-    DevBuf state, pairs, guess, active, nactive, results, ticket, nnpart, corr, nnpt, nnaux, sqd, maha, blkpart, errpart;
+    DevBuf state, pairs, guess, results, ticket, nnpart, corr, nnpt, nnaux, sqd, maha, blkpart, errpart;
     Work work{};
-    char* host = nullptr;  // pinned: ResultRec[cap], then PoolHdr[kPoolRing]
+    char* host = nullptr;  // pinned: ResultRec[cap], then PoolHdr[kLists][kPoolRing]
     char* host_dev = nullptr;
     size_t host_cap = 0;
-    hipEvent_t ev[kPoolRing] = {};
     PoolJob jobs[kPoolLanes];
-    uint64_t seq_enq = 0, seq_seen = 0;
-    int adm[kPoolRing] = {};
-    int ub = 0;  // upper bound of the device's list length behind the last ENQUEUED poll
-    int kill_mask = 0;
-    int ticks_per_chunk = 2;  // APDGICP_POOL_TICKS
+    // TWO independent pair lists, each with its own tick stream, poll kernel, header ring and chunk numbering; a batch lives on
+    // one of them (the less loaded one when it is enqueued).  Nothing ever waits across the two streams: the poll of a list is
+    // a bubble only on its own stream, while the other list ticks.  (Until round 4: ONE list, cut into two slices on two
+    // streams that forked behind every poll and joined in front of the next -- 13 % of the time no kernel ran at all.  Two pooled
+    // handles on two host threads showed what independence is worth, tools/lm_threads.py: 1.03 -> 0.96 ms per batch of 32 loop
+    // pairs with sixteen batches in flight, 0.91 with thirty-two.)
+    static constexpr int kLists = 2;
+    struct List {
+      DevBuf active, nactive;          // the device-side list of running pairs and its length
+      hipStream_t st = nullptr;        // list 0: the engine's stream; list 1: gstreams[0]
+      hipEvent_t ev[kPoolRing] = {};   // behind the poll of chunk seq % kPoolRing
+      uint64_t seq_enq = 0, seq_seen = 0;
+      int adm[kPoolRing] = {};
+      int ub = 0;                      // upper bound of the device's list length behind the last ENQUEUED poll
+      int kill_mask = 0;
+    } L[kLists];
+    int cur = 0;                       // the list whose ticks are being launched (t_work)
+    int ticks_per_chunk = 1;  // APDGICP_POOL_TICKS
     // measured (tools/pool_sweep.sh, docs/experiments.md): chunks two deep, the list cut into two slices from 24 pairs on
-    static constexpr int depth = 2, groups = 2, group_min = 24;
+    static constexpr int groups = 2, group_min = 24;
+    int depth = 1;  // APDGICP_POOL_DEPTH: chunks enqueued ahead of the last header seen, per list
     int last_lane = -1;
     long long n_chunks = 0, n_ticks = 0, n_pair_ticks = 0;  // statistics (apdgicp_batch_last_ticks)
     std::vector<int> cloud_busy;
@@ -1368,7 +1384,7 @@ class Engine {
     struct Timed {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       uint64_t seq = 0;
-      int p0 = 0, p1 = 0, n_active = -1;
+      int list = 0, p0 = 0, p1 = 0, n_active = -1;
       bool busy = false;
     };
     std::vector<Timed> timed;
@@ -1382,9 +1398,10 @@ class Engine {
     const bool enabled = env_int("APDGICP_LM_POOL", 1) != 0;  // (0: the host-polled loop of run_align, the cross-check)
     return enabled && params.optimizer == APDGICP_OPT_LM && params.max_iterations > 0 && nn_pruned;
   }
-  // batches of one handle that may be in flight at once (8 / 12 / 16 / 24 / 32: 1.27 / 1.13 / 1.07 / 1.03 / 1.01 ms per 32 loop pairs)
-  static int pool_lanes_cfg() { return std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 16))); }
-  PoolHdr* pool_hdr(uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing; }
+  // batches of one handle that may be in flight at once (round 4, two lists: 8 / 16 / 24 / 32 in flight: 1.08 / 0.91 / 0.87 / 0.86 ms per 32 loop
+  // pairs; round 3, one list: 8 / 12 / 16 / 24 / 32: 1.27 / 1.13 / 1.07 / 1.03 / 1.01)
+  static int pool_lanes_cfg() { return std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 24))); }
+  PoolHdr* pool_hdr(int l, uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + (size_t)l * kPoolRing + seq % kPoolRing; }
   bool pool_busy() const {
     for (const PoolJob& j : pool.jobs)
       if (j.state == PoolJob::PENDING || j.state == PoolJob::RUNNING) return true;
@@ -1396,9 +1413,16 @@ class Engine {
     APD_HIP(hipStreamSynchronize(stream));  // whatever the clouds went through on the main stream so far
     if (!pool.cstream) {
       APD_HIP(hipStreamCreateWithFlags(&pool.cstream, hipStreamNonBlocking));
-      for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&pool.ev[i], hipEventDisableTiming));
+      for (Pool::List& li : pool.L)
+        for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&li.ev[i], hipEventDisableTiming));
+      APD_TRY(ensure_group_streams(3));  // gstreams[0]: the second list; gstreams[1]: the slice stream of a list that ticks alone
+      pool.L[0].st = stream, pool.L[1].st = gstreams[0];
       for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
-      pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 2)));
+      // measured on the two-list pool (docs/experiments.md, round 4): ticks per chunk 1 / 2 / 3 / 4 -> 0.931 / 0.962 / 1.018 / 1.065 ms per batch of
+      // 32 loop pairs (16 in flight, two chunks ahead); chunks ahead 1 / 2 / 3 / 4 -> 0.906 / 0.933 / 0.951 / 0.970 (one tick per chunk): a poll
+      // is a bubble on its own list's stream only, and every tick enqueued past a pair's last one is three empty launches
+      pool.ticks_per_chunk = std::max(1, std::min(16, env_int("APDGICP_POOL_TICKS", 1)));
+      pool.depth = std::max(1, std::min(kPoolRing - 2, env_int("APDGICP_POOL_DEPTH", 1)));
       profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 10));
 
     }
@@ -1411,6 +1435,8 @@ class Engine {
     if (!pool.on) return 0;
     APD_TRY(pool_drain());
     APD_HIP(hipStreamSynchronize(pool.cstream));
+    for (Pool::List& li : pool.L)
+      if (li.st) APD_HIP(hipStreamSynchronize(li.st));
     APD_HIP(hipStreamSynchronize(stream));
     for (Cloud& c : clouds) c.stage_pending = false, c.stage_wait = nullptr, c.stage_seq_word = nullptr;  // (every sort has run)
     n_stage_pending = 0;
@@ -1434,8 +1460,10 @@ class Engine {
     APD_TRY(pool.state.ensure((size_t)cap * sizeof(PairState)));
     APD_TRY(pool.pairs.ensure((size_t)cap * sizeof(PairDesc)));
     APD_TRY(pool.guess.ensure((size_t)cap * sizeof(Rigid)));
-    APD_TRY(pool.active.ensure((size_t)cap * sizeof(int)));
-    APD_TRY(pool.nactive.ensure(sizeof(int)));
+    for (Pool::List& li : pool.L) {
+      APD_TRY(li.active.ensure((size_t)cap * sizeof(int)));
+      APD_TRY(li.nactive.ensure(sizeof(int)));
+    }
     APD_TRY(pool.results.ensure((size_t)cap * sizeof(ResultRec)));
     APD_TRY(pool.ticket.ensure((size_t)2 * cap * sizeof(int)));
     APD_TRY(pool.nnpart.ensure((size_t)cap * ns * 8));
@@ -1446,7 +1474,7 @@ class Engine {
     APD_TRY(pool.maha.ensure((size_t)cap * 6 * ns * 8));
     APD_TRY(pool.blkpart.ensure((size_t)cap * nblk * kRed * 8));
     APD_TRY(pool.errpart.ensure((size_t)cap * nblk * 8));
-    const size_t host_bytes = (size_t)cap * sizeof(ResultRec) + kPoolRing * sizeof(PoolHdr);
+    const size_t host_bytes = (size_t)cap * sizeof(ResultRec) + (size_t)Pool::kLists * kPoolRing * sizeof(PoolHdr);
     if (host_bytes > pool.host_cap) {
       if (pool.host) APD_HIP(hipHostFree(pool.host));
       pool.host = pool.host_dev = nullptr, pool.host_cap = 0;
@@ -1455,8 +1483,10 @@ class Engine {
       pool.host_cap = host_bytes;
     }
     memset(pool.host, 0, pool.host_cap);  // (also the sequence words: a header counts once its word equals the expected number, never 0)
-    APD_HIP(hipMemsetAsync(pool.nactive.p, 0, sizeof(int), stream));
-    APD_HIP(hipMemsetAsync(pool.active.p, 0xff, (size_t)cap * sizeof(int), stream));
+    for (Pool::List& li : pool.L) {
+      APD_HIP(hipMemsetAsync(li.nactive.p, 0, sizeof(int), stream));
+      APD_HIP(hipMemsetAsync(li.active.p, 0xff, (size_t)cap * sizeof(int), stream));
+    }
     APD_HIP(hipStreamSynchronize(stream));
     Work& w = pool.work;
     w = Work{};
@@ -1477,13 +1507,15 @@ class Engine {
     w.ticket = pool.ticket.as<int>();
     w.coop_search = 1;
     w.pair0 = 0, w.npairs = cap;
-    w.active = pool.active.as<int>();
+    w.active = pool.L[0].active.as<int>();  // (t_work puts in the list that is being launched)
     nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)
     pool.lanes = lanes, pool.segcap = segcap, pool.cap = cap, pool.nmax_src = nmax;
     pool.layout_gen++;  // (the batches that finished under the old layout keep their host records; pool_collect knows by this number)
     for (Pool::Timed& c : pool.timed) c.busy = false;
-    pool.ub = 0, pool.seq_seen = pool.seq_enq;  // (nothing is in flight; headers of older chunks were wiped)
-    for (int& a : pool.adm) a = 0;
+    for (Pool::List& li : pool.L) {  // (nothing is in flight; headers of older chunks were wiped)
+      li.ub = 0, li.seq_seen = li.seq_enq, li.kill_mask = 0;
+      for (int& a : li.adm) a = 0;
+    }
     pool.layout_valid = true;
     return 0;
   }
@@ -1494,57 +1526,59 @@ class Engine {
       if (id < (int)pool.cloud_busy.size() && pool.cloud_busy[id] > 0) pool.cloud_busy[id]--;
   }
 
-  // one chunk: the poll (completions of everything enqueued before, admissions) and ticks_per_chunk ticks over the list
-  int pool_enqueue_chunk() {
+  // one chunk of list l: the poll (completions of everything enqueued before, admissions) and ticks_per_chunk ticks over the list
+  int pool_enqueue_chunk(int l) {
+    Pool::List& li = pool.L[l];
     PoolAdmit adm{};
     int admitted = 0;
     // A pending batch joins when its clouds are ready (sorted, covariances computed -- on the cloud stream).  While pairs are
     // still ticking the tick stream does not WAIT for that: the batch stays pending and is looked at again in front of the next
     // chunk.  (Every batch used to be admitted by the first chunk after its enqueue, behind a stream wait for its covariance
     // launch: 0.4 ms without a tick per batch, the tick stream 75 % busy.)
-    for (int l = 0; l < pool.lanes; l++) {
-      PoolJob& j = pool.jobs[l];
-      if (j.state != PoolJob::PENDING) continue;
+    for (int ln = 0; ln < pool.lanes; ln++) {
+      PoolJob& j = pool.jobs[ln];
+      if (j.state != PoolJob::PENDING || j.list != l) continue;
       const hipError_t ready = hipEventQuery(j.ev_pro);
       if (ready == hipErrorNotReady) {
-        if (pool.ub > 0 || admitted > 0) continue;
-        APD_HIP(hipStreamWaitEvent(stream, j.ev_pro, 0));  // nothing else to do: the ticks wait for these clouds
+        if (li.ub > 0 || admitted > 0) continue;
+        APD_HIP(hipStreamWaitEvent(li.st, j.ev_pro, 0));  // nothing else to do: the ticks wait for these clouds
       } else {
         APD_HIP(ready);
       }
-      adm.seg0[adm.count] = l * pool.segcap, adm.np[adm.count] = j.np, adm.count++;
-      j.state = PoolJob::RUNNING, j.admit_seq = pool.seq_enq + 1;
+      adm.seg0[adm.count] = ln * pool.segcap, adm.np[adm.count] = j.np, adm.count++;
+      j.state = PoolJob::RUNNING, j.admit_seq = li.seq_enq + 1;
       admitted += j.np;
     }
-    adm.kill_mask = pool.kill_mask, pool.kill_mask = 0;
-    const uint64_t seq = ++pool.seq_enq;
-    pool.adm[seq % kPoolRing] = admitted;
-    PoolHdr* hdr_dev = (PoolHdr*)(pool.host_dev + (size_t)pool.cap * sizeof(ResultRec)) + seq % kPoolRing;
-    hipLaunchKernelGGL(k_pool_poll, dim3(1), dim3(256), 0, stream, pool.state.as<PairState>(), pool.active.as<int>(), pool.nactive.as<int>(), pool.cap,
+    adm.kill_mask = li.kill_mask, li.kill_mask = 0;
+    const uint64_t seq = ++li.seq_enq;
+    li.adm[seq % kPoolRing] = admitted;
+    PoolHdr* hdr_dev = (PoolHdr*)(pool.host_dev + (size_t)pool.cap * sizeof(ResultRec)) + (size_t)l * kPoolRing + seq % kPoolRing;
+    hipLaunchKernelGGL(k_pool_poll, dim3(1), dim3(256), 0, li.st, pool.state.as<PairState>(), li.active.as<int>(), li.nactive.as<int>(), pool.cap,
                        pool.segcap, adm, pool.guess.as<Rigid>(), params.max_iterations, pool.ticket.as<int>(), pool.results.as<ResultRec>(),
                        (ResultRec*)pool.host_dev, hdr_dev, (int)seq, d_errflag.as<int>());
-    APD_HIP(hipEventRecord(pool.ev[seq % kPoolRing], stream));
-    pool.ub += admitted;
+    APD_HIP(hipEventRecord(li.ev[seq % kPoolRing], li.st));
+    li.ub += admitted;
     pool.n_chunks++;
-    if (pool.ub > 0) {
+    if (li.ub > 0) {
       roctx_range rr("apdgicp:pool_ticks");
       struct Reset {
         Engine& e;
         ~Reset() { e.in_pool = false, e.cur_active = 0; }
       } reset{*this};
       in_pool = true;
-      // The list is in admission order: its head holds what is left of the oldest batches -- few pairs, each with many iterations
-      // to go, a latency-bound chain of small launches -- its tail the young batches whose launches are wide.  In one stream
-      // every pair advances at the pace of the widest launch, so the list is cut into `groups` slices that tick on streams of
-      // their own between two polls (a pair that is done, or a slot behind the end of the list, leaves its launches at once).
-      const int G = pool.ub >= pool.group_min ? pool.groups : 1;
-      APD_TRY(ensure_group_streams(G));
+      pool.cur = l;
+      // A list that ticks ALONE (a single batch in flight, or its sister list is empty) is cut into two slices on two streams
+      // between its polls, like the one list of round 3: its head holds few pairs with many iterations to go, a latency-bound
+      // chain of small launches, its tail the young wide ones.  With both lists busy every list is one stream of its own.
+      const int other = pool.L[l ^ 1].ub;
+      const int G = other == 0 && li.ub >= pool.group_min ? std::max(1, std::min(pool.groups, env_int("APDGICP_POOL_GROUPS", pool.groups))) : 1;
+      hipStream_t slice = gstreams[1];
       if (G > 1) {
-        APD_HIP(hipEventRecord(ev_main, stream));
-        for (int g = 1; g < G; g++) APD_HIP(hipStreamWaitEvent(gstreams[g - 1], ev_main, 0));
+        APD_HIP(hipEventRecord(ev_main, li.st));
+        APD_HIP(hipStreamWaitEvent(slice, ev_main, 0));
       }
       for (int g = 0; g < G; g++) {
-        const int p0 = (int)((long long)pool.ub * g / G), p1 = (int)((long long)pool.ub * (g + 1) / G);
+        const int p0 = (int)((long long)li.ub * g / G), p1 = (int)((long long)li.ub * (g + 1) / G);
         if (p1 <= p0) continue;
         const int nt = pool.ticks_per_chunk;
         cur_active = p1 - p0;
@@ -1561,17 +1595,17 @@ class Engine {
               APD_HIP(hipEventCreate(&slot->e0));
               APD_HIP(hipEventCreate(&slot->e1));
             }
-            if (slot) slot->busy = true, slot->seq = seq, slot->p0 = p0, slot->p1 = p1, slot->n_active = -1, pool.cur_timed = slot;
+            if (slot) slot->busy = true, slot->list = l, slot->seq = seq, slot->p0 = p0, slot->p1 = p1, slot->n_active = -1, pool.cur_timed = slot;
           }
-          const int rc_t = launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]});
+          const int rc_t = launch_tick(Span{p0, p1 - p0, g == 0 ? li.st : slice});
           pool.cur_timed = nullptr;
           APD_TRY(rc_t);
         }
         pool.n_pair_ticks += (long long)nt * (p1 - p0);
       }
-      for (int g = 1; g < G; g++) {
-        APD_HIP(hipEventRecord(gevents[g - 1], gstreams[g - 1]));
-        APD_HIP(hipStreamWaitEvent(stream, gevents[g - 1], 0));
+      if (G > 1) {
+        APD_HIP(hipEventRecord(gevents[1], slice));
+        APD_HIP(hipStreamWaitEvent(li.st, gevents[1], 0));
       }
       pool.n_ticks += pool.ticks_per_chunk;
     }
@@ -1579,12 +1613,13 @@ class Engine {
     return 0;
   }
 
-  int pool_process(uint64_t seq) {  // header `seq` has arrived
+  int pool_process(int l, uint64_t seq) {  // header `seq` of list l has arrived
+    Pool::List& li = pool.L[l];
     std::atomic_thread_fence(std::memory_order_acquire);
-    const PoolHdr h = *pool_hdr(seq);
-    pool.seq_seen = seq;
+    const PoolHdr h = *pool_hdr(l, seq);
+    li.seq_seen = seq;
     for (Pool::Timed& c : pool.timed) {
-      if (!c.busy) continue;
+      if (!c.busy || c.list != l) continue;
       if (c.seq == seq) c.n_active = h.n_active;
       if (c.seq < seq) {  // its chunk's ticks ran in front of this poll: the events have fired
         float ms = 0.f;
@@ -1596,22 +1631,22 @@ class Engine {
       }
     }
     int ub = h.n_active;
-    for (uint64_t c = seq + 1; c <= pool.seq_enq; c++) ub += pool.adm[c % kPoolRing];
-    pool.ub = ub;
+    for (uint64_t c = seq + 1; c <= li.seq_enq; c++) ub += li.adm[c % kPoolRing];
+    li.ub = ub;
     if (h.errflag) {  // raised by a covariance launch: whose, the flag does not say -- every batch in flight fails
-      for (int l = 0; l < pool.lanes; l++) {
-        PoolJob& j = pool.jobs[l];
+      for (int ln = 0; ln < pool.lanes; ln++) {
+        PoolJob& j = pool.jobs[ln];
         if (j.state != PoolJob::PENDING && j.state != PoolJob::RUNNING) continue;
         j.err = APDGICP_ERR_INTERNAL, j.errmsg = errflag_text(h.errflag);
         if (j.state == PoolJob::PENDING) pool_job_finished(j);
-        else pool.kill_mask |= 1 << l;  // its pairs end with the next poll
+        else pool.L[j.list].kill_mask |= 1 << ln;  // its pairs end with the next poll of its list
       }
     }
-    for (int l = 0; l < pool.lanes; l++) {
-      PoolJob& j = pool.jobs[l];
-      if (j.state != PoolJob::RUNNING || j.admit_seq > seq || h.lane_left[l] != 0) continue;
+    for (int ln = 0; ln < pool.lanes; ln++) {
+      PoolJob& j = pool.jobs[ln];
+      if (j.state != PoolJob::RUNNING || j.list != l || j.admit_seq > seq || h.lane_left[ln] != 0) continue;
       j.recs.resize(j.np);
-      memcpy(j.recs.data(), (const ResultRec*)pool.host + (size_t)l * pool.segcap, (size_t)j.np * sizeof(ResultRec));
+      memcpy(j.recs.data(), (const ResultRec*)pool.host + (size_t)ln * pool.segcap, (size_t)j.np * sizeof(ResultRec));
       pool_job_finished(j);
     }
     return 0;
@@ -1619,48 +1654,68 @@ class Engine {
 
   int pool_topup() {
     for (;;) {
-      if ((int)(pool.seq_enq - pool.seq_seen) >= pool.depth) return 0;
-      bool pending = pool.kill_mask != 0;
-      for (const PoolJob& j : pool.jobs) pending |= j.state == PoolJob::PENDING;
-      if (pool.ub <= 0 && !pending) return 0;
-      APD_TRY(pool_enqueue_chunk());
+      bool any = false;
+      for (int l = 0; l < Pool::kLists; l++) {
+        Pool::List& li = pool.L[l];
+        if ((int)(li.seq_enq - li.seq_seen) >= pool.depth) continue;
+        bool pending = li.kill_mask != 0;
+        for (const PoolJob& j : pool.jobs) pending |= j.state == PoolJob::PENDING && j.list == l;
+        if (li.ub <= 0 && !pending) continue;
+        APD_TRY(pool_enqueue_chunk(l));
+        any = true;
+      }
+      if (!any) return 0;
     }
   }
 
-  // serves the pool: reads the headers that have arrived, keeps `depth` chunks enqueued; block: waits for one more header
+  // serves the pool: reads the headers that have arrived, keeps `depth` chunks enqueued per list; block: waits for one more header
   int pool_pump(bool block) {
     if (!pool.layout_valid) return block ? fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight") : 0;
     APD_HIP(hipSetDevice(device));
-    bool progress = false;
-    while (pool.seq_seen < pool.seq_enq && *(volatile int*)&pool_hdr(pool.seq_seen + 1)->seq == (int)(pool.seq_seen + 1)) {
-      APD_TRY(pool_process(pool.seq_seen + 1));
-      progress = true;
-    }
+    auto arrived = [&]() -> int {  // processes every header that is there; > 0 when there was one
+      int n = 0;
+      for (int l = 0; l < Pool::kLists; l++) {
+        Pool::List& li = pool.L[l];
+        while (li.seq_seen < li.seq_enq && *(volatile int*)&pool_hdr(l, li.seq_seen + 1)->seq == (int)(li.seq_seen + 1)) {
+          const int rc = pool_process(l, li.seq_seen + 1);
+          if (rc < 0) return rc;
+          n++;
+        }
+      }
+      return n;
+    };
+    int got = arrived();
+    if (got < 0) return got;
     APD_TRY(pool_topup());
-    if (!block || progress) return 0;  // (a header that had arrived already may be the one the caller waits for: it looks again)
-    if (pool.seq_seen == pool.seq_enq) {
+    if (!block || got > 0) return 0;  // (a header that had arrived already may be the one the caller waits for: it looks again)
+    bool outstanding = false;
+    for (const Pool::List& li : pool.L) outstanding |= li.seq_seen < li.seq_enq;
+    if (!outstanding) {
       std::string st;
-      for (int l = 0; l < pool.lanes; l++)
-        st += " [" + std::to_string(l) + ": state " + std::to_string((int)pool.jobs[l].state) + " ticket " + std::to_string(pool.jobs[l].ticket) + " np " +
-              std::to_string(pool.jobs[l].np) + " admitted at " + std::to_string(pool.jobs[l].admit_seq) + "]";
-      return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for (chunk " + std::to_string(pool.seq_enq) + ", list bound " + std::to_string(pool.ub) + ";" + st + ")");
+      for (int ln = 0; ln < pool.lanes; ln++)
+        st += " [" + std::to_string(ln) + ": state " + std::to_string((int)pool.jobs[ln].state) + " list " + std::to_string(pool.jobs[ln].list) + " ticket " +
+              std::to_string(pool.jobs[ln].ticket) + " np " + std::to_string(pool.jobs[ln].np) + " admitted at " + std::to_string(pool.jobs[ln].admit_seq) + "]";
+      return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for (chunks " + std::to_string(pool.L[0].seq_enq) + " / " + std::to_string(pool.L[1].seq_enq) +
+                                            ", list bounds " + std::to_string(pool.L[0].ub) + " / " + std::to_string(pool.L[1].ub) + ";" + st + ")");
     }
-    const uint64_t want = pool.seq_seen + 1;
-    volatile int* word = (volatile int*)&pool_hdr(want)->seq;
     {
       roctx_range rr("apdgicp:pool_wait");
       const auto t0 = std::chrono::steady_clock::now();
-      bool seen = false;
-      for (unsigned it = 0; !seen; it++) {
-        seen = *word == (int)want;
-        if (!seen && (it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(600)) break;
+      for (unsigned it = 0;; it++) {  // the next header of either list
+        got = arrived();
+        if (got != 0) break;
+        if ((it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(600)) break;
       }
-      if (!seen) {
-        APD_HIP(hipEventSynchronize(pool.ev[want % kPoolRing]));
-        if (*word != (int)want) return fail(APDGICP_ERR_INTERNAL, "pool: a poll finished without posting its header");
+      if (got < 0) return got;
+      if (got == 0) {  // a GPU that takes this long gets the sleeping wait: the older outstanding poll of the two lists
+        int l = pool.L[0].seq_seen < pool.L[0].seq_enq ? 0 : 1;
+        const uint64_t want = pool.L[l].seq_seen + 1;
+        APD_HIP(hipEventSynchronize(pool.L[l].ev[want % kPoolRing]));
+        if (*(volatile int*)&pool_hdr(l, want)->seq != (int)want) return fail(APDGICP_ERR_INTERNAL, "pool: a poll finished without posting its header");
+        got = arrived();
+        if (got < 0) return got;
       }
     }
-    APD_TRY(pool_process(want));
     return pool_topup();
   }
 
@@ -1700,6 +1755,11 @@ class Engine {
       const int rank = c.state == PoolJob::FREE ? 0 : c.state == PoolJob::DONE && c.collected ? 1 : 2;
       if (rank < best_rank || (rank == best_rank && c.ticket < best_ticket)) lane = l, best_rank = rank, best_ticket = c.ticket;
     }
+    // the pair list the batch joins: the one with fewer pairs pending or running
+    int load[Pool::kLists] = {0, 0};
+    for (const PoolJob& c : pool.jobs)
+      if (c.state == PoolJob::PENDING || c.state == PoolJob::RUNNING) load[c.list] += c.np;
+    const int list = load[1] < load[0] ? 1 : 0;
     while (pool.jobs[lane].state == PoolJob::PENDING || pool.jobs[lane].state == PoolJob::RUNNING) APD_TRY(pool_pump(true));  // (the oldest batch: its lane is next)
     PoolJob& j = pool.jobs[lane];
     // the clouds of this batch, on the cloud stream: sort, covariances of those that lack them, descriptor table
@@ -1735,14 +1795,15 @@ class Engine {
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 4; c++) hg[i].m[4 * r + c] = (double)pairs[i].guess[r + 4 * c];  // L:56 x0 = guess.cast<double>()
     }
-    APD_HIP(hipMemcpyAsync(pool.pairs.as<PairDesc>() + (size_t)lane * pool.segcap, hp, (size_t)n * sizeof(PairDesc), hipMemcpyHostToDevice, stream));
-    APD_HIP(hipMemcpyAsync(pool.guess.as<Rigid>() + (size_t)lane * pool.segcap, hg, (size_t)n * sizeof(Rigid), hipMemcpyHostToDevice, stream));
+    // (on the list's own stream: in front of the poll that admits them)
+    APD_HIP(hipMemcpyAsync(pool.pairs.as<PairDesc>() + (size_t)lane * pool.segcap, hp, (size_t)n * sizeof(PairDesc), hipMemcpyHostToDevice, pool.L[list].st));
+    APD_HIP(hipMemcpyAsync(pool.guess.as<Rigid>() + (size_t)lane * pool.segcap, hg, (size_t)n * sizeof(Rigid), hipMemcpyHostToDevice, pool.L[list].st));
     std::sort(need.begin(), need.end());
     need.erase(std::unique(need.begin(), need.end()), need.end());
     if (pool.cloud_busy.size() < clouds.size()) pool.cloud_busy.resize(clouds.size(), 0);
     for (int id : need) pool.cloud_busy[id]++;
     j.cloud_ids = need;
-    j.state = PoolJob::PENDING, j.ticket = ++align_seq, j.np = (int)n, j.collected = false, j.err = 0, j.errmsg.clear(), j.admit_seq = 0;
+    j.state = PoolJob::PENDING, j.ticket = ++align_seq, j.np = (int)n, j.collected = false, j.err = 0, j.errmsg.clear(), j.admit_seq = 0, j.list = list;
     j.layout_gen = pool.layout_gen;
     pool.last_lane = lane;
     *ticket = j.ticket;

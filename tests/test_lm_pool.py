@@ -100,12 +100,12 @@ def test_four_batches_in_flight_on_one_handle(reg, scene):
     assert b.align([(2 * i, 2 * i + 1) for i in range(sizes[5])], data[5][1]).tobytes() == want[5].tobytes()
 
 
-@pytest.mark.parametrize("lanes", (8, 16))
+@pytest.mark.parametrize("lanes", (8, 24))
 def test_more_batches_than_lanes_and_a_growing_pool(reg, scene, monkeypatch, lanes):
     """lanes + 2 enqueues without a collect: the oldest batches give their lanes up (their tickets are void), the newest
     `lanes` stay collectable; then a batch with more pairs and larger clouds than the pool was laid out for."""
-    if lanes != 16:
-        monkeypatch.setenv("APDGICP_POOL_LANES", str(lanes))   # (read when the pool is laid out; sixteen by default)
+    if lanes != 24:
+        monkeypatch.setenv("APDGICP_POOL_LANES", str(lanes))   # (read when the pool is laid out; twenty-four by default)
     else:
         monkeypatch.delenv("APDGICP_POOL_LANES", raising=False)
     data = loop_batches(scene, lanes + 2, 4, 800, 340)
@@ -223,11 +223,11 @@ def test_pool_list_longer_than_one_poll_round(reg, scene):
 
 
 def test_is_pooled_reports_the_number_of_batches_a_handle_keeps_in_flight(reg, monkeypatch):
-    """include/apdgicp_hip.h: > 0 = the pool's lanes (16 unless APDGICP_POOL_LANES says otherwise, at most 32), 0 = no pool
+    """include/apdgicp_hip.h: > 0 = the pool's lanes (24 unless APDGICP_POOL_LANES says otherwise, at most 32), 0 = no pool
     (Gauss-Newton: two record buffers per handle)."""
     monkeypatch.delenv("APDGICP_POOL_LANES", raising=False)
     lm = reg.BatchAPDGICP(reg.default_params(**LM))
-    assert lm.L.apdgicp_batch_is_pooled(lm.b) == 16
+    assert lm.L.apdgicp_batch_is_pooled(lm.b) == 24
     gn = reg.BatchAPDGICP(reg.default_params(optimizer=1, **LM))
     assert gn.L.apdgicp_batch_is_pooled(gn.b) == 0
     for env, want in (("8", 8), ("64", 32), ("0", 1)):

@@ -2,7 +2,7 @@
 """The C++ multi-device host path against the Python one on the same box and the same pairs: 32 pairs of
 8192 points per device per batch, clouds resident in HBM and re-registered every batch.
   gn: bench.py's step (odometry pairs, GN-20)      -- Python: four batch handles in flight; C++: ShardedBatchAlignerHip, 4 in flight
-  lm: SURVEY 8d's C4 shard (loop pairs from the identity, LM launch parameters) -- Python: one pooled handle, 16 in flight; C++: the same handle behind the aligner
+  lm: SURVEY 8d's C4 shard (loop pairs from the identity, LM launch parameters) -- Python: one pooled handle, 24 in flight; C++: the same handle behind the aligner
 Prints one JSON object; records of the C++ runs are checked against the Python handles byte for byte."""
 import importlib
 import json
@@ -39,7 +39,7 @@ for mode in ("gn", "lm"):
         guesses.append(g if mode == "gn" else np.eye(4, dtype=np.float32))
     path, rec = os.path.join(tmp, f"cppbench_{mode}.bin"), os.path.join(tmp, f"cppbench_{mode}.rec")
     T.write_batch_file(path, clouds, pairs, guesses)
-    F = 4 if mode == "gn" else 16
+    F = 4 if mode == "gn" else 24
     STEPS = {"gn": 60, "lm": 128}   # (timed steps: several rounds over the batches in flight)
     best = None
     for rep in range(3):
