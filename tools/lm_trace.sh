@@ -3,7 +3,7 @@
 # usage (inside gpurun): bash tools/lm_trace.sh <tag>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 t=${1:-lm}; rm -rf gpurun_out/lt_$t
-F_LIST=16 NO_POLLED=1 REPS=96 timeout 300 rocprofv3 --kernel-trace -d gpurun_out/lt_$t -o k -- python3 tools/lm_loop_bench.py > gpurun_out/lt_$t.log 2>&1
+F_LIST=${F:-24} NO_POLLED=1 REPS=96 timeout 300 rocprofv3 --kernel-trace -d gpurun_out/lt_$t -o k -- python3 tools/lm_loop_bench.py > gpurun_out/lt_$t.log 2>&1
 db=$(find gpurun_out/lt_$t -name "*.db" | head -1)
 tail -1 gpurun_out/lt_$t.log | cut -c1-300
 python3 tools/rocpd_streams.py $db 0.5 | tee gpurun_out/lt_$t.streams.txt
