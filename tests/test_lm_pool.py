@@ -233,3 +233,49 @@ def test_is_pooled_reports_the_number_of_batches_a_handle_keeps_in_flight(reg, m
     for env, want in (("8", 8), ("64", 32), ("0", 1)):
         monkeypatch.setenv("APDGICP_POOL_LANES", env)
         assert lm.L.apdgicp_batch_is_pooled(lm.b) == want
+
+
+@pytest.mark.parametrize("lanes,seed", ((24, 1), (5, 2), (2, 3)))
+def test_random_schedule_on_the_two_lists(reg, scene, monkeypatch, lanes, seed):
+    """A randomised stream of batches -- 1 ... 20 pairs, clouds of 400 ... 2600 points (the pool lays itself out anew when a batch
+    outgrows it), a random number of batches in flight, collected in random order, odometry and loop pairs mixed (2 ... 40
+    iterations) -- on the two independent pair lists of one handle: every record byte-identical to the host-polled loop."""
+    if lanes != 24:
+        monkeypatch.setenv("APDGICP_POOL_LANES", str(lanes))
+    else:
+        monkeypatch.delenv("APDGICP_POOL_LANES", raising=False)
+    rng = np.random.default_rng(1000 + seed)
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    slot_base, in_flight, done = 0, [], 0
+    for step in range(36):
+        n_pairs = int(rng.integers(1, 21))
+        n_pts = int(rng.choice([400, 900, 1500, 2600]))
+        clouds, guesses = [], []
+        for p in range(n_pairs):
+            kind = "loop" if rng.random() < 0.6 else "odometry"
+            a, c_, _, g = scene.make_pair(n_pts + int(rng.integers(0, 50)), n_pts, scene.pair_seed(500 + seed, 100 * step + p), kind)
+            clouds += [a, c_]
+            guesses.append(np.eye(4, dtype=np.float32) if kind == "loop" else g)
+        ref_b.set_clouds(0, clouds)
+        want = polled_align(ref_b, [(2 * i, 2 * i + 1) for i in range(n_pairs)], guesses)
+        # every batch in flight owns its own range of cloud slots
+        base = slot_base
+        slot_base = (slot_base + 2 * n_pairs) % 4000
+        if base + 2 * n_pairs > 4000:
+            base, slot_base = 0, 2 * n_pairs
+        if any(not (base + 2 * n_pairs <= ob or ob + 2 * on <= base) for _, _, ob, on in in_flight):   # would overlap a batch in flight: drain first
+            for t, w, _, _ in in_flight:
+                assert b.align_collect(t).tobytes() == w.tobytes()
+                done += 1
+            in_flight = []
+        b.set_clouds(base, clouds)
+        in_flight.append((b.align_enqueue([(base + 2 * i, base + 2 * i + 1) for i in range(n_pairs)], guesses), want, base, n_pairs))
+        while len(in_flight) > min(lanes - 1, int(rng.integers(1, 12))):   # (one lane stays free for the next enqueue: a ticket whose lane is reused is void)
+            t, w, _, _ = in_flight.pop(int(rng.integers(0, len(in_flight))))
+            assert b.align_collect(t).tobytes() == w.tobytes(), step
+            done += 1
+    for t, w, _, _ in in_flight:
+        assert b.align_collect(t).tobytes() == w.tobytes()
+        done += 1
+    assert done == 36
