@@ -127,9 +127,9 @@ def section_c4():
             return b.align(pairs4)
         ms = timed(c4, 10)
         res = c4()
-        # ONE handle, ONE host thread, sixteen batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
+        # ONE handle, ONE host thread, 24 batches in flight (disjoint cloud-slot ranges): LM batches share the handle's pair pool
         # (include/apdgicp_hip.h); GN batches: two record buffers, so two in flight
-        F4 = 16 if tag == "lm_launch" else 2
+        F4 = 24 if tag == "lm_launch" else 2
         b8 = reg.BatchAPDGICP(reg.default_params(**kw))
         pairs8 = [b8.make_pairs([(2 * P4 * f + s_, 2 * P4 * f + t_) for s_, t_ in pr4], gs4) for f in range(F4)]
         packed8 = b8.pack_clouds(cl4)
