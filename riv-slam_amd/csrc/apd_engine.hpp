@@ -388,6 +388,7 @@ class Engine {
       return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 64]");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
+    if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
     if (pool.on) APD_TRY(pool_drain());  // the batches in flight finish with the parameters they were enqueued with
     const bool cov_change = clouds.size() && (p->k_correspondences != params.k_correspondences || p->regularization != params.regularization);
     params = *p;

@@ -303,6 +303,11 @@ class FastAPDGICP:
         self.params.elevation_variance_deg = v
         self._push()
 
+    def setTransformOrder(self, linear_chain: bool):
+        """fp32 summation order of T * p (A:149): False = pairwise (Eigen >= 3.3, default), True = linear chain (Eigen 3.2); include/apdgicp_hip.h"""
+        self.params.flags = (self.params.flags | FLAG_XF_LINEAR_CHAIN) if linear_chain else (self.params.flags & ~FLAG_XF_LINEAR_CHAIN)
+        self._push()
+
     def setInitialLambdaFactor(self, v):
         self.params.lm_init_lambda_factor = v
         self._push()

@@ -433,6 +433,15 @@ def test_errors_are_codes_not_crashes(reg, golden):
         g.setRegularizationMethod(9)
     with pytest.raises(reg.ApdgicpError):
         g.compute_error(np.eye(4))
+    g.params.regularization = 3
+    with pytest.raises(reg.ApdgicpError) as e:   # an unknown flag bit is refused, not ignored
+        g.set_params(reg.default_params(flags=4))
+    assert e.value.code == -1
+    g.set_params(reg.default_params())
+    g.setTransformOrder(True)
+    assert g.params.flags == reg.FLAG_XF_LINEAR_CHAIN
+    g.setTransformOrder(False)
+    assert g.params.flags == 0
 
 
 def test_two_handles_two_threads(reg, golden):
