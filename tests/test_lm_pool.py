@@ -279,3 +279,30 @@ def test_random_schedule_on_the_two_lists(reg, scene, monkeypatch, lanes, seed):
         assert b.align_collect(t).tobytes() == w.tobytes()
         done += 1
     assert done == 36
+
+
+def test_pooled_search_launches_are_timed(reg, scene, monkeypatch):
+    """bench.py's roofline for the LM line: with profiling on, the pool brackets one search launch of every APDGICP_PROFILE_STRIDE-th
+    chunk with events; last_nn_profile() hands out what has been harvested since the previous call (milliseconds, launches, pairs
+    really on the list) and resets it; profiling changes no record."""
+    monkeypatch.setenv("APDGICP_PROFILE_STRIDE", "2")
+    data = loop_batches(scene, 6, 8, 2048, 390)
+    pair_idx = lambda base: [(base + 2 * i, base + 2 * i + 1) for i in range(8)]  # noqa: E731
+    ref_b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b = reg.BatchAPDGICP(reg.default_params(**LM))
+    b.set_profiling(True)
+    tickets, want = [], []
+    for s, (clouds, guesses) in enumerate(data):
+        ref_b.set_clouds(0, clouds)
+        want.append(polled_align(ref_b, pair_idx(0), guesses))
+        b.set_clouds(16 * s, clouds)
+        tickets.append(b.align_enqueue(pair_idx(16 * s), guesses))
+    ms = launches = pairs = 0
+    for t, w in zip(tickets, want):
+        assert b.align_collect(t).tobytes() == w.tobytes()
+        m_, l_, p_ = b.last_nn_profile()
+        ms, launches, pairs = ms + m_, launches + l_, pairs + p_
+    assert launches >= 2 and 0.0 < ms / launches < 5.0
+    assert launches <= pairs <= launches * 6 * 8          # at least one pair per timed launch, never more than are in flight
+    assert b.last_nn_profile() == (0.0, 0, 0)             # reading resets
+    assert "k_nn" in b.last_nn_kernel()
