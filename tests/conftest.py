@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hang (a rendezvous that never completes, a GPU that stops answering) fails the test that hangs instead of holding the run:
+    every GPU test gets a ten-minute ceiling when pytest-timeout is installed (it is in this image)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def golden():
     path = os.path.join(ROOT, "tests", "golden", "apdgicp_golden.npz")
