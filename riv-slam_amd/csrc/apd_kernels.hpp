@@ -2070,6 +2070,47 @@ __device__ __forceinline__ void block_reduce_lds(Gen&& gen /* gen(r): this lane'
   __syncthreads();
 }
 
+// ---- fp64 contraction region.  The whole library is compiled -ffp-contract=off because the fp32 nearest-neighbour arithmetic must
+// not be fused (A:149-153: the reference's build has no FMA).  The fp64 algebra behind the search -- RCR, its inverse, e, J^T M J,
+// compute_error -- is compared with the reference by tolerance (5e-6, set by the fp32 atan2f), and there a*b + c as ONE rounding
+// instead of two moves results by ~1e-16 relative while a third of k_linearize's fp64 instructions disappear (v_mul_f64 + v_add_f64
+// -> v_fma_f64: 961 -> ~800 vector instructions per wave).  Everything fp32 inside stays in explicit contract(off) blocks; the
+// covariance kernels (bitwise equal across their four variants) and apd_math.hpp stay unfused.
+#pragma clang fp contract(fast)
+__device__ __forceinline__ Sym3 sym3_rotate_c(const Rigid& T, const Sym3& c) {  // sym3_rotate (apd_math.hpp), contracted
+  double rc[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double a = T.m[4 * i], b = T.m[4 * i + 1], d = T.m[4 * i + 2];
+    rc[3 * i + 0] = a * c.xx + b * c.xy + d * c.xz;
+    rc[3 * i + 1] = a * c.xy + b * c.yy + d * c.yz;
+    rc[3 * i + 2] = a * c.xz + b * c.yz + d * c.zz;
+  }
+  Sym3 o;
+  o.xx = rc[0] * T.m[0] + rc[1] * T.m[1] + rc[2] * T.m[2];
+  o.xy = rc[0] * T.m[4] + rc[1] * T.m[5] + rc[2] * T.m[6];
+  o.xz = rc[0] * T.m[8] + rc[1] * T.m[9] + rc[2] * T.m[10];
+  o.yy = rc[3] * T.m[4] + rc[4] * T.m[5] + rc[5] * T.m[6];
+  o.yz = rc[3] * T.m[8] + rc[4] * T.m[9] + rc[5] * T.m[10];
+  o.zz = rc[6] * T.m[8] + rc[7] * T.m[9] + rc[8] * T.m[10];
+  return o;
+}
+__device__ __forceinline__ Sym3 sym3_inverse_c(const Sym3& a) {  // sym3_inverse (apd_math.hpp), contracted
+  const double c00 = a.yy * a.zz - a.yz * a.yz;
+  const double c01 = a.yz * a.xz - a.xy * a.zz;
+  const double c02 = a.xy * a.yz - a.yy * a.xz;
+  const double det = a.xx * c00 + a.xy * c01 + a.xz * c02;
+  const double id = 1.0 / det;
+  Sym3 r;
+  r.xx = c00 * id;
+  r.xy = c01 * id;
+  r.xz = c02 * id;
+  r.yy = (a.xx * a.zz - a.xz * a.xz) * id;
+  r.yz = (a.xy * a.xz - a.xx * a.yz) * id;
+  r.zz = (a.xx * a.yy - a.xy * a.xy) * id;
+  return r;
+}
+
 // what one source point contributes to linearize (A:229-258); all zero without a correspondence
 struct LinPoint {
   Sym3 Mi;                    // RCR^-1, A:191
@@ -2127,15 +2168,19 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
     // APD sensor-noise covariance from the transformed point (A:167-184)
     const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
-    const double aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
+    double aoa, elevation, azimuth;
+    {  // fp32, as the reference evaluates it (float overloads, no FMA): not contracted
+#pragma clang fp contract(off)
+      aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
+      elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
+      azimuth = (double)atan2f(pty, ptx);
+    }
     double sin_aoa, cos_aoa;
     sincos_pi(aoa, &sin_aoa, &cos_aoa);
     (void)sin_aoa;
     const double s_x = dist * cst.dist_var / 400;
     const double s_y = dist * cst.sin_az / cos_aoa;
     const double s_z = dist * cst.sin_el / cos_aoa;
-    const double elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
-    const double azimuth = (double)atan2f(pty, ptx);
     double ce, se, caz, saz;
     sincos_pi(elevation, &se, &ce);
     sincos_pi(azimuth, &saz, &caz);
@@ -2151,8 +2196,8 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     cd.yz = a10 * a20 + a12 * a22;
     cd.zz = a20 * a20 + a22 * a22;
     if (cst.plain_gicp) cd = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fast_gicp_impl.hpp: RCR = cov_B + T cov_A T^T
-    const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate(T, sym3_add(cov_A, cd)));  // A:188
-    const Sym3 Mi = sym3_inverse(RCR);                                                      // A:191
+    const Sym3 RCR = sym3_add(sym3_add(cov_B, cd), sym3_rotate_c(T, sym3_add(cov_A, cd)));  // A:188
+    const Sym3 Mi = sym3_inverse_c(RCR);                                                      // A:191
     if (w.maha) {  // (null in a Gauss-Newton batch: only compute_error and the Mahalanobis getter of a single handle read it)
       double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
       mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
@@ -2219,6 +2264,9 @@ __device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int 
     default: return -mez;
   }
 }
+
+#pragma clang fp contract(off)
+// ---- end of the fp64 contraction region
 
 // ----------------------------------------------------------------------------------------------
 // k_linearize: one lane per source point.  Merges the split partials, re-scans the winning chunk
@@ -2407,10 +2455,14 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
       const size_t ns = w.nstride;
       const double mxx = mo[0], mxy = mo[ns], mxz = mo[2 * ns], myy = mo[3 * ns], myz = mo[4 * ns], mzz = mo[5 * ns];
       const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
-      const double ex = (double)q.x - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
-      const double ey = (double)q.y - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
-      const double ez = (double)q.z - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
-      acc[0] = ex * (mxx * ex + mxy * ey + mxz * ez) + ey * (mxy * ex + myy * ey + myz * ez) + ez * (mxz * ex + myz * ey + mzz * ez);
+      {  // fp64 algebra, contracted like linearize_point's (the two costs an LM step compares are evaluated alike)
+#pragma clang fp contract(fast)
+        const double ex = (double)q.x - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
+        const double ey = (double)q.y - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
+        const double ez = (double)q.z - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
+        const double mex = mxx * ex + mxy * ey + mxz * ez, mey = mxy * ex + myy * ey + myz * ez, mez = mxz * ex + myz * ey + mzz * ez;
+        acc[0] = ex * mex + ey * mey + ez * mez;
+      }
     }
   }
   block_reduce<1, LIN_BLK>(acc, red, tid);

@@ -1188,3 +1188,16 @@ def test_covariances_are_equivariant_at_8k(reg, scene):
     err = np.abs(covs[1] - want).reshape(len(cloud), -1).max(1) / np.maximum(np.abs(want).reshape(len(cloud), -1).max(1), 1e-12)
     assert (err < 1e-3).mean() > 0.99, float((err < 1e-3).mean())
 
+
+
+def test_adversarial_fuzz_runs_clean_for_a_few_seconds():
+    """tests/measure/fuzz_parity.py (lattices, duplicates, lines, planes, 3 km offsets, block-edge sizes, tiny clouds; every
+    regularisation, both transform orders, GN and LM) against the oracle: about 300 cases here, 5 000 per run in profiles/."""
+    import json
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "measure", "fuzz_parity.py")
+    out = subprocess.run([sys.executable, tool, "20", "100000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout)
+    assert d["n_failures"] == 0 and sum(k["cases"] for k in d["kinds"].values()) >= 50

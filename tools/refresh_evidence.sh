@@ -7,11 +7,12 @@
 #   pmc_*.md             separate --pmc passes (never combined with other trace domains): HBM bytes and the issue-side SQ counters
 #   pmc_nn_latest.json   per-launch PMC numbers of the batch's nearest-neighbour launches (bench.py's roofline.traffic / roofline_issue)
 #   pmc_lm_loop.json     the same per listed pair slot for the pooled LM ticks (bench.py --kind loop --optimizer lm)
+#   fuzz_parity.json     tests/measure/fuzz_parity.py, 300 s of adversarial cases against the oracle; parity_sweep*.json: the seeded sweep
 #   bench.json           the un-profiled default run; bench_lm_loop.json: the reference's optimiser on the C4 shard
 if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
   for f in kernel_stats.md kernel_stats_lm_loop.md knob_matrix.txt pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
-           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json; do
+           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json parity_sweep.json parity_sweep_xflin.json; do
     [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
   done
   for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
@@ -66,6 +67,10 @@ timeout 900 python3 tests/measure/bench_configs.py > $ev/other_configs.json 2> $
 timeout 600 python3 tests/measure/odometry_protocol.py > $ev/odometry_protocol.json 2> $ev/odometry.err
 timeout 900 python3 tools/cpp_vs_python.py 2> $ev/cpp_vs_python.err | tail -1 > $ev/cpp_vs_python.json
 timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
+# parity beyond the test suite: the seeded sweep under both transform orders, the adversarial fuzz (five minutes of cases)
+timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep.json 2> $ev/parity_sweep.err
+XF_FLAGS=2 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep_xflin.json 2>> $ev/parity_sweep.err
+timeout 500 python3 tests/measure/fuzz_parity.py 300 0 > $ev/fuzz_parity.json 2> $ev/fuzz_parity.err
 for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ $ev/p_lm_fetch $ev/p_lm_write $ev/p_lm_insts $ev/p_lm_busy $ev/ks_lm; do rm -rf $d; done
 find $ev/ks -type f ! -name "*.db" -delete
 head -c 1500 $ev/bench.json; echo
