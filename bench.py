@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI, records gathered from device memory (the measured configuration); gloo: the 96-byte records "
                          "travel as CPU tensors through the same gather / barrier / all_reduce(MAX) code")
+    ap.add_argument("--host-clouds", action="store_true",
+                    help="every step hands the library HOST clouds (numpy, pageable) instead of resident device buffers: the PCIe-inclusive rate "
+                         "DESIGN.md quotes beside the headline -- never the headline itself")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered records of the last step (uint8 [pairs, 96]) to this .npy file")
     return ap.parse_args()
 
@@ -254,7 +257,8 @@ def main():
     slots = [(batches[0], 2 * P * h, batch.make_pairs([(2 * P * h + a, 2 * P * h + b_) for a, b_ in pair_idx], guesses)) if lm else
              (batches[h], 0, batch.make_pairs(pair_idx, guesses)) for h in range(H)]
     pairs_arr = slots[0][2]
-    clouds_arg = batch.pack_clouds(d_clouds)   # the pointer array a C caller would hold; the clouds themselves are re-registered every step
+    # the pointer array a C caller would hold; the clouds themselves are re-registered every step
+    clouds_arg = batch.pack_clouds([c for s_, t_, _g in h_pairs for c in (s_, t_)] if args.host_clouds else d_clouds)
     hstreams = [torch.cuda.ExternalStream(bh.stream_ptr(), device=local_rank) for bh in batches]
 
     class Engine:  # this rank's block through the C ABI, synchronous form (ShardedBatchAligner.align); the timed loop uses gather() only
@@ -424,6 +428,8 @@ def main():
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 nearest-neighbour search + f64 covariance/Mahalanobis/Hessian", "data": "synthetic",
+            "inputs": ("HOST clouds every step (numpy, pageable; packed into pinned memory by the library, read over PCIe): the PCIe-inclusive rate, NOT the headline"
+                       if args.host_clouds else "resident in HBM before the timed region"),
             "config": {"workload": (f"BASELINE configs[1] (8k x 8k scan pair, 20 GN iterations) x {P} independent pairs per GPU per step "
                                     f"(= per-GPU shard of configs[3]); pair kind '{args.kind}'" if not lm else
                                     f"BASELINE configs[3], per-GPU shard as SURVEY 8d specifies it: {P} pairs per GPU per step, kind '{args.kind}'"

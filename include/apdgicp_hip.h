@@ -204,8 +204,10 @@ int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64
 /* sets cloud slot `index` (>= 0; slots need not be contiguous: a caller that keeps several batches in flight gives each its own
  * range), reusing the slot's device buffers; its covariances are recomputed by the next align */
 int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
-/* sets clouds first_index .. first_index+count-1 in one call (one pack launch when on_device):
- * xyz[i] / n[i] describe cloud first_index+i, all with the same stride */
+/* sets clouds first_index .. first_index+count-1 in one call: xyz[i] / n[i] describe cloud first_index+i, all with the same stride.
+ * on_device: one pack launch.  Host clouds (four or more, 32 k points or more in all): packed by a few host threads
+ * (APDGICP_HOST_THREADS, default 4, the caller included) into one pinned region, ONE asynchronous copy, one pack launch; the
+ * caller's buffers are free on return */
 int apdgicp_batch_set_clouds(apdgicp_batch* b, int32_t first_index, int32_t count, const float* const* xyz, const int64_t* n,
                              int64_t stride_bytes, int on_device);
 /* covariances of every cloud that does not have them yet (align does this lazily as well) */

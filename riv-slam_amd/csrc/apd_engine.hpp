@@ -12,10 +12,15 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -347,6 +352,10 @@ class Engine {
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
+    if (bulk_host) e = hipHostFree(bulk_host);
+    if (bulk_ev) e = hipEventDestroy(bulk_ev);
+    bulk_dev.release();
+    host_pool.reset();
     if (h_poll) e = hipHostFree(h_poll);
     if (alt.h_poll) e = hipHostFree(alt.h_poll);
     if (alt.ev_poll) e = hipEventDestroy(alt.ev_poll);
@@ -409,7 +418,7 @@ class Engine {
     c.trans_eps = params.transformation_epsilon;
     c.rot_eps = params.rotation_epsilon;
     c.lm_init_lambda_factor = params.lm_init_lambda_factor;
-    c.dist_var = params.distance_variance;
+    c.dist_var_400 = params.distance_variance / 400;
     c.sin_az = std::sin(params.azimuth_variance_deg / 180 * M_PI);   // A:170
     c.sin_el = std::sin(params.elevation_variance_deg / 180 * M_PI); // A:171
     return c;
@@ -427,6 +436,99 @@ class Engine {
     if (cstream != stream) APD_HIP(hipStreamWaitEvent(cstream, ev_producer, 0));
     return 0;
   }
+
+  // A scan-sized host cloud into its pinned buffer: {x, y, z, 1} per point, the bounding box behind the points.  Touches nothing but
+  // its arguments: apdgicp_batch_set_clouds runs it for many clouds at once on the host pool below.
+  struct HostPackTask {
+    float4* dst;
+    const char* raw;
+    int64_t n, stride_bytes;
+  };
+  static void pack_staged_host(float4* dst, const char* raw, int64_t n, int64_t stride_bytes) {
+    const float inf = std::numeric_limits<float>::infinity();
+    // four independent running boxes (a single one is a chain of dependent min/max, twice the time of the packing itself);
+    // `v < lo ? v : lo` leaves a NaN coordinate out, like the device's fminf
+    float lo[4][3], hi[4][3];
+    for (int u = 0; u < 4; u++)
+      for (int a = 0; a < 3; a++) lo[u][a] = inf, hi[u][a] = -inf;
+    auto put = [&](int64_t q, int u) {
+      const float* sp = (const float*)(raw + q * stride_bytes);
+      const float v[3] = {sp[0], sp[1], sp[2]};
+      dst[q] = make_float4(v[0], v[1], v[2], 1.0f);
+      for (int a = 0; a < 3; a++) lo[u][a] = v[a] < lo[u][a] ? v[a] : lo[u][a], hi[u][a] = v[a] > hi[u][a] ? v[a] : hi[u][a];
+    };
+    int64_t q = 0;
+    {  // one 16-byte load, blend, store: the fourth float read with a point is its own padding or the next point's x -- inside the caller's buffer
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f vlo[2] = {v4f(inf), v4f(inf)}, vhi[2] = {v4f(-inf), v4f(-inf)};
+      for (; q + 2 <= n - 1; q += 2)  // (not the last point: its fourth float may lie outside the caller's buffer)
+        for (int u = 0; u < 2; u++) {
+          v4f v;
+          memcpy(&v, raw + (q + u) * stride_bytes, 16);
+          vlo[u] = v < vlo[u] ? v : vlo[u], vhi[u] = v > vhi[u] ? v : vhi[u];
+          v.w = 1.0f;
+          memcpy(&dst[q + u], &v, 16);
+        }
+      for (int u = 0; u < 2; u++)
+        for (int a = 0; a < 3; a++) lo[u][a] = vlo[u][a], hi[u][a] = vhi[u][a];
+    }
+    for (; q + 4 <= n; q += 4) put(q, 0), put(q + 1, 1), put(q + 2, 2), put(q + 3, 3);
+    for (; q < n; q++) put(q, 0);
+    for (int u = 1; u < 4; u++)
+      for (int a = 0; a < 3; a++) lo[0][a] = std::min(lo[0][a], lo[u][a]), hi[0][a] = std::max(hi[0][a], hi[u][a]);
+    dst[n] = make_float4(lo[0][0], lo[0][1], lo[0][2], 0.f), dst[n + 1] = make_float4(hi[0][0], hi[0][1], hi[0][2], 0.f);
+  }
+
+  // A few persistent host threads for set_clouds_host (64 clouds of 8192 points: 0.25 ms of packing on one core, a third of a
+  // step).  Created on first use, parked on a condition variable in between.
+  struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)>* fn = nullptr;
+    int n = 0, busy = 0;
+    std::atomic<int> next{0};
+    uint64_t gen = 0;
+    bool stop = false;
+    void start(int k) {
+      for (int t = 0; t < k; t++)
+        th.emplace_back([this]() {
+          uint64_t seen = 0;
+          for (;;) {
+            const std::function<void(int)>* f;
+            int cnt;
+            {
+              std::unique_lock<std::mutex> lk(m);
+              cv.wait(lk, [&]() { return stop || gen != seen; });
+              if (stop) return;
+              seen = gen, f = fn, cnt = n;
+            }
+            for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < cnt;) (*f)(i);
+            std::lock_guard<std::mutex> lk(m);
+            if (--busy == 0) cv_done.notify_one();
+          }
+        });
+    }
+    void run(int count, const std::function<void(int)>& f) {  // f(0 .. count - 1), the caller takes part; returns when all are done
+      {
+        std::lock_guard<std::mutex> lk(m);
+        fn = &f, n = count, busy = (int)th.size(), next.store(0, std::memory_order_relaxed), gen++;
+      }
+      cv.notify_all();
+      for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) f(i);
+      std::unique_lock<std::mutex> lk(m);
+      cv_done.wait(lk, [&]() { return busy == 0; });
+    }
+    ~HostPool() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+      }
+      cv.notify_all();
+      for (auto& t : th) t.join();
+    }
+  };
+  std::unique_ptr<HostPool> host_pool;
 
   struct HostStage {
     char* p = nullptr;
@@ -474,39 +576,7 @@ class Engine {
         APD_HIP(hipHostGetDevicePointer((void**)&c.stage_dev, c.stage_p, 0));
         c.stage_cap = cap;
       }
-      float4* dst = (float4*)c.stage_p;
-      const float inf = std::numeric_limits<float>::infinity();
-      // four independent running boxes (a single one is a chain of dependent min/max, twice the time of the packing itself);
-      // `v < lo ? v : lo` leaves a NaN coordinate out, like the device's fminf
-      float lo[4][3], hi[4][3];
-      for (int u = 0; u < 4; u++)
-        for (int a = 0; a < 3; a++) lo[u][a] = inf, hi[u][a] = -inf;
-      auto put = [&](int64_t q, int u) {
-        const float* sp = (const float*)(raw + q * stride_bytes);
-        const float v[3] = {sp[0], sp[1], sp[2]};
-        dst[q] = make_float4(v[0], v[1], v[2], 1.0f);
-        for (int a = 0; a < 3; a++) lo[u][a] = v[a] < lo[u][a] ? v[a] : lo[u][a], hi[u][a] = v[a] > hi[u][a] ? v[a] : hi[u][a];
-      };
-      int64_t q = 0;
-      if (stride_bytes >= 16) {  // the fourth float read with the point belongs to the point: one 16-byte load, blend, store
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        v4f vlo[2] = {v4f(inf), v4f(inf)}, vhi[2] = {v4f(-inf), v4f(-inf)};
-        for (; q + 2 <= n - 1; q += 2)  // (not the last point: its fourth float may lie outside the caller's buffer)
-          for (int u = 0; u < 2; u++) {
-            v4f v;
-            memcpy(&v, raw + (q + u) * stride_bytes, 16);
-            vlo[u] = v < vlo[u] ? v : vlo[u], vhi[u] = v > vhi[u] ? v : vhi[u];
-            v.w = 1.0f;
-            memcpy(&dst[q + u], &v, 16);
-          }
-        for (int u = 0; u < 2; u++)
-          for (int a = 0; a < 3; a++) lo[u][a] = vlo[u][a], hi[u][a] = vhi[u][a];
-      }
-      for (; q + 4 <= n; q += 4) put(q, 0), put(q + 1, 1), put(q + 2, 2), put(q + 3, 3);
-      for (; q < n; q++) put(q, 0);
-      for (int u = 1; u < 4; u++)
-        for (int a = 0; a < 3; a++) lo[0][a] = std::min(lo[0][a], lo[u][a]), hi[0][a] = std::max(hi[0][a], hi[u][a]);
-      dst[n] = make_float4(lo[0][0], lo[0][1], lo[0][2], 0.f), dst[n + 1] = make_float4(hi[0][0], hi[0][1], hi[0][2], 0.f);
+      pack_staged_host((float4*)c.stage_p, raw, n, stride_bytes);
       c.staged = true;
     } else if (!on_device) {
       // Host clouds (the odometry nodelet hands over pcl::PointXYZI, 32 bytes a point): the three coordinates are packed into
@@ -540,6 +610,65 @@ class Engine {
     c.token = token;
     desc_dirty = true;
     return 0;
+  }
+
+  // Many host clouds at once (a batch of loop-closure candidates handed over as PCL clouds): packed to {x, y, z, 1} by the host
+  // pool into ONE pinned region, ONE asynchronous copy (the DMA engine, beside the kernels of the other steps in flight) and the
+  // pack launch of set_clouds_device.  The single-cloud path lets the sort read a scan-sized cloud straight from pinned memory --
+  // right for one frame (no copy in front of the first kernel), wrong for 64 clouds: the sort's blocks then sit on their compute
+  // units waiting for PCIe (bench.py --host-clouds: 1.07 ms per step that way, 0.96 with the packing vectorised, see docs/experiments.md).
+  char* bulk_host = nullptr;
+  size_t bulk_cap = 0;
+  hipEvent_t bulk_ev = nullptr;
+  DevBuf bulk_dev;
+  int set_clouds_host(int first, int count, const float* const* xyz, const int64_t* ns, int64_t stride_bytes) {
+    if (first < 0 || count <= 0 || first + (long long)count > (1 << 24)) return fail(APDGICP_ERR_INVALID_ARG, "bad cloud range");
+    if (!xyz || !ns) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail(APDGICP_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 12");
+    int64_t pts = 0;
+    for (int q = 0; q < count; q++) {
+      if (!xyz[q] || ns[q] <= 0 || ns[q] > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud is null, empty or too large");
+      pts += ns[q];
+    }
+    if (count < 4 || pts < 32768) {
+      for (int q = 0; q < count; q++) APD_TRY(set_cloud(first + q, xyz[q], ns[q], stride_bytes, 0, 0));
+      return 0;
+    }
+    APD_HIP(hipSetDevice(device));
+    const size_t need = ((size_t)pts + 2 * (size_t)count) * 16;  // (pack_staged_host leaves a bounding box behind every cloud: not used here)
+    if (!bulk_ev) APD_HIP(hipEventCreateWithFlags(&bulk_ev, hipEventDisableTiming));
+    else APD_HIP(hipEventSynchronize(bulk_ev));  // the previous copy out of the pinned region (long done: a step ago on this handle)
+    if (need > bulk_cap) {
+      if (bulk_host) APD_HIP(hipHostFree(bulk_host));
+      bulk_host = nullptr, bulk_cap = 0;
+      APD_HIP(hipHostMalloc((void**)&bulk_host, need * 5 / 4, hipHostMallocDefault));
+      bulk_cap = need * 5 / 4;
+    }
+    if (need > bulk_dev.cap) APD_HIP(hipStreamSynchronize(cstream));  // (the pack launch of the previous call may still read it)
+    APD_TRY(bulk_dev.ensure(need));
+    std::vector<HostPackTask> tasks(count);
+    std::vector<const float*> dptr(count);
+    size_t off = 0;
+    for (int q = 0; q < count; q++) {
+      tasks[q] = HostPackTask{(float4*)(bulk_host + off), (const char*)xyz[q], ns[q], stride_bytes};
+      dptr[q] = (const float*)((char*)bulk_dev.p + off);
+      off += ((size_t)ns[q] + 2) * 16;
+    }
+    static const int want = []() {
+      const char* e = getenv("APDGICP_HOST_THREADS");  // threads packing host clouds, the caller included (1: no pool)
+      const int hc = (int)std::thread::hardware_concurrency();
+      return std::max(1, e ? atoi(e) : std::min(4, hc > 1 ? hc / 2 : 1));
+    }();
+    if (want > 1) {
+      if (!host_pool) host_pool.reset(new HostPool()), host_pool->start(want - 1);
+      const std::function<void(int)> f = [&](int i) { pack_staged_host(tasks[i].dst, tasks[i].raw, tasks[i].n, tasks[i].stride_bytes); };
+      host_pool->run(count, f);
+    } else {
+      for (const HostPackTask& t : tasks) pack_staged_host(t.dst, t.raw, t.n, t.stride_bytes);
+    }
+    APD_HIP(hipMemcpyAsync(bulk_dev.p, bulk_host, need, hipMemcpyHostToDevice, cstream));
+    APD_HIP(hipEventRecord(bulk_ev, cstream));
+    return set_clouds_device(first, count, dptr.data(), ns, 16);
   }
 
   // many device-resident clouds at once: one pack launch instead of one per cloud

@@ -67,7 +67,7 @@ struct Consts {
   int plain_gicp;    // APDGICP_FLAG_PLAIN_GICP: no APD covariance (upstream FastGICP cost)
   double thr2;       // corr_dist_threshold_^2 in double (A:156)
   double trans_eps, rot_eps, lm_init_lambda_factor;
-  double dist_var, sin_az, sin_el;  // A:169-171
+  double dist_var_400, sin_az, sin_el;  // A:169-171: distance_variance / 400, sin(azimuth variance), sin(elevation variance)
 };
 
 enum { ST_NEED_LIN = 0, ST_NEED_ERR = 1, ST_DONE = 2 };
@@ -2178,9 +2178,12 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     double sin_aoa, cos_aoa;
     sincos_pi(aoa, &sin_aoa, &cos_aoa);
     (void)sin_aoa;
-    const double s_x = dist * cst.dist_var / 400;
-    const double s_y = dist * cst.sin_az / cos_aoa;
-    const double s_z = dist * cst.sin_el / cos_aoa;
+    // (A:169-171 divide three times -- dist * dist_var / 400, dist * sin(az) / cos(aoa), dist * sin(el) / cos(aoa); here one
+    // division, dist / cos(aoa), and dist_var / 400 from the host: a rounding apart, like the contraction, 22 fp64 instructions less)
+    const double s_x = dist * cst.dist_var_400;
+    const double dist_c = dist / cos_aoa;
+    const double s_y = dist_c * cst.sin_az;
+    const double s_z = dist_c * cst.sin_el;
     double ce, se, caz, saz;
     sincos_pi(elevation, &se, &ce);
     sincos_pi(azimuth, &saz, &caz);

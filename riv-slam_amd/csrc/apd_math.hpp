@@ -107,14 +107,36 @@ APD_HD Sym3 sym3_inverse(const Sym3& a) {
   return r;
 }
 
+// 1 / sqrt(x) for a finite x >= 1 to within an ulp or two: v_rsq_f64 and two Newton steps (the IEEE route is a square root AND a
+// division: 23 fp64 instructions against 9)
+APD_HD double rsqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // One Jacobi rotation zeroing a_pq of a symmetric 3x3; r is the third index.
 // (app, aqq, apq, arp, arq) are the affected entries, (v?p, v?q) the two eigenvector columns.
+// t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without theta: numerator and denominator
+// times |2 apq| -- one division and one square root per rotation instead of three and two; c = 1 / sqrt(t^2 + 1) by rsqrt_pos.
+// (theta = 0 takes the root t = +1 like `theta >= 0` did.)  The algebra is allowed to contract (fma): the result is compared by
+// tolerance (the reference runs Eigen's JacobiSVD), and every covariance kernel runs this one function, so they stay bitwise equal.
 APD_HD void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq, double& v0p, double& v0q, double& v1p, double& v1q,
                        double& v2p, double& v2q) {
+#pragma clang fp contract(fast)
   if (apq == 0.0) return;
-  const double theta = (aqq - app) / (2.0 * apq);
-  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  const double d = aqq - app, h = 2.0 * apq;
+  const bool pos = d == 0.0 || ((d > 0.0) == (apq > 0.0));
+  const double t = (pos ? fabs(h) : -fabs(h)) / (fabs(d) + sqrt(d * d + h * h));
+  const double c = rsqrt_pos(t * t + 1.0), s = t * c;
   app = app - t * apq;
   aqq = aqq + t * apq;
   apq = 0.0;
@@ -134,6 +156,7 @@ APD_HD void sym3_eig(const Sym3& A, double w[3], double u[9]) {
   double a00 = A.xx, a01 = A.xy, a02 = A.xz, a11 = A.yy, a12 = A.yz, a22 = A.zz;
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
   for (int sweep = 0; sweep < 32; sweep++) {
+#pragma clang fp contract(fast)
     const double off = a01 * a01 + a02 * a02 + a12 * a12;
     const double diag = a00 * a00 + a11 * a11 + a22 * a22;
     if (off == 0.0 || off <= 1e-40 * diag) break;
@@ -160,6 +183,7 @@ APD_HD void sym3_eig(const Sym3& A, double w[3], double u[9]) {
 
 // U * diag(vals) * U^T
 APD_HD Sym3 sym3_from_eig(const double u[9], double l0, double l1, double l2) {
+#pragma clang fp contract(fast)
   Sym3 o;
   o.xx = u[0] * l0 * u[0] + u[1] * l1 * u[1] + u[2] * l2 * u[2];
   o.xy = u[0] * l0 * u[3] + u[1] * l1 * u[4] + u[2] * l2 * u[5];

@@ -594,9 +594,7 @@ int apdgicp_batch_set_clouds(apdgicp_batch* b, int32_t first_index, int32_t coun
   return guarded([&]() -> int {
     if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
     if (on_device) return b->eng.set_clouds_device(first_index, count, xyz, n, stride_bytes);
-    if (!xyz || !n) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
-    for (int q = 0; q < count; q++) APD_TRY(b->eng.set_cloud(first_index + q, xyz[q], n[q], stride_bytes, 0, 0));
-    return 0;
+    return b->eng.set_clouds_host(first_index, count, xyz, n, stride_bytes);
   });
 }
 

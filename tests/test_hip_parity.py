@@ -959,6 +959,43 @@ def test_a_host_cloud_replaced_by_a_device_cloud_before_any_align(reg, scene):
     assert b.align([(0, 1)], [guess]).tobytes() == want.tobytes()
 
 
+def test_many_host_clouds_packed_by_the_host_pool(reg, scene):
+    """apdgicp_batch_set_clouds with HOST clouds packs them on a few host threads (four or more scan-sized clouds): records byte for
+    byte those of the same clouds set one by one (no pool) and of device-resident copies -- for tight [n, 3] rows, padded rows
+    (pcl::PointXYZI: 32 bytes), mixed sizes including one outside the pinned size class, repeated on the same slots."""
+    import torch
+    kw = dict(optimizer=1, max_iterations=4, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0)
+    sizes = [(8192, 8192), (4096, 8192), (8192, 2049), (3000, 8192), (8192, 8192), (1500, 20000)]
+    clouds, guesses = [], []
+    for i, (n, m) in enumerate(sizes):
+        s_, t_, _, g_ = scene.make_pair(n, m, scene.pair_seed(21, i), "odometry")
+        clouds += [s_, t_]
+        guesses.append(g_)
+    pairs = [(2 * i, 2 * i + 1) for i in range(len(sizes))]
+
+    def padded(c):
+        buf = np.full((len(c), 8), 7.0, dtype=np.float32)   # x y z pad intensity pad pad pad
+        buf[:, :3] = c
+        return buf
+
+    one = reg.BatchAPDGICP(reg.default_params(**kw))
+    for i, c in enumerate(clouds):
+        one.set_cloud(i, c)
+    want = one.align(pairs, guesses).tobytes()
+    dev = reg.BatchAPDGICP(reg.default_params(**kw))
+    dev.set_clouds(0, [torch.from_numpy(c).cuda() for c in clouds])
+    assert dev.align(pairs, guesses).tobytes() == want
+    many = reg.BatchAPDGICP(reg.default_params(**kw))
+    for rnd in range(3):
+        many.set_clouds(0, [padded(c) for c in clouds] if rnd == 1 else clouds)
+        assert many.align(pairs, guesses).tobytes() == want, rnd
+    # the same slots with OTHER clouds in between: the pinned buffers are rewritten, nothing stale survives
+    many.set_clouds(0, clouds[::-1])
+    many.align([(1, 0)], [guesses[-1]])
+    many.set_clouds(0, clouds)
+    assert many.align(pairs, guesses).tobytes() == want
+
+
 def test_exact_ties_resolve_to_the_lowest_original_index(reg):
     """A source point exactly midway between two target points (equal fp32 distances, far apart on the
     Z-curve) and duplicated target points: the oracle's rule is (distance, index) lexicographic."""

@@ -12,7 +12,7 @@
 if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
   for f in kernel_stats.md kernel_stats_lm_loop.md knob_matrix.txt pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
-           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json parity_sweep.json parity_sweep_xflin.json; do
+           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json; do
     [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
   done
   for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
@@ -53,6 +53,7 @@ pass lm_busy "$LMC" $BUSY
 dbs=$(for n in lm_fetch lm_write lm_insts lm_busy; do find $ev/p_$n -name "*.db" | head -1; done)
 python3 tools/pmc_lm_json.py $ev/pmc_lm_loop.json 8192 $dbs > /dev/null && cp $ev/pmc_lm_loop.json profiles/pmc_lm_loop.json
 timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
+timeout 300 python3 bench.py --host-clouds --no-cpu-baseline --no-diagnostics > $ev/bench_host_clouds.json 2> /dev/null   # the PCIe-inclusive rate
 # the reference's optimiser on the C4 shard (bench.py --kind loop --optimizer lm): the JSON line, its kernel table, its streams
 timeout 600 python3 bench.py --kind loop --optimizer lm --no-cpu-baseline > $ev/bench_lm_loop.json 2> $ev/bench_lm.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $ev/ks_lm -o k -- python3 bench.py --kind loop --optimizer lm --no-cpu-baseline --repeats 3 > /dev/null 2> $ev/ks_lm.err
