@@ -58,12 +58,24 @@ class LoopVerifierHip {
     if (candidates.empty()) return 0;  // :388-390
     int rc = apdgicp_batch_clear(batch_);
     if (rc < 0) return rc;
-    const int tgt = apdgicp_batch_add_cloud(batch_, new_keyframe.xyz, new_keyframe.n, new_keyframe.stride_bytes, 0);  // setInputTarget(new_keyframe->cloud), :392
-    if (tgt < 0) return tgt;
     const int64_t n = (int64_t)candidates.size();
+    // cloud 0 = the new keyframe (setInputTarget(new_keyframe->cloud), :392), clouds 1 .. n = the candidates.  With one row stride
+    // (the usual case: every cloud a pcl::PointCloud<PointT>) all of them go over in ONE call -- packed by the library's host
+    // threads into one pinned region, one copy -- instead of n + 1 clouds read over PCIe one by one.
+    bool one_stride = true;
+    for (const LoopCloud& c : candidates) one_stride &= c.stride_bytes == new_keyframe.stride_bytes;
+    if (one_stride) {
+      std::vector<const float*> ptrs((size_t)n + 1);
+      std::vector<int64_t> ns((size_t)n + 1);
+      ptrs[0] = new_keyframe.xyz, ns[0] = new_keyframe.n;
+      for (int64_t i = 0; i < n; i++) ptrs[(size_t)i + 1] = candidates[(size_t)i].xyz, ns[(size_t)i + 1] = candidates[(size_t)i].n;
+      if ((rc = apdgicp_batch_set_clouds(batch_, 0, (int32_t)(n + 1), ptrs.data(), ns.data(), new_keyframe.stride_bytes, 0)) < 0) return rc;
+    }
+    const int tgt = one_stride ? 0 : apdgicp_batch_add_cloud(batch_, new_keyframe.xyz, new_keyframe.n, new_keyframe.stride_bytes, 0);
+    if (tgt < 0) return tgt;
     std::vector<apdgicp_pair> pairs((size_t)n);
     for (int64_t i = 0; i < n; i++) {
-      const int src = apdgicp_batch_add_cloud(batch_, candidates[(size_t)i].xyz, candidates[(size_t)i].n, candidates[(size_t)i].stride_bytes, 0);
+      const int src = one_stride ? (int)i + 1 : apdgicp_batch_add_cloud(batch_, candidates[(size_t)i].xyz, candidates[(size_t)i].n, candidates[(size_t)i].stride_bytes, 0);
       if (src < 0) return src;
       pairs[(size_t)i].source_cloud = src, pairs[(size_t)i].target_cloud = tgt;
       if (guesses) {

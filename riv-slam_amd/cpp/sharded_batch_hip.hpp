@@ -344,12 +344,13 @@ class ShardedBatchAlignerHip {
       }
       base = (int)(job.seq % (uint64_t)slots_) * k.cloud_cap;
     }
-    const bool all_dev = std::all_of(job.clouds.begin(), job.clouds.end(), [&](const ShardCloud& c) { return c.on_device && c.stride_bytes == job.clouds[0].stride_bytes; });
+    const bool uniform = std::all_of(job.clouds.begin(), job.clouds.end(),
+                                     [&](const ShardCloud& c) { return c.on_device == job.clouds[0].on_device && c.stride_bytes == job.clouds[0].stride_bytes; });
     int rc = 0;
-    if (all_dev) {  // one pack launch for the whole block
+    if (uniform) {  // the whole block in one call: device clouds one pack launch; host clouds (PCL) packed by the library's host threads, ONE copy
       k.ptrs.resize(job.clouds.size()), k.ns.resize(job.clouds.size());
       for (size_t c = 0; c < job.clouds.size(); c++) k.ptrs[c] = job.clouds[c].xyz, k.ns[c] = job.clouds[c].n;
-      if ((rc = apdgicp_batch_set_clouds(b, base, (int)job.clouds.size(), k.ptrs.data(), k.ns.data(), job.clouds[0].stride_bytes, 1)) < 0)
+      if ((rc = apdgicp_batch_set_clouds(b, base, (int)job.clouds.size(), k.ptrs.data(), k.ns.data(), job.clouds[0].stride_bytes, job.clouds[0].on_device ? 1 : 0)) < 0)
         return fail(rc, "apdgicp_batch_set_clouds");
     } else {
       for (size_t c = 0; c < job.clouds.size(); c++)

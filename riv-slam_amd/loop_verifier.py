@@ -28,10 +28,15 @@ def verify_candidates(batch, target_cloud, candidate_clouds, guesses=None, fitne
     worse than the best so far; reject the loop when best_score > fitness_score_thresh (:431)."""
     reg = __import__("importlib").import_module("riv-slam_amd.registration")
     batch.clear()
-    tgt = batch.add_cloud(target_cloud)
-    srcs = [batch.add_cloud(c) for c in candidate_clouds]
-    if not srcs:
+    if not len(candidate_clouds):
         return None, np.zeros(0), None
+    try:    # all clouds in ONE call (host clouds: packed by the library's host threads, one copy; device clouds: one pack launch)
+        batch.set_clouds(0, [target_cloud, *candidate_clouds])
+        tgt, srcs = 0, list(range(1, len(candidate_clouds) + 1))
+    except ValueError:   # mixed strides / memory spaces: one by one
+        batch.clear()
+        tgt = batch.add_cloud(target_cloud)
+        srcs = [batch.add_cloud(c) for c in candidate_clouds]
     pairs = batch.make_pairs([(s, tgt) for s in srcs], guesses)
     results = batch.align(pairs)
     scores, _ = batch.fitness(pairs, None, fitness_score_max_range)
