@@ -12,7 +12,7 @@
 if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
   for f in kernel_stats.md kernel_stats_lm_loop.md knob_matrix.txt pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
-           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json; do
+           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json fuzz_batch.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json; do
     [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
   done
   for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
@@ -72,6 +72,7 @@ timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep.json 2> $ev/parity_sweep.err
 XF_FLAGS=2 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep_xflin.json 2>> $ev/parity_sweep.err
 timeout 500 python3 tests/measure/fuzz_parity.py 300 0 > $ev/fuzz_parity.json 2> $ev/fuzz_parity.err
+timeout 400 python3 tests/measure/fuzz_batch.py 240 0 > $ev/fuzz_batch.json 2> $ev/fuzz_batch.err
 for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ $ev/p_lm_fetch $ev/p_lm_write $ev/p_lm_insts $ev/p_lm_busy $ev/ks_lm; do rm -rf $d; done
 find $ev/ks -type f ! -name "*.db" -delete
 head -c 1500 $ev/bench.json; echo
