@@ -41,7 +41,7 @@ typedef enum {
   APDGICP_ERR_HIP = -2,           /* a HIP runtime call failed (no device, OOM, launch failure) */
   APDGICP_ERR_NO_INPUT = -3,      /* source/target (or correspondences) not set yet */
   APDGICP_ERR_TOO_FEW_POINTS = -4,/* cloud has fewer than k_correspondences points (reference: UB, A:318-321) */
-  APDGICP_ERR_UNSUPPORTED = -5,   /* e.g. k_correspondences > 64, unknown regularization (reference aborts, A:341-343) */
+  APDGICP_ERR_UNSUPPORTED = -5,   /* e.g. unknown regularization (reference aborts, A:341-343) */
   APDGICP_ERR_INTERNAL = -6
 } apdgicp_status;
 
@@ -73,7 +73,7 @@ typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
  * defaults: A:14-28, H:107-109, L:11-24.  The ROS factory overrides some of them
  * (registrations.cpp:41-48). */
 typedef struct {
-  int32_t k_correspondences;            /* setCorrespondenceRandomness, A:45 ; default 20 ; 1..64 (33..64: exact, through the brute-force covariance kernel) */
+  int32_t k_correspondences;            /* setCorrespondenceRandomness, A:45 ; default 20 ; any k >= 1, exact: 1..32 the pruned kernel, 33..64 the brute-force one, above a selection kernel (~35 sweeps of the cloud per query block: experiments) */
   int32_t max_iterations;               /* pcl setMaximumIterations ; default 64, L:13 */
   int32_t lm_max_iterations;            /* L:19 ; default 10 */
   int32_t optimizer;                    /* apdgicp_optimizer ; default LM */

@@ -393,8 +393,7 @@ class Engine {
 
   int set_params(const apdgicp_params* p) {
     if (!p) return fail(APDGICP_ERR_INVALID_ARG, "params is null");
-    if (p->k_correspondences < 1 || p->k_correspondences > 2 * KNN_NC)
-      return fail(APDGICP_ERR_UNSUPPORTED, "k_correspondences must be in [1, 64]");
+    if (p->k_correspondences < 1) return fail(APDGICP_ERR_INVALID_ARG, "k_correspondences must be >= 1");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
     if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
@@ -922,7 +921,10 @@ class Engine {
     int nmax = 0;
     long long total = 0;
     for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
-    if (knn_pruned && params.k_correspondences <= KNN_NC) {
+    if (params.k_correspondences > 2 * KNN_NC) {  // any k: selection by bisection, no lists (for experiments: ~35 sweeps of the cloud per query block)
+      hipLaunchKernelGGL(k_knn_cov_select, dim3((unsigned)((nmax + SEL_Q - 1) / SEL_Q), (unsigned)count), dim3(64), 0, st, d_desc.as<CloudDesc>(), d_list,
+                         params.k_correspondences, params.regularization, d_errflag.as<int>());
+    } else if (knn_pruned && params.k_correspondences <= KNN_NC) {
       // queries per wave = 64 / lanes per query: fewer queries per wave shorten the per-wave dependency chain and shrink its LDS
       // lists, which wins whenever the GPU is not already full (r01, 2 clouds of 8k: 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16)
       const int qpw = total >= 100000 ? 16 : total >= 40000 ? 8 : 4;

@@ -520,6 +520,151 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_knn_cov_select: calculate_covariances for ANY k (the reference takes any k, A:45-47; it ships 20).  One wave owns SEL_Q
+// consecutive sorted queries and keeps no list: the k-th smallest key (distance bits, original index) is found by bisection -- on the
+// bits of the fp32 distance, then, only when several points share the k-th distance and not all of them fit, on the original
+// index -- every probe ONE sweep of the cloud counting the keys at or below it; a last sweep adds up the moments of the keys at or
+// below the k-th.  About 35 sweeps of the cloud per SEL_Q queries: for experiments with k = 65 ... n, not for 10 Hz.  Exact, and
+// in the (distance, original index) order of every other covariance kernel; the sums run in curve order (compared by tolerance).
+constexpr int SEL_Q = 4;
+__global__ __launch_bounds__(64) void k_knn_cov_select(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag) {
+  const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
+  const int n = c.n, lane = threadIdx.x;
+  const int i0 = (int)blockIdx.x * SEL_Q;
+  if (i0 >= n) return;
+  const float4* pts = G(c.pts);
+  float qx[SEL_Q], qy[SEL_Q], qz[SEL_Q];
+#pragma unroll
+  for (int u = 0; u < SEL_Q; u++) {
+    const float4 q = pts[min(i0 + u, n - 1)];
+    qx[u] = q.x, qy[u] = q.y, qz[u] = q.z;
+  }
+  auto wave_sum_i = [](int v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  // D[u]: the smallest distance with at least k points at or below it (distances are finite and >= 0: their bits order like the values)
+  unsigned lo[SEL_Q], hi[SEL_Q];
+#pragma unroll
+  for (int u = 0; u < SEL_Q; u++) lo[u] = 0u, hi[u] = 0x7F800000u;
+  for (int it = 0; it < 32; it++) {
+    unsigned mid[SEL_Q];
+    bool open = false;
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1), open |= lo[u] < hi[u];
+    if (!open) break;
+    int cnt[SEL_Q];
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) cnt[u] = 0;
+    for (int j = lane; j < n; j += 64) {
+      const float4 t = pts[j];
+#pragma unroll
+      for (int u = 0; u < SEL_Q; u++) cnt[u] += __float_as_uint(sqdist1(t.x, t.y, t.z, qx[u], qy[u], qz[u])) <= mid[u] ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) {
+      const int tot = wave_sum_i(cnt[u]);
+      if (lo[u] < hi[u]) {
+        if (tot >= k) hi[u] = mid[u];
+        else lo[u] = mid[u] + 1u;
+      }
+    }
+  }
+  // how many lie strictly below D, how many at D: all of the latter belong to the answer unless more than k - below share D
+  int need[SEL_Q];
+  unsigned ilo[SEL_Q], ihi[SEL_Q];
+  bool surplus = false;
+  {
+    int clt[SEL_Q], ceq[SEL_Q];
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) clt[u] = 0, ceq[u] = 0;
+    for (int j = lane; j < n; j += 64) {
+      const float4 t = pts[j];
+#pragma unroll
+      for (int u = 0; u < SEL_Q; u++) {
+        const unsigned d = __float_as_uint(sqdist1(t.x, t.y, t.z, qx[u], qy[u], qz[u]));
+        clt[u] += d < hi[u] ? 1 : 0, ceq[u] += d == hi[u] ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) {
+      const int lt = wave_sum_i(clt[u]), eq = wave_sum_i(ceq[u]);
+      need[u] = k - lt;
+      ilo[u] = 0u, ihi[u] = 0x7FFFFFFFu;
+      if (eq > need[u]) surplus = true;
+      else ilo[u] = ihi[u];  // every point at D is taken
+    }
+  }
+  if (surplus) {  // (uniform) I[u]: the smallest original index with `need` points at D at or below it
+    for (int it = 0; it < 32; it++) {
+      unsigned mid[SEL_Q];
+      bool open = false;
+#pragma unroll
+      for (int u = 0; u < SEL_Q; u++) mid[u] = ilo[u] + ((ihi[u] - ilo[u]) >> 1), open |= ilo[u] < ihi[u];
+      if (!open) break;
+      int cnt[SEL_Q];
+#pragma unroll
+      for (int u = 0; u < SEL_Q; u++) cnt[u] = 0;
+      for (int j = lane; j < n; j += 64) {
+        const float4 t = pts[j];
+#pragma unroll
+        for (int u = 0; u < SEL_Q; u++)
+          cnt[u] += (__float_as_uint(sqdist1(t.x, t.y, t.z, qx[u], qy[u], qz[u])) == hi[u] && __float_as_uint(t.w) <= mid[u]) ? 1 : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < SEL_Q; u++) {
+        const int tot = wave_sum_i(cnt[u]);
+        if (ilo[u] < ihi[u]) {
+          if (tot >= need[u]) ihi[u] = mid[u];
+          else ilo[u] = mid[u] + 1u;
+        }
+      }
+    }
+  }
+  // moments of the k points, relative to the query (exact differences)
+  Mom9 mp[SEL_Q];
+  int taken[SEL_Q];
+#pragma unroll
+  for (int u = 0; u < SEL_Q; u++) taken[u] = 0;
+  for (int j = lane; j < n; j += 64) {
+    const float4 t = pts[j];
+#pragma unroll
+    for (int u = 0; u < SEL_Q; u++) {
+      const unsigned d = __float_as_uint(sqdist1(t.x, t.y, t.z, qx[u], qy[u], qz[u]));
+      if (d < hi[u] || (d == hi[u] && __float_as_uint(t.w) <= ihi[u])) {
+        mp[u].add((double)t.x - (double)qx[u], (double)t.y - (double)qy[u], (double)t.z - (double)qz[u]);
+        taken[u]++;
+      }
+    }
+  }
+  auto wave_sum_d = [](double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int u = 0; u < SEL_Q; u++) {
+    const int i = i0 + u;
+    const int tot = wave_sum_i(taken[u]);
+    const double s1x = wave_sum_d(mp[u].s1x), s1y = wave_sum_d(mp[u].s1y), s1z = wave_sum_d(mp[u].s1z);
+    const double sxx = wave_sum_d(mp[u].sxx), sxy = wave_sum_d(mp[u].sxy), sxz = wave_sum_d(mp[u].sxz);
+    const double syy = wave_sum_d(mp[u].syy), syz = wave_sum_d(mp[u].syz), szz = wave_sum_d(mp[u].szz);
+    if (i >= n || lane != 0) continue;
+    if (tot != k) atomicExch(err_flag, 2);  // (cannot happen for k <= n)
+    const double ik = 1.0 / (double)k;
+    const double mx = s1x * ik, my = s1y * ik, mz = s1z * ik;
+    Sym3 pc;
+    pc.xx = sxx * ik - mx * mx, pc.xy = sxy * ik - mx * my, pc.xz = sxz * ik - mx * mz;
+    pc.yy = syy * ik - my * my, pc.yz = syz * ik - my * mz, pc.zz = szz * ik - mz * mz;
+    Sym3 out;
+    if (!regularize_cov(reg, pc, out)) atomicExch(err_flag, 3);
+    double* cov = c.cov;
+    cov[i] = out.xx, cov[n + i] = out.xy, cov[2 * n + i] = out.xz, cov[3 * n + i] = out.yy, cov[4 * n + i] = out.yz, cov[5 * n + i] = out.zz;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // k_nn_partial: brute-force nearest neighbour of T*p_i in the target (A:149-153), exact fp32
 // difference form.  grid = (source blocks, target splits, pairs); block = 256 lanes, S sources per
 // lane held as packed float2 registers so the distance math issues as v_pk_{add,mul}_f32.

@@ -88,6 +88,27 @@ def test_cov_k_beyond_32_at_scan_and_submap_sizes(reg, scene, n, k):
     assert np.abs(g.getSourceCovariances()[:, :3, :3] - o.covariances("source")).max() <= 1e-10
 
 
+@pytest.mark.parametrize("n,k,mode", ((4000, 65, 0), (4000, 128, 3), (8192, 100, 3), (300, 200, 1), (66, 66, 0), (1001, 1000, 2)))
+def test_cov_any_k_above_64(reg, scene, n, k, mode):
+    """k > 64 (the reference takes any k, A:45-47): the selection kernel -- the k-th key by bisection, no lists -- against the oracle;
+    with duplicated points the (distance, original index) rule decides which copies belong to the k."""
+    src, _, _, _ = scene.make_pair(n, 32, scene.pair_seed(7, 3 * n + k), "odometry")
+    if n == 4000:
+        src[1::3] = src[0:-1:3][: len(src[1::3])]      # a third of the points twice: ties at the k-th distance
+    g = reg.FastAPDGICP(reg.default_params(k_correspondences=k, regularization=mode))
+    g.setInputSource(src)
+    o = R.RefAPDGICP(R.default_params(k_correspondences=k, regularization=mode))
+    o.setInputSource(src)
+    co = o.covariances("source")
+    assert np.abs(g.getSourceCovariances()[:, :3, :3] - co).max() <= 1e-10 * max(1.0, np.abs(co).max())
+    if n == 8192:   # and a whole registration with it
+        s2, t2, _, guess = scene.make_pair(2000, 2500, scene.pair_seed(7, 99), "odometry")
+        g2, o2 = both(reg, s2, t2, k_correspondences=k, max_correspondence_distance=2.0)
+        T, To = g2.align(guess), o2.align(guess)
+        te, re_ = scene.pose_error(To, T)
+        assert te <= T_TOL and re_ <= R_TOL and info_of(g2) == [int(o2.converged), o2.nr_iterations, o2.n_linearize, o2.n_compute_error]
+
+
 @pytest.mark.parametrize("n", (2000, 8192))   # (8192: host clouds read by the sort from pinned memory, bounding box from the host)
 def test_non_finite_points_fail_loudly(reg, scene, n):
     """The preprocessing nodelet removes NaNs before registration (preprocessing_nodelet.cpp); a cloud that still carries
@@ -426,9 +447,14 @@ def test_errors_are_codes_not_crashes(reg, golden):
         g.align(None)
     assert e.value.code == -4
     with pytest.raises(reg.ApdgicpError) as e:
-        g.setCorrespondenceRandomness(65)
-    assert e.value.code == -5
+        g.setCorrespondenceRandomness(0)
+    assert e.value.code == -1
     g.params.k_correspondences = 20
+    g.setCorrespondenceRandomness(101)            # any k is accepted (A:45-47) ...
+    with pytest.raises(reg.ApdgicpError) as e:    # ... and a cloud with fewer points than k is an error code, as for k = 20
+        g.align(None)
+    assert e.value.code == -4
+    g.setCorrespondenceRandomness(20)
     with pytest.raises(reg.ApdgicpError):
         g.setRegularizationMethod(9)
     with pytest.raises(reg.ApdgicpError):
