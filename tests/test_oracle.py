@@ -37,7 +37,7 @@ def test_kdtree_equals_bruteforce(golden):
     rng = np.random.default_rng(3)
     qs = np.concatenate([cloud[rng.integers(0, len(cloud), 64)], rng.uniform(-5, 100, size=(64, 3)).astype(np.float32)])
     d = O.sqdist_f32(qs, cloud)
-    for k in (1, 20):
+    for k in (1, 20, 70, 200):   # (k > 64: the product's selection kernel is held against this)
         want = np.argsort(d, axis=1, kind="stable")[:, :k]
         for i, q in enumerate(qs):
             idx, dist = r.knn_kdtree("target", q, k)
