@@ -118,7 +118,9 @@ def load_pmc(path=None, stamp=None):
     except Exception as e:  # noqa: BLE001
         return None, f"{os.path.relpath(path, ROOT)}: {type(e).__name__}"
     if stamp is None:
-        stamp = importlib.import_module("riv-slam_amd.build").source_stamp()
+        # the stamp compiled into the library this process loaded (apdgicp_source_stamp) -- which the loader has already compared
+        # with the sources on disk (registration.load_library refuses a library built from other sources)
+        stamp = importlib.import_module("riv-slam_amd.registration").source_stamp()
     have = pmc.get("source_stamp")
     if have != stamp:
         return None, (f"{os.path.relpath(path, ROOT)} was collected from kernel sources {have or '(unstamped)'}, this run is built from {stamp}: "
@@ -470,6 +472,7 @@ def main():
                                  "`traffic` (PMC, committed profile of the same sources) also carries the warm-start hints and neighbour-keeping records: see traffic_over_algorithmic"},
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
+            "library_source_stamp": importlib.import_module("riv-slam_amd.registration").source_stamp(),
             "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_lm_loop.json" if lm else "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,

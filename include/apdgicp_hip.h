@@ -32,8 +32,10 @@
 extern "C" {
 #endif
 
-#define APDGICP_ABI_VERSION 4   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots;
-                                   4: T*p is summed pairwise by default (Eigen >= 3.3), APDGICP_FLAG_XF_LINEAR_CHAIN selects the former order */
+#define APDGICP_ABI_VERSION 5   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots;
+                                   4: T*p is summed pairwise by default (Eigen >= 3.3), APDGICP_FLAG_XF_LINEAR_CHAIN selects the former order;
+                                   5: the three fp32 angles of the sensor model (A:168,172-173) through glibc's atan2f algorithm (apd_atan2f.h) instead of the
+                                      device library's; + source_stamp, set_trace / get_trace, debug_atan2f */
 
 typedef enum {
   APDGICP_OK = 0,
@@ -108,6 +110,11 @@ enum { APDGICP_SOURCE = 0, APDGICP_TARGET = 1 };
 
 /* ------------------------------------------------------------------ library */
 int apdgicp_abi_version(void);
+/* Fingerprint of the kernel sources this library was compiled from (riv-slam_amd/build.py:source_stamp(), the first 16 hex digits
+ * of a SHA-256 over csrc/ and include/, passed in at compile time): what bench.py and the test suite compare with the sources on
+ * disk before they trust a prebuilt library, and what a committed counter profile names.  "unstamped" for a build that did not
+ * go through build.py. */
+const char* apdgicp_source_stamp(void);
 const char* apdgicp_last_error(void);
 int apdgicp_device_count(int* count);
 void apdgicp_default_params(apdgicp_params* p);                                  /* A:14-28, L:11-24 */
@@ -159,6 +166,18 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
  * like the reference's virtual calls (L:127-173): the bit-faithful debug path */
 int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_result* out);
 int apdgicp_get_final_hessian(apdgicp_handle* h, double H[36]);                   /* getFinalHessian, L:45 */
+/* Debug: the optimiser's per-iteration trace, as a debugger stepping through L:64-76 / L:127-173 would write it down.  With
+ * tracing enabled every apdgicp_align (the device state machine writes the trace itself) and apdgicp_align_host_loop of this
+ * handle records, per Levenberg-Marquardt trial, the lambda the step was solved with, its gain ratio rho and the two costs rho
+ * compares (L:137-146: y0 of linearize, yi of compute_error at the trial pose; y0s / yis may be NULL) and, per completed outer
+ * iteration, the pose x0 behind it (L:119 / L:166; column-major 4x4 doubles).  get_trace returns the counts of the last align
+ * (they may exceed the capacities given: only what fits is copied).  Gauss-Newton runs record poses only. */
+int apdgicp_set_trace(apdgicp_handle* h, int enable);
+int apdgicp_get_trace(apdgicp_handle* h, int64_t trial_capacity, double* lambdas, double* rhos, double* y0s, double* yis, int64_t* n_trials,
+                      int64_t pose_capacity, double* poses16, int64_t* n_poses);
+/* Debug: out[i] = atan2f(y[i], x[i]) as the kernels evaluate it on `device` (include/apd_atan2f.h: glibc's generic atan2f restated;
+ * A:168,172-173 call the C library's float overload); host arrays.  For the bit-for-bit comparison with the host's evaluation. */
+int apdgicp_debug_atan2f(int device, const float* y, const float* x, float* out, int64_t n);
 /* pcl::transformPointCloud(*input_, output, final_transformation_) (L:79): writes n xyz triples
  * `out_stride_bytes` apart into host memory */
 int apdgicp_transform_source(apdgicp_handle* h, const float T[16], float* out_xyz, int64_t n, int64_t out_stride_bytes);

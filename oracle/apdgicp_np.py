@@ -105,6 +105,72 @@ def knn(cloud: np.ndarray, k: int, chunk: int = 512) -> np.ndarray:
     return out
 
 
+# ----------------------------------------------------------------------------- fp32 atan2 (the C library's)
+def _f32(v):
+    return np.asarray(v, dtype=F32)
+
+
+def atanf_fdlibm(x: np.ndarray) -> np.ndarray:
+    """glibc's generic flt-32 atanf (fdlibm s_atanf.c) on an fp32 array, every operation in fp32 in the published order:
+    reduction to one of five intervals (|x| < 7/16, < 11/16, < 19/16, < 39/16, above), atan(c) as hi + lo for c = 0.5, 1, 1.5, inf,
+    odd polynomial of degree 23 split into even and odd powers.  A second, independent writing of include/apd_atan2f.h
+    (tests/test_atan2f.py compares the two, and both with the C library, bit for bit)."""
+    x = _f32(x)
+    ix = x.view(np.int32) & 0x7FFFFFFF
+    neg = x.view(np.int32) < 0
+    ax = np.abs(x)
+    hi = _f32([4.6364760399e-01, 7.8539812565e-01, 9.8279368877e-01, 1.5707962513e+00])
+    lo = _f32([5.0121582440e-09, 3.7748947079e-08, 3.4473217170e-08, 7.5497894159e-08])
+    aT = _f32([3.3333334327e-01, -2.0000000298e-01, 1.4285714924e-01, -1.1111110449e-01, 9.0908870101e-02, -7.6918758452e-02,
+               6.6610731184e-02, -5.8335702866e-02, 4.9768779427e-02, -3.6531571299e-02, 1.6285819933e-02])
+    one, two, onep5 = F32(1.0), F32(2.0), F32(1.5)
+    idn = np.where(ix < 0x3EE00000, -1, np.where(ix < 0x3F300000, 0, np.where(ix < 0x3F980000, 1, np.where(ix < 0x401C0000, 2, 3))))
+    with np.errstate(all="ignore"):
+        r = np.where(idn == -1, x,
+                     np.where(idn == 0, (two * ax - one) / (two + ax),
+                              np.where(idn == 1, (ax - one) / (ax + one),
+                                       np.where(idn == 2, (ax - onep5) / (one + onep5 * ax), -one / ax)))).astype(F32)
+        z = r * r
+        w = z * z
+        s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))))
+        s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))))
+        small = r - r * (s1 + s2)
+        k = np.clip(idn, 0, 3)
+        big = hi[k] - ((r * (s1 + s2) - lo[k]) - r)
+        out = np.where(idn < 0, small, np.where(neg, -big, big)).astype(F32)
+        out = np.where(ix < 0x31000000, x, out)                                   # |x| < 2^-29
+        huge = np.where(neg, -hi[3] - lo[3], hi[3] + lo[3]).astype(F32)
+        out = np.where(ix >= 0x4C000000, np.where(ix > 0x7F800000, x + x, huge), out)  # |x| >= 2^25, NaN
+    return out.astype(F32)
+
+
+def atan2f_fdlibm(y: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """glibc's generic flt-32 atan2f (fdlibm e_atan2f.c): what `atan2(float, float)` is at fast_apdgicp_impl.hpp:168,172-173 on
+    the platforms the reference names (glibc 2.27 / 2.31)."""
+    y, x = np.broadcast_arrays(_f32(y), _f32(x))
+    y, x = np.ascontiguousarray(y), np.ascontiguousarray(x)
+    hx, hy = x.view(np.int32), y.view(np.int32)
+    ix, iy = hx & 0x7FFFFFFF, hy & 0x7FFFFFFF
+    pi_o_4, pi_o_2, pi, pi_lo = F32(7.8539818525e-01), F32(1.5707963705e+00), F32(3.1415927410e+00), F32(-8.7422776573e-08)
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2)
+    k = (iy - ix) >> 23
+    with np.errstate(all="ignore"):
+        z = atanf_fdlibm(np.abs(y / x))
+        z = np.where(k > 60, pi_o_2 + F32(0.5) * pi_lo, np.where((hx < 0) & (k < -60), F32(0.0), z)).astype(F32)
+        out = np.where(m == 0, z, np.where(m == 1, -z, np.where(m == 2, pi - (z - pi_lo), (z - pi_lo) - pi))).astype(F32)
+        # special cases, in the order of the original (the later line wins here, so they are applied last to first)
+        y_inf = np.where(hy < 0, -pi_o_2, pi_o_2)
+        out = np.where(iy == 0x7F800000, y_inf, out)
+        x_inf_y_inf = np.where(m == 0, pi_o_4, np.where(m == 1, -pi_o_4, np.where(m == 2, F32(3.0) * pi_o_4, F32(-3.0) * pi_o_4)))
+        x_inf = np.where(m == 0, F32(0.0), np.where(m == 1, F32(-0.0), np.where(m == 2, pi, -pi)))
+        out = np.where(ix == 0x7F800000, np.where(iy == 0x7F800000, x_inf_y_inf, x_inf), out)
+        out = np.where(ix == 0, np.where(hy < 0, -pi_o_2, pi_o_2), out)
+        out = np.where(iy == 0, np.where(m < 2, y, np.where(m == 2, pi, -pi)), out)
+        out = np.where(hx == 0x3F800000, atanf_fdlibm(y), out)
+        out = np.where((ix > 0x7F800000) | (iy > 0x7F800000), x + y, out)
+    return out.astype(F32)
+
+
 # ----------------------------------------------------------------------------- covariances
 def calculate_covariances(cloud: np.ndarray, k: int = 20, regularization: int = REG_PLANE) -> np.ndarray:
     """gicp/impl/fast_apdgicp_impl.hpp:303-363.  Returns [n,3,3] fp64 (top-left block of the
@@ -221,18 +287,22 @@ class FastAPDGICP:
         R = np.asarray(T, dtype=np.float64)[:3, :3]
         sin_az = math.sin(p.azimuth_variance_deg / 180 * math.pi)
         sin_el = math.sin(p.elevation_variance_deg / 180 * math.pi)
+        # the three angles (:168,172-173): float overloads of atan2 / sqrt on fp32 members -- the C library's atan2f, restated
+        px, py, pz = pt[:, 0], pt[:, 1], pt[:, 2]
+        aoa_f = atan2f_fdlibm(px, np.sqrt(py * py + pz * pz))
+        elev_f = atan2f_fdlibm(np.sqrt(px * px + py * py), pz)
+        azim_f = atan2f_fdlibm(py, px)
         for i in range(n):
             j = corr[i]
             if j < 0:
                 continue
-            x, y, z = pt[i, 0], pt[i, 1], pt[i, 2]               # fp32 scalars
             dist = float(np.linalg.norm(pt[i].astype(np.float64)))            # :167
-            aoa = float(np.arctan2(x, np.sqrt(y * y + z * z)))               # :168 (float overloads)
+            aoa = float(aoa_f[i])                                              # :168 (float overloads)
             s_x = dist * p.distance_variance / 400                             # :169
             s_y = dist * sin_az / math.cos(aoa)                                # :170
             s_z = dist * sin_el / math.cos(aoa)                                # :171
-            elevation = float(np.arctan2(np.sqrt(x * x + y * y), z))          # :172
-            azimuth = float(np.arctan2(y, x))                                  # :173
+            elevation = float(elev_f[i])                                       # :172
+            azimuth = float(azim_f[i])                                         # :173
             ce, se = math.cos(elevation), math.sin(elevation)
             ca, sa = math.cos(azimuth), math.sin(azimuth)
             Ry = np.array([[ce, 0, se], [0, 1, 0], [-se, 0, ce]])

@@ -34,6 +34,10 @@
 #include <omp.h>
 #endif
 
+// glibc's generic atan2f (fdlibm) restated once for kernels and checker: with the C library's own atan2f the checker's angles
+// (A:168,172-173) would be those of whatever libm the TEST box has.  tests/test_atan2f.py pins the header bit for bit to glibc.
+#include "../include/apd_atan2f.h"
+
 namespace {
 
 struct RefParams {  // independent mirror of include/apdgicp_hip.h:apdgicp_params
@@ -329,6 +333,9 @@ struct Ref {
   double lm_lambda = -1.0;
   double final_hessian[36];
   int n_linearize = 0, n_compute_error = 0;
+  // trace of the last align: per LM trial (L:136-164) the lambda it was solved with and its rho; per completed outer iteration
+  // (L:67-76) the pose x0 behind it (column-major 4x4)
+  std::vector<double> tr_lambda, tr_rho, tr_y0, tr_yi, tr_poses;
 };
 
 void ensure_tree(Cloud& c) {
@@ -468,12 +475,12 @@ void update_correspondences(Ref& r, const M4& T) {
     const M3& cov_A = r.src.covs[i];
     const M3& cov_B = r.tgt.covs[r.corr[i]];
     const double dist = std::sqrt((double)pt.x * pt.x + (double)pt.y * pt.y + (double)pt.z * pt.z);  // A:167
-    const double aoa = (double)atan2f(pt.x, sqrtf(pt.y * pt.y + pt.z * pt.z));   // A:168 float overloads
+    const double aoa = (double)apd::apd_atan2f(pt.x, sqrtf(pt.y * pt.y + pt.z * pt.z));   // A:168 float overloads
     const double s_x = dist * r.p.distance_variance / 400;                          // A:169
     const double s_y = dist * sin_az / std::cos(aoa);                               // A:170
     const double s_z = dist * sin_el / std::cos(aoa);                               // A:171
-    const double elevation = (double)atan2f(sqrtf(pt.x * pt.x + pt.y * pt.y), pt.z);  // A:172
-    const double azimuth = (double)atan2f(pt.y, pt.x);                               // A:173
+    const double elevation = (double)apd::apd_atan2f(sqrtf(pt.x * pt.x + pt.y * pt.y), pt.z);  // A:172
+    const double azimuth = (double)apd::apd_atan2f(pt.y, pt.x);                               // A:173
     const double ce = std::cos(elevation), se = std::sin(elevation);
     const double ca = std::cos(azimuth), sa = std::sin(azimuth);
     M3 Ry{{{ce, 0, se}, {0, 1, 0}, {-se, 0, ce}}};
@@ -626,6 +633,7 @@ bool step_lm(Ref& r, M4& x0, M4& delta) {
     double den = 0;
     for (int i = 0; i < 6; i++) den += d[i] * (r.lm_lambda * d[i] - b[i]);
     const double rho = (y0 - yi) / den;
+    r.tr_lambda.push_back(r.lm_lambda), r.tr_rho.push_back(rho), r.tr_y0.push_back(y0), r.tr_yi.push_back(yi);
     if (rho < 0) {
       if (is_converged(r, delta)) return true;
       r.lm_lambda = nu * r.lm_lambda;
@@ -743,12 +751,15 @@ int ref_align(void* h, const float* guess16, float* out_T16, int* out_info) {
   bool converged = false;
   int nr_iterations = 0;
   r->n_linearize = r->n_compute_error = 0;
+  r->tr_lambda.clear(), r->tr_rho.clear(), r->tr_y0.clear(), r->tr_yi.clear(), r->tr_poses.clear();
   for (int i = 0; i < r->p.max_iterations && !converged; i++) {  // L:67-76
     nr_iterations = i;
     M4 delta;
     const bool ok = r->p.optimizer == 1 ? step_gn(*r, x0, delta) : step_lm(*r, x0, delta);
     if (!ok) break;  // "lm not converged!!"
     converged = is_converged(*r, delta);
+    for (int c = 0; c < 4; c++)
+      for (int q = 0; q < 4; q++) r->tr_poses.push_back(x0.m[q][c]);
   }
   for (int i = 0; i < 4; i++)
     for (int j = 0; j < 4; j++) out_T16[i + 4 * j] = (float)x0.m[i][j];  // L:78
@@ -757,6 +768,22 @@ int ref_align(void* h, const float* guess16, float* out_T16, int* out_info) {
   out_info[2] = r->n_linearize;
   out_info[3] = r->n_compute_error;
   return 0;
+}
+// trace of the last ref_align: returns the number of LM trials; *n_poses the number of completed outer iterations.
+// lambdas / rhos / y0s / yis: room for max_iterations * lm_max_iterations doubles, poses16: max_iterations x 16 (any may be null)
+int ref_get_trace(void* h, double* lambdas, double* rhos, double* y0s, double* yis, double* poses16, int* n_poses) {
+  Ref* r = (Ref*)h;
+  if (lambdas) std::memcpy(lambdas, r->tr_lambda.data(), r->tr_lambda.size() * sizeof(double));
+  if (rhos) std::memcpy(rhos, r->tr_rho.data(), r->tr_rho.size() * sizeof(double));
+  if (y0s) std::memcpy(y0s, r->tr_y0.data(), r->tr_y0.size() * sizeof(double));
+  if (yis) std::memcpy(yis, r->tr_yi.data(), r->tr_yi.size() * sizeof(double));
+  if (poses16) std::memcpy(poses16, r->tr_poses.data(), r->tr_poses.size() * sizeof(double));
+  if (n_poses) *n_poses = (int)(r->tr_poses.size() / 16);
+  return (int)r->tr_lambda.size();
+}
+// the atan2f every angle of the sensor model goes through (include/apd_atan2f.h), for the tests
+void ref_atan2f(const float* y, const float* x, float* out, long long n) {
+  for (long long i = 0; i < n; i++) out[i] = apd::apd_atan2f(y[i], x[i]);
 }
 void ref_get_final_hessian(void* h, double* H36) { std::memcpy(H36, ((Ref*)h)->final_hessian, 36 * sizeof(double)); }
 

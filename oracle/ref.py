@@ -43,10 +43,10 @@ def default_params(**kw) -> RefParams:
 
 def build(force: bool = False) -> str:
     import fcntl
-    src = os.path.join(_HERE, "apdgicp_ref.cpp")
+    srcs = [os.path.join(_HERE, "apdgicp_ref.cpp"), os.path.join(_HERE, "..", "include", "apd_atan2f.h"), os.path.join(_HERE, "Makefile")]
 
     def stale():
-        return force or not os.path.exists(_LIB_PATH) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH))
+        return force or not os.path.exists(_LIB_PATH) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale():
         os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
         with open(_LIB_PATH + ".lock", "w") as lock:  # one builder at a time (bench.py: every rank of a node gets here)
@@ -83,6 +83,9 @@ def lib():
         L.ref_get_mahalanobis.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_get_final_hessian.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_atan2f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        L.ref_atan2f.restype = None
         L.ref_knn_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_knn_kdtree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_submap_assemble.restype = C.c_longlong
@@ -184,6 +187,17 @@ class RefAPDGICP:
         self.final_transformation = np.ascontiguousarray(out)
         return self.final_transformation
 
+    def trace(self):
+        """dict(lambda, rho, y0, yi, poses) of the last align: per LM trial the lambda it was solved with, its rho and the two costs
+        rho compares (L:137-146); per completed outer iteration the pose behind it ([n, 4, 4] row-major numpy)."""
+        cap = max(1, self.params.max_iterations) * max(1, self.params.lm_max_iterations)
+        lam, rho, y0, yi = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        poses = np.zeros((max(1, self.params.max_iterations), 16))
+        npo = C.c_int()
+        nt = self.L.ref_get_trace(self.h, _ptr(lam), _ptr(rho), _ptr(y0), _ptr(yi), _ptr(poses), C.byref(npo))
+        return {"lambda": lam[:nt].copy(), "rho": rho[:nt].copy(), "y0": y0[:nt].copy(), "yi": yi[:nt].copy(),
+                "poses": poses[:npo.value].reshape(-1, 4, 4).transpose(0, 2, 1).copy()}
+
     def final_hessian(self) -> np.ndarray:
         H = np.zeros((6, 6), order="F")
         self.L.ref_get_final_hessian(self.h, _ptr(H))
@@ -201,6 +215,15 @@ class RefAPDGICP:
         qq = np.ascontiguousarray(q, dtype=np.float32)
         n = self.L.ref_knn_kdtree(self.h, 0 if which == "source" else 1, _ptr(qq), k, _ptr(idx), _ptr(d))
         return idx[:n], d[:n]
+
+
+def atan2f(y, x) -> np.ndarray:
+    """include/apd_atan2f.h (the C library's fdlibm atan2f restated) on fp32 arrays."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(y)
+    lib().ref_atan2f(_ptr(y), _ptr(x), _ptr(out), y.size)
+    return out
 
 
 def submap_assemble(clouds, rel_poses=None, leaf=None):

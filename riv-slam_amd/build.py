@@ -9,28 +9,40 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libapdgicp_hip.so")
 SOURCES = ["apdgicp_hip.hip"]
-DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os.path.join("..", "..", "include", "apdgicp_hip.h")]  # every source the one translation unit includes
+INCLUDE = os.path.join(HERE, "..", "include")
+HEADERS = ["apdgicp_hip.h", "apd_atan2f.h"]  # include/: what the one translation unit includes from there
 FLAGS = [*os.environ.get("APD_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
 def source_stamp() -> str:
-    """Fingerprint of the kernel sources (csrc/*.hip, *.hpp): profiles/pmc_nn_latest.json carries the stamp of the sources its
-    counters were collected from (tools/pmc_nn_json.py), and bench.py reports PMC-derived numbers only when it equals this one."""
+    """Fingerprint of everything the library is compiled from (csrc/*.hip, *.hpp, the two headers under include/, the compiler
+    flags).  It is compiled INTO the library (apdgicp_source_stamp()): the loader, the test suite and bench.py compare the
+    loaded library's stamp with this one, and profiles/pmc_nn_latest.json carries the stamp of the library its counters were
+    collected from (tools/pmc_nn_json.py) -- bench.py reports PMC-derived numbers only when all three agree."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp")):
+    for d, names in ((CSRC, sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))), (INCLUDE, HEADERS)):
+        for f in names:
             h.update(f.encode() + b"\0")
-            with open(os.path.join(CSRC, f), "rb") as fh:
+            with open(os.path.join(d, f), "rb") as fh:
                 h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]
 
 
+def library_stamp(path: str = LIB) -> str | None:
+    """The stamp compiled into a built library, read from the file itself (no dlopen: the bytes behind the marker)."""
+    if not os.path.exists(path):
+        return None
+    import re
+    with open(path, "rb") as fh:
+        m = re.search(rb"apd-source-stamp:([0-9a-f]{16})", fh.read())
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS if os.path.exists(os.path.join(CSRC, d)))
+    """Identity, not age: the library is current when the stamp inside it equals the stamp of the sources on disk."""
+    return library_stamp() != source_stamp()
 
 
 def build(force: bool = False, verbose: bool = False, extra: list[str] | None = None) -> str:
@@ -45,7 +57,7 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
             if force or needs_build():  # (another process may have built it while this one waited)
                 hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
                 tmp = f"{LIB}.{os.getpid()}.tmp"
-                cmd = [hipcc, *FLAGS, *(extra or []), "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+                cmd = [hipcc, *FLAGS, f'-DAPD_SOURCE_STAMP="apd-source-stamp:{source_stamp()}"', *(extra or []), "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
                 if verbose:
                     print(" ".join(cmd), file=sys.stderr)
                 try:

@@ -349,7 +349,7 @@ class Engine {
     for (auto& c : clouds) c.release_all();
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_tilejobs[0], &d_tilejobs[1], &d_tilejobs[2], &d_active, &d_post}) t->dev.release();
     d_tkeys.release();
-    for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T,
+    for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T, &d_trace,
                       &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (bulk_host) e = hipHostFree(bulk_host);
@@ -1093,8 +1093,24 @@ class Engine {
   Span whole() const { return Span{0, npairs, stream}; }
   // what the tick launches run over: the batch set up by setup_pairs, or (inside pool_enqueue_chunk) the pair pool
   bool in_pool = false;
+  // debug trace of the optimiser (apdgicp_set_trace): single-registration handles only
+  bool trace_on = false;
+  DevBuf d_trace;
+  int trace_cap_trial = 0, trace_cap_pose = 0;
+  size_t trace_bytes() const { return 16 + ((size_t)4 * trace_cap_trial + (size_t)12 * trace_cap_pose) * sizeof(double); }
+  int trace_reset() {  // in front of an align: capacities from the current parameters, counts zero
+    if (!trace_on) return 0;
+    trace_cap_pose = std::max(1, params.max_iterations);
+    trace_cap_trial = trace_cap_pose * std::max(1, params.lm_max_iterations);
+    if (trace_bytes() > d_trace.cap) APD_HIP(hipStreamSynchronize(stream));
+    APD_TRY(d_trace.ensure(trace_bytes()));
+    const int hdr[4] = {0, 0, trace_cap_trial, trace_cap_pose};
+    APD_HIP(hipMemcpyAsync(d_trace.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+    return 0;
+  }
   Work t_work() const {
     Work w = in_pool ? pool.work : work;
+    w.trace = trace_on && !in_pool && npairs == 1 ? d_trace.as<double>() : nullptr;
     if (in_pool) w.active = pool.L[pool.cur].active.as<int>();
     w.xf_linear = (params.flags & APDGICP_FLAG_XF_LINEAR_CHAIN) ? 1 : 0;  // (read at launch time: set_params may come between aligns)
     return w;
@@ -1304,6 +1320,7 @@ class Engine {
   int run_align(bool defer_poll = false) {
     APD_HIP(hipSetDevice(device));
     APD_TRY(finish_align());  // (an uncollected deferred align of this slot)
+    APD_TRY(trace_reset());
     nn_events_used = 0;
     nn_pairs_acc = 0;
     cur_tick = 0;

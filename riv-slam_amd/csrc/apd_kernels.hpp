@@ -166,6 +166,7 @@ struct Work {
                                // (post_result).  Not in k_linearize: with the record code in its last block the register allocator
                                // moved that kernel's spills into the per-point pass (32.6 -> 45.0 us per batch launch)
   int post_seq;
+  double* trace;               // debug (apdgicp_set_trace; null otherwise): the optimiser's per-iteration trace of pair 0, see trace_trial
   const Rigid* init;           // non-null in the FIRST tick of an align (fused optimiser): the guesses, one pose per pair.  The
                                // search and the per-point pass take their pose from there and run cold, and the last block of
                                // k_linearize builds the pair's state from scratch (L:56-59) instead of loading it: no k_init_state launch
@@ -2256,6 +2257,12 @@ __device__ __forceinline__ Sym3 sym3_inverse_c(const Sym3& a) {  // sym3_inverse
   return r;
 }
 
+// the interval table of apd_atan2f (include/apd_atan2f.h) into the block's LDS: the first 40 threads, before a barrier
+__device__ __forceinline__ void atan_tab_to_lds(float* lds, int tid) {
+  static constexpr float init[APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE] = APD_ATAN_TAB_INIT;
+  if (tid < APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE) lds[tid] = init[tid];
+}
+
 // what one source point contributes to linearize (A:229-258); all zero without a correspondence
 struct LinPoint {
   Sym3 Mi;                    // RCR^-1, A:191
@@ -2270,7 +2277,8 @@ struct LinPoint {
 __device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
                                                 int pair, int i, const float4 p, float ptx, float pty, float ptz, float m, unsigned chunk,
                                                 bool tie, bool kept, const float4 tq_rec /* nnpt[i], read by the caller */,
-                                                const Sym3& cov_A /* the point's covariance, read by the caller */, LinPoint& lp) {
+                                                const Sym3& cov_A /* the point's covariance, read by the caller */, LinPoint& lp,
+                                                const float* atan_tab /* the block's LDS copy of apd_atan2f's interval table */) {
   const int M = tgt.n;
   int j = -1;
   float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);  // the neighbour itself
@@ -2314,11 +2322,17 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     // APD sensor-noise covariance from the transformed point (A:167-184)
     const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
     double aoa, elevation, azimuth;
-    {  // fp32, as the reference evaluates it (float overloads, no FMA): not contracted
+    {  // fp32, as the reference evaluates it (float overloads, no FMA): not contracted.  apd_atan2f is glibc's generic atan2f
+       // (fdlibm, include/apd_atan2f.h) restated: the device library's own atan2f is another ~1 ulp implementation
 #pragma clang fp contract(off)
-      aoa = (double)atan2f(ptx, sqrtf(pty * pty + ptz * ptz));
-      elevation = (double)atan2f(sqrtf(ptx * ptx + pty * pty), ptz);
-      azimuth = (double)atan2f(pty, ptx);
+#ifdef APD_OCML_ATAN2F  // (A/B builds only, tools/ab_bench.sh: what the restated atan2f costs against the device library's)
+#define APD_ATAN2F(y, x) atan2f(y, x)
+#else
+#define APD_ATAN2F(y, x) apd_atan2f_tab(y, x, atan_tab)
+#endif
+      aoa = (double)APD_ATAN2F(ptx, sqrtf(pty * pty + ptz * ptz));
+      elevation = (double)APD_ATAN2F(sqrtf(ptx * ptx + pty * pty), ptz);
+      azimuth = (double)APD_ATAN2F(pty, ptx);
     }
     double sin_aoa, cos_aoa;
     sincos_pi(aoa, &sin_aoa, &cos_aoa);
@@ -2424,8 +2438,8 @@ __device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int 
 constexpr int LIN_BLK = 256;
 constexpr int kSerialRows = 32;  // up to this many block rows (8192 points) the last block adds them one after the other
 
-__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws);
-__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws);
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws, double* tr);
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws, double* tr);
 __device__ __forceinline__ void fill_from_sums(PairState& s, const double* v);
 
 // Cross-block traffic inside one launch (the rows of partial sums, read by the last block of a pair) goes through
@@ -2494,6 +2508,9 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
   LinPoint lp;
   lp.Mi = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
+  __shared__ float s_atan[APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE];
+  atan_tab_to_lds(s_atan, tid);
+  __syncthreads();  // (every exit above is taken by the whole block)
 
   if (i < N) {
     // everything that depends on the point index alone is requested FIRST -- the point, its covariance, the neighbour on
@@ -2525,7 +2542,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     float Tf[12];
     load_Tf(T, Tf);
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), pty = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), ptz = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
-    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp);
+    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
   block_reduce_lds<29, LIN_BLK>([&](int r) { return lin_term(lp, want_Hb, r); }, red, red_scratch, tid);
@@ -2567,7 +2584,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
       if (tid == 0) {
         if (w.init) init_pair_state(ls, w.init + pair, cst.max_iterations);  // first tick: the state starts here
         fill_from_sums(ls, red);
-        lm_after_gather(ls, cst, red_scratch);  // (the reduction scratch is free by now)
+        lm_after_gather(ls, cst, red_scratch, pair == 0 ? w.trace : nullptr);  // (the reduction scratch is free by now)
       }
       __syncthreads();
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
@@ -2645,13 +2662,36 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&ls)[q] = ((const double*)&st[pair])[q];
       __syncthreads();
       if (tid == 0) {
-        lm_decide_after_sum(ls, s_yi, cst, s_ws);
+        lm_decide_after_sum(ls, s_yi, cst, s_ws, pair == 0 ? w.trace : nullptr);
         if (w.post) post_result(*w.post, w.post_seq, ls);
       }
       __syncthreads();
       for (int q = tid; q < (int)(sizeof(PairState) / 8); q += LIN_BLK) ((double*)&st[pair])[q] = ((const double*)&ls)[q];
     }
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Debug trace of the state machine (apdgicp_set_trace / apdgicp_get_trace; Work::trace, null in every product run): what a
+// debugger stepping through L:64-76 / L:127-173 would write down -- per LM trial the lambda it was solved with and its rho
+// and the two costs it compares (L:137-146: y0 from linearize, yi from compute_error at the trial pose), per completed outer
+// iteration the pose x0 behind it (L:119 / L:166).  Layout: {int n_trial, n_pose, cap_trial, cap_pose} (16 bytes),
+// lambda[cap_trial], rho[cap_trial], y0[cap_trial], yi[cap_trial], pose[cap_pose][12] (row-major 3x4).  Counts keep counting
+// past the capacity; only what fits is stored.
+__device__ __forceinline__ void trace_trial(double* tr, double lambda, double rho, double y0, double yi) {
+  int* h = (int*)tr;
+  const int n = h[0], cap = h[2];
+  if (n < cap) tr[2 + n] = lambda, tr[2 + cap + n] = rho, tr[2 + 2 * cap + n] = y0, tr[2 + 3 * cap + n] = yi;
+  h[0] = n + 1;
+}
+__device__ __forceinline__ void trace_pose(double* tr, const Rigid& x) {
+  int* h = (int*)tr;
+  const int n = h[1];
+  if (n < h[3]) {
+    double* o = tr + 2 + 4 * h[2] + 12 * n;
+    for (int q = 0; q < 12; q++) o[q] = x.m[q];
+  }
+  h[1] = n + 1;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2675,12 +2715,13 @@ __device__ __forceinline__ void lm_trial(PairState& s, double* ws) {  // L:137-1
 }
 
 // after step_optimize returned `ok` (L:71-75): convergence test and loop bookkeeping
-__device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok) {
+__device__ __forceinline__ void step_done(PairState& s, const Consts& c, bool ok, double* tr) {
   if (!ok) {  // "lm not converged!!" -> break
     s.failed = 1;
     s.status = ST_DONE;
     return;
   }
+  if (tr) trace_pose(tr, s.x0);
   s.converged = is_converged(s.delta, c.rot_eps, c.trans_eps) ? 1 : 0;
   if (s.converged || s.iter + 1 >= c.max_iterations) {
     s.status = ST_DONE;
@@ -2713,7 +2754,7 @@ __device__ __forceinline__ void gather_linearize(PairState& s, const Work& w, in
 }
 
 // one lane: the optimiser step once H, b and the cost are in the state
-__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws) {
+__device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, double* ws, double* tr) {
   s.n_lin += 1;
   const bool gn = c.optimizer == 1;
   if (gn) {  // step_gn
@@ -2727,7 +2768,7 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, d
     s.nu = 2.0;
     s.inner = 0;
     if (c.lm_max_iterations <= 0) {  // the for loop at L:136 never runs -> return false
-      step_done(s, c, false);
+      step_done(s, c, false, tr);
       return;
     }
   }
@@ -2735,29 +2776,30 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, d
   if (gn) {
     s.x0 = s.xi;
     for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
-    step_done(s, c, true);
+    step_done(s, c, true, tr);
   } else {
     s.status = ST_NEED_ERR;
   }
 }
 
 // after k_error: L:145-172 (one lane)
-__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws) {
+__device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, const Consts& c, double* ws, double* tr) {
   s.yi = yi;
   s.n_err += 1;
   double den = 0.0;
   for (int q = 0; q < 6; q++) den += s.d[q] * (s.lambda * s.d[q] - s.b[q]);
   const double rho = (s.y0 - yi) / den;  // L:146
+  if (tr) trace_trial(tr, s.lambda, rho, s.y0, yi);
   if (rho < 0) {                         // L:156-164
     if (is_converged(s.delta, c.rot_eps, c.trans_eps)) {
-      step_done(s, c, true);  // returns true WITHOUT applying delta
+      step_done(s, c, true, tr);  // returns true WITHOUT applying delta
       return;
     }
     s.lambda = s.nu * s.lambda;
     s.nu = 2 * s.nu;
     s.inner += 1;
     if (s.inner >= c.lm_max_iterations) {  // L:172
-      step_done(s, c, false);
+      step_done(s, c, false, tr);
       return;
     }
     lm_trial(s, ws);  // next inner iteration, status stays ST_NEED_ERR
@@ -2767,7 +2809,7 @@ __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, con
   const double t = 2 * rho - 1;
   s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
   for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
-  step_done(s, c, true);
+  step_done(s, c, true, tr);
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false
@@ -2947,6 +2989,15 @@ __global__ __launch_bounds__(256) void k_pool_poll(PairState* st, int* active, i
     __threadfence_system();
     __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// apdgicp_debug_atan2f: the device's evaluation of include/apd_atan2f.h, for the bit-for-bit comparison with the host's
+__global__ void k_debug_atan2f(const float* y, const float* x, float* out, long long n) {
+  __shared__ float s_atan[APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE];
+  atan_tab_to_lds(s_atan, (int)threadIdx.x);
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = apd_atan2f_tab(y[i], x[i], s_atan);
 }
 
 // pcl::transformPointCloud (L:79): float 4x4 times {x,y,z,1}

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "../../include/apd_atan2f.h"  // apd::apd_atan2f: the C library's algorithm (fdlibm), the same bits on host and device
+
 #define APD_HD __host__ __device__ __forceinline__
 
 namespace apd {

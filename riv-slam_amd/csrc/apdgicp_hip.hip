@@ -14,6 +14,9 @@ struct apdgicp_handle {
   bool pair_ready = false;   // work buffers / descriptors match the current source+target
   bool have_corr = false;    // correspondences_/mahalanobis_ hold a linearize result
   int n_src_at_corr = 0;
+  // apdgicp_set_trace: the trace of the last apdgicp_align_host_loop (apdgicp_align leaves its own on the device, Engine::d_trace)
+  bool trace_from_host_loop = false;
+  std::vector<double> tr_lambda, tr_rho, tr_y0, tr_yi, tr_poses;  // poses: 16 doubles each, column-major
 };
 
 struct apdgicp_batch {
@@ -88,6 +91,15 @@ int guarded(F&& f) {
 extern "C" {
 
 int apdgicp_abi_version(void) { return APDGICP_ABI_VERSION; }
+#ifndef APD_SOURCE_STAMP
+#define APD_SOURCE_STAMP "unstamped"
+#endif
+// (build.py passes "apd-source-stamp:<16 hex digits>": the marker is what build.library_stamp() looks for in the file)
+const char* apdgicp_source_stamp(void) {
+  static const char stamp[] = APD_SOURCE_STAMP;
+  const char* colon = strchr(stamp, ':');
+  return colon ? colon + 1 : stamp;
+}
 const char* apdgicp_last_error(void) { return g_last_error.c_str(); }
 
 int apdgicp_device_count(int* count) {
@@ -310,6 +322,7 @@ int apdgicp_align(apdgicp_handle* h, const float guess[16], apdgicp_result* out)
     APD_TRY(ensure_pair(h, g));
     APD_TRY(e.upload_guesses(g, 1));  // no-op when ensure_pair has just uploaded it
     APD_TRY(e.run_align());
+    h->trace_from_host_loop = false;
     if (const ResultRec* r = e.host_results()) {  // came home with the last poll
       memcpy(out, r, sizeof(apdgicp_result));
     } else {
@@ -342,6 +355,8 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
     double final_H[36];
     for (int q = 0; q < 36; q++) final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
     double y0 = 0.0;
+    h->tr_lambda.clear(), h->tr_rho.clear(), h->tr_y0.clear(), h->tr_yi.clear(), h->tr_poses.clear();
+    h->trace_from_host_loop = true;
     for (int it = 0; it < p.max_iterations && !converged; it++) {  // L:67
       nr_iterations = it;
       double T16[16], H[36], b[6], d[6];
@@ -374,6 +389,7 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
           double den = 0.0;
           for (int q = 0; q < 6; q++) den += d[q] * (lambda * d[q] - b[q]);
           const double rho = (y0 - yi) / den;
+          if (e.trace_on) h->tr_lambda.push_back(lambda), h->tr_rho.push_back(rho), h->tr_y0.push_back(y0), h->tr_yi.push_back(yi);
           if (rho < 0) {
             if (is_converged(delta, p.rotation_epsilon, p.transformation_epsilon)) {
               ok = true;
@@ -395,6 +411,11 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
         failed = 1;
         break;
       }
+      if (e.trace_on) {
+        double P[16];
+        rigid_to_colmajor(x0, P);
+        h->tr_poses.insert(h->tr_poses.end(), P, P + 16);
+      }
       converged = is_converged(delta, p.rotation_epsilon, p.transformation_epsilon);
     }
     for (int i = 0; i < 3; i++)
@@ -413,6 +434,71 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
     APD_HIP(hipMemcpyAsync((char*)e.d_state.p + offsetof(PairState, final_H), final_H, sizeof(final_H), hipMemcpyHostToDevice, e.stream));
     APD_HIP(hipStreamSynchronize(e.stream));
     return 0;
+  });
+}
+
+int apdgicp_set_trace(apdgicp_handle* h, int enable) {
+  if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
+  h->eng.trace_on = enable != 0;
+  return 0;
+}
+
+int apdgicp_get_trace(apdgicp_handle* h, int64_t trial_capacity, double* lambdas, double* rhos, double* y0s, double* yis, int64_t* n_trials,
+                      int64_t pose_capacity, double* poses16, int64_t* n_poses) {
+  return guarded([&]() -> int {
+    if (!h || !n_trials || !n_poses) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    if (trial_capacity < 0 || pose_capacity < 0 || (trial_capacity > 0 && (!lambdas || !rhos)) || (pose_capacity > 0 && !poses16))
+      return fail(APDGICP_ERR_INVALID_ARG, "bad capacity / buffer");
+    Engine& e = h->eng;
+    if (!e.trace_on) return fail(APDGICP_ERR_NO_INPUT, "tracing is off (apdgicp_set_trace)");
+    if (h->trace_from_host_loop) {
+      *n_trials = (int64_t)h->tr_lambda.size(), *n_poses = (int64_t)h->tr_poses.size() / 16;
+      const int64_t nt = std::min<int64_t>(*n_trials, trial_capacity), np = std::min<int64_t>(*n_poses, pose_capacity);
+      if (nt) memcpy(lambdas, h->tr_lambda.data(), nt * sizeof(double)), memcpy(rhos, h->tr_rho.data(), nt * sizeof(double));
+      if (nt && y0s) memcpy(y0s, h->tr_y0.data(), nt * sizeof(double));
+      if (nt && yis) memcpy(yis, h->tr_yi.data(), nt * sizeof(double));
+      if (np) memcpy(poses16, h->tr_poses.data(), np * 16 * sizeof(double));
+      return 0;
+    }
+    if (!e.d_trace.p) return fail(APDGICP_ERR_NO_INPUT, "no align has run since tracing was enabled");
+    std::vector<double> buf(e.trace_bytes() / sizeof(double));
+    APD_HIP(hipMemcpyAsync(buf.data(), e.d_trace.p, e.trace_bytes(), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    int hdr[4];
+    memcpy(hdr, buf.data(), sizeof(hdr));
+    *n_trials = hdr[0], *n_poses = hdr[1];
+    const int64_t nt = std::min<int64_t>(std::min(hdr[0], hdr[2]), trial_capacity), np = std::min<int64_t>(std::min(hdr[1], hdr[3]), pose_capacity);
+    if (nt) memcpy(lambdas, &buf[2], nt * sizeof(double)), memcpy(rhos, &buf[2 + hdr[2]], nt * sizeof(double));
+    if (nt && y0s) memcpy(y0s, &buf[2 + 2 * (size_t)hdr[2]], nt * sizeof(double));
+    if (nt && yis) memcpy(yis, &buf[2 + 3 * (size_t)hdr[2]], nt * sizeof(double));
+    for (int64_t q = 0; q < np; q++) {
+      Rigid r;
+      memcpy(r.m, &buf[2 + 4 * (size_t)hdr[2] + 12 * (size_t)q], sizeof(r.m));
+      rigid_to_colmajor(r, poses16 + 16 * q);
+    }
+    return 0;
+  });
+}
+
+int apdgicp_debug_atan2f(int device, const float* y, const float* x, float* out, int64_t n) {
+  return guarded([&]() -> int {
+    if (!y || !x || !out || n < 0) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    if (n == 0) return 0;
+    APD_HIP(hipSetDevice(device));
+    DevBuf buf;
+    APD_TRY(buf.ensure((size_t)n * 12));
+    float* dy = buf.as<float>();
+    int rc = 0;
+    hipError_t he = hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(dy + n, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+      hipLaunchKernelGGL(k_debug_atan2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dy, dy + n, dy + 2 * n, (long long)n);
+      he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpy(out, dy + 2 * n, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) rc = fail(APDGICP_ERR_HIP, hipGetErrorString(he));
+    buf.release();
+    return rc;
   });
 }
 

@@ -80,7 +80,8 @@ assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 96
 
 # every symbol include/apdgicp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "apdgicp_abi_version", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
+    "apdgicp_abi_version", "apdgicp_source_stamp", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
+    "apdgicp_set_trace", "apdgicp_get_trace", "apdgicp_debug_atan2f",
     "apdgicp_create", "apdgicp_destroy", "apdgicp_set_params", "apdgicp_get_params",
     "apdgicp_set_source", "apdgicp_set_target", "apdgicp_clear_source", "apdgicp_clear_target",
     "apdgicp_swap_source_and_target", "apdgicp_compute_covariances", "apdgicp_get_covariances",
@@ -116,6 +117,16 @@ def load_library(path: str | None = None):
                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     L = C.CDLL(p)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+    # The library says which sources it was compiled from (apdgicp_source_stamp); one that was built from other sources than the
+    # ones beside it is refused, whatever its age (a prebuilt library pushed with the tree would otherwise be measured and tested
+    # under the name of sources it does not contain).  APDGICP_ALLOW_STALE_LIB=1 is for bisecting with hand-built libraries.
+    L.apdgicp_source_stamp.restype = C.c_char_p
+    if path is None and os.environ.get("APDGICP_ALLOW_STALE_LIB", "0") != "1":
+        from . import build as _build
+        have, want = L.apdgicp_source_stamp().decode(), _build.source_stamp()
+        if have != want:
+            raise RuntimeError(f"{p} was compiled from other sources (stamp {have}) than the ones on disk ({want}): rebuild it "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     L.apdgicp_abi_version.restype = i32
     L.apdgicp_last_error.restype = C.c_char_p
     L.apdgicp_device_count.argtypes = [C.POINTER(i32)]
@@ -139,6 +150,9 @@ def load_library(path: str | None = None):
     L.apdgicp_align.argtypes = [vp, vp, C.POINTER(Result)]
     L.apdgicp_align_host_loop.argtypes = [vp, vp, C.POINTER(Result)]
     L.apdgicp_get_final_hessian.argtypes = [vp, vp]
+    L.apdgicp_set_trace.argtypes = [vp, i32]
+    L.apdgicp_get_trace.argtypes = [vp, i64, vp, vp, vp, vp, C.POINTER(i64), i64, vp, C.POINTER(i64)]
+    L.apdgicp_debug_atan2f.argtypes = [i32, vp, vp, vp, i64]
     L.apdgicp_transform_source.argtypes = [vp, vp, vp, i64, i64]
     L.apdgicp_fitness_score.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
     L.apdgicp_inlier_fraction.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
@@ -174,6 +188,22 @@ def load_library(path: str | None = None):
     if path is None:
         _lib = L
     return L
+
+
+def source_stamp() -> str:
+    """The fingerprint of the sources the loaded library was compiled from (apdgicp_source_stamp)."""
+    return load_library().apdgicp_source_stamp().decode()
+
+
+def debug_atan2f(y, x, device: int = 0) -> np.ndarray:
+    """atan2f as the kernels evaluate it on the device (include/apd_atan2f.h), for the bit-for-bit comparison with the host."""
+    y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+    x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    if y.shape != x.shape:
+        raise ValueError("y and x must have the same number of elements")
+    out = np.empty_like(y)
+    _check(load_library().apdgicp_debug_atan2f(device, _ptr(y), _ptr(x), _ptr(out), y.size))
+    return out
 
 
 def default_params(**kw) -> Params:
@@ -437,6 +467,22 @@ class FastAPDGICP:
 
     def getFinalTransformation(self) -> np.ndarray:
         return self._final
+
+    def setTrace(self, enable: bool = True):
+        """Debug: record the optimiser's per-iteration trace in the aligns that follow (include/apdgicp_hip.h: apdgicp_set_trace)."""
+        _check(self.L.apdgicp_set_trace(self.h, 1 if enable else 0))
+
+    def trace(self):
+        """dict(lambda, rho, y0, yi, poses) of the last align: per LM trial the lambda the step was solved with, its rho and the two
+        costs rho compares (L:137-146); per completed outer iteration the pose x0 behind it, [n, 4, 4] row-major."""
+        cap_p = max(1, int(self.params.max_iterations))
+        cap_t = cap_p * max(1, int(self.params.lm_max_iterations))
+        lam, rho, y0, yi, poses = np.zeros(cap_t), np.zeros(cap_t), np.zeros(cap_t), np.zeros(cap_t), np.zeros((cap_p, 16))
+        nt, npo = C.c_int64(), C.c_int64()
+        _check(self.L.apdgicp_get_trace(self.h, cap_t, _ptr(lam), _ptr(rho), _ptr(y0), _ptr(yi), C.byref(nt), cap_p, _ptr(poses), C.byref(npo)))
+        nt_, np_ = min(nt.value, cap_t), min(npo.value, cap_p)
+        return {"lambda": lam[:nt_].copy(), "rho": rho[:nt_].copy(), "y0": y0[:nt_].copy(), "yi": yi[:nt_].copy(),
+                "poses": poses[:np_].reshape(-1, 4, 4).transpose(0, 2, 1).copy()}
 
     def getFinalHessian(self) -> np.ndarray:
         H = np.zeros((6, 6), order="F")

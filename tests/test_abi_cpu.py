@@ -21,12 +21,12 @@ def reg(pkg):
 def test_library_exports_every_declared_symbol(reg):
     L = reg.load_library()
     header = open(os.path.join(ROOT, "include", "apdgicp_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(apdgicp_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(apdgicp_[a-z0-9_]+)\s*\(", header)))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/apdgicp_hip.h but not exported"
     assert sorted(reg.SYMBOLS) == declared
-    assert L.apdgicp_abi_version() == 4
+    assert L.apdgicp_abi_version() == 5
 
 
 def test_default_params_match_reference_defaults(reg):

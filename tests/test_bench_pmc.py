@@ -56,3 +56,30 @@ def test_the_committed_profile_is_either_current_or_refused():
         assert pmc is None and why
         pytest.xfail(f"profiles/pmc_nn_latest.json is stale ({have} vs {build.source_stamp()}): bench.py prints null for the PMC fields until "
                      "tools/refresh_evidence.sh has been re-run on the GPU box and the file committed")
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
+    """The library carries the stamp of the sources it was compiled from (apdgicp_source_stamp); the loader compares it with
+    the sources on disk and refuses a mismatch -- age plays no part (a prebuilt library pushed with a tree of newer mtimes used
+    to pass the freshness test).  Simulated without a second compile: the sources "on disk" are a touched copy."""
+    reg = importlib.import_module("riv-slam_amd.registration")
+    import __graft_entry__ as g
+    g.build()
+    assert build.library_stamp() == build.source_stamp() and not build.needs_build()
+    assert reg.load_library().apdgicp_source_stamp().decode() == build.source_stamp()
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    for f in os.listdir(build.CSRC):
+        if f.endswith((".hip", ".hpp")):
+            (csrc / f).write_bytes(open(os.path.join(build.CSRC, f), "rb").read())
+    with open(csrc / "apd_kernels.hpp", "ab") as fh:
+        fh.write(b"\n// touched\n")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    assert build.needs_build()                       # identity, not mtime: the library on disk is older AND of other sources
+    os.utime(build.LIB)                               # ... and making it the newest file changes nothing
+    assert build.needs_build()
+    monkeypatch.setattr(reg, "_lib", None)
+    with pytest.raises(RuntimeError, match="compiled from other sources"):
+        reg.load_library()
+    monkeypatch.setenv("APDGICP_ALLOW_STALE_LIB", "1")
+    assert reg.load_library() is not None

@@ -6,6 +6,7 @@ import pytest
 import apdgicp_np as O
 import ref as R
 from conftest import rel_err
+from trace_util import golden_trace, trace_close
 
 LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
 REGS = (("none", 0), ("min_eig", 1), ("norm_min_eig", 2), ("plane", 3), ("frobenius", 4))
@@ -82,7 +83,8 @@ def test_linearize_golden_cpp(golden, tag, kw, sfx, flags):
 
 @pytest.mark.parametrize("sfx,flags", XF)
 def test_linearize_golden_numpy(golden, sfx, flags):
-    """Independent restatement: exact on the discrete outputs, 5e-6 on the smooth ones (fp32 atan2)."""
+    """Independent restatement: exact on the discrete outputs, 1e-10 on the smooth ones (both evaluate the fp32 angles with the
+    C library's atan2f algorithm: include/apd_atan2f.h and apdgicp_np.atan2f_fdlibm)."""
     n = O.FastAPDGICP(O.Params(flags=flags, **LAUNCH))
     n.setInputSource(golden["lin_source"])
     n.setInputTarget(golden["lin_target"])
@@ -91,9 +93,9 @@ def test_linearize_golden_numpy(golden, sfx, flags):
     cost, H, b = n.linearize(golden[f"lin_launch{sfx}_{k}_T"])
     assert np.array_equal(n.correspondences, golden[f"lin_launch{sfx}_{k}_corr"])
     assert np.array_equal(n.sq_distances, golden[f"lin_launch{sfx}_{k}_sqd"])
-    assert rel_err(H, golden[f"lin_launch{sfx}_{k}_H"]) < 5e-6
-    assert rel_err(b, golden[f"lin_launch{sfx}_{k}_b"]) < 5e-6
-    assert abs(cost - golden[f"lin_launch{sfx}_{k}_cost"]) < 5e-6 * cost
+    assert rel_err(H, golden[f"lin_launch{sfx}_{k}_H"]) < 1e-10
+    assert rel_err(b, golden[f"lin_launch{sfx}_{k}_b"]) < 1e-10
+    assert abs(cost - golden[f"lin_launch{sfx}_{k}_cost"]) < 1e-10 * cost
 
 
 def test_transform_orders_by_hand():
@@ -148,6 +150,8 @@ def test_align_golden_cpp(golden, scene, tag, sfx, flags):
     te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
     assert te < 1e-7 and re_ < 1e-7
     assert rel_err(r.final_hessian(), golden[f"{tag}_final_hessian"]) < 1e-9
+    d = trace_close(r.trace(), golden_trace(golden, tag))   # KAT-lm: lambda, rho, costs per trial, pose per outer iteration
+    assert max(d.values()) < 1.0, d
 
 
 @pytest.mark.parametrize("sfx,flags", XF)
@@ -158,7 +162,11 @@ def test_align_golden_numpy_launch(golden, scene, sfx, flags):
     T = n.align(golden["lin_guess"])
     assert [int(n.converged), n.nr_iterations, n.trace.n_linearize, n.trace.n_compute_error] == list(golden[f"lm_launch{sfx}_info"])
     te, re_ = scene.pose_error(golden[f"lm_launch{sfx}_T"], T)
-    assert te < 1e-5 and re_ < 1e-5
+    assert te < 1e-7 and re_ < 1e-7
+    tn = {"lambda": np.array(n.trace.lambdas), "rho": np.array(n.trace.rhos), "y0": np.array(n.trace.y0s), "yi": np.array(n.trace.yis),
+          "poses": np.array(n.trace.poses)}
+    d = trace_close(tn, golden_trace(golden, f"lm_launch{sfx}"))
+    assert max(d.values()) < 1.0, d
 
 
 @pytest.mark.parametrize("sfx,flags", XF)
@@ -191,6 +199,8 @@ def test_lm_rejection_paths_cpp(golden, scene, tag, kw, sfx, flags):
     assert (golden[f"{tag}{sfx}_trace_rho"] < 0).any()
     te, re_ = scene.pose_error(golden[f"{tag}{sfx}_T"], T)
     assert te < 1e-6 and re_ < 1e-8
+    d = trace_close(r.trace(), golden_trace(golden, tag + sfx))
+    assert max(d.values()) < 1.0, d
     if tag == "fail":
         assert not r.converged and r.nr_iterations < 63
 

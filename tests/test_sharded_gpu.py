@@ -205,3 +205,62 @@ def test_bench_timed_loop_with_two_ranks_on_one_gpu(tmp_path, scene, optimizer):
     single.set_clouds(0, clouds)
     want = single.align([(2 * i, 2 * i + 1) for i in range(2 * P)], guesses)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("optimizer", ("lm", "gn"))
+def test_c4_whole_256_pairs_over_8_ranks(tmp_path, scene, optimizer):
+    """BASELINE configs[3] as a whole: 256 pairwise registrations of 8 192-point clouds, block-partitioned 32 per rank over EIGHT
+    ranks (loop_detector.cpp:404-423 is the workload), through bench.py's own N > 1 launch path -- rank spawn, pooled / pipelined
+    steps, one all-gather of 96-byte records per step, barrier, all_reduce(MAX).  The box has one GPU, so the eight ranks share
+    it and gather with gloo (RCCL refuses several ranks on one device); partition, engine and gather call are the ones the 8-GPU
+    run takes.  The 256 gathered records must equal, byte for byte, those of ONE handle registering all 256 pairs, and 16 of
+    them (two per rank's block) are checked against the CPU oracle: counts exact, pose inside the north-star tolerance."""
+    import importlib
+    import json
+    import numpy as np
+    import ref as R
+    reg = importlib.import_module("riv-slam_amd.registration")
+    sys.path.insert(0, ROOT)
+    import bench
+    W, P, n = 8, 32, 8192
+    kind = "loop" if optimizer == "lm" else "odometry"
+    dump = tmp_path / "records.npy"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--ranks-share-gpu", "--dist-backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--repeats", "1", "--pairs-per-gpu", str(P), "--points", str(n), "--optimizer", optimizer, "--kind", kind,
+                        "--no-cpu-baseline", "--no-diagnostics", "--dump-records", str(dump)],
+                       capture_output=True, text=True, timeout=1200, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["world_size"] == W and d["n_gpus"] == W and d["config"]["pairs_per_gpu"] == P and d["scaling"] == "weak"
+    assert abs(d["value"] - W * P / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    got = np.frombuffer(np.load(dump).tobytes(), dtype=reg.RESULT_DTYPE)
+    assert len(got) == W * P
+    params = bench.bench_params(reg, optimizer)
+    single = reg.BatchAPDGICP(params)
+    clouds, guesses = [], []
+    for p in range(W * P):
+        s_, t_, _, g = scene.make_pair(n, n, scene.pair_seed(2, p), kind)
+        clouds += [s_, t_]
+        guesses.append(np.eye(4, dtype=np.float32) if kind == "loop" else g)
+    single.set_clouds(0, clouds)
+    want = single.align([(2 * i, 2 * i + 1) for i in range(W * P)], guesses)
+    assert got.tobytes() == want.tobytes(), int((got["T"] != want["T"]).any(axis=1).sum())
+    rp = R.default_params(**{f: getattr(params, f) for f, _ in reg.Params._fields_})
+    worst = [0.0, 0.0]
+    for p in [q for rank in range(W) for q in (rank * P + 3, rank * P + P - 1)]:
+        o = R.RefAPDGICP(rp)
+        o.setInputSource(clouds[2 * p])
+        o.setInputTarget(clouds[2 * p + 1])
+        To = o.align(guesses[p])
+        rec = got[p]
+        assert [int(rec["converged"]), int(rec["iterations"]), int(rec["n_linearize"]), int(rec["n_compute_error"])] == \
+            [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error], p
+        te, re_ = scene.pose_error(To, rec["T"].reshape(4, 4).T)
+        worst = [max(worst[0], te), max(worst[1], re_)]
+        assert te <= 1e-3 and re_ <= 1e-4, (p, te, re_)
+    print(f"C4 whole ({optimizer}): 256 records byte-equal to one handle; 16 oracle checks, worst pose difference {worst[0]:.2e} m / {worst[1]:.2e} rad; "
+          f"{d['value']:.0f} registrations/s with 8 ranks sharing the GPU")

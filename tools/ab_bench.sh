@@ -1,8 +1,9 @@
 #!/bin/bash
 # A/B of library builds on ONE box (boxes differ by ~1.5 %): alternates riv-slam_amd/_<name>.bin copies of libapdgicp_hip.so
 # and prints ms_per_step of the default bench for each.   usage (inside gpurun): bash tools/ab_bench.sh old new [rounds]
-# build a variant here with:  hipcc <flags> -o riv-slam_amd/_<name>.bin riv-slam_amd/csrc/apdgicp_hip.hip
+# build a variant here with:  python tools/build_variant.py <name> [extra hipcc flags]
 a=$1; b=$2; rounds=${3:-3}
+export APDGICP_ALLOW_STALE_LIB=1   # (the loader refuses a library whose compiled-in source stamp is not that of the tree)
 cp riv-slam_amd/libapdgicp_hip.so riv-slam_amd/_keep.bin
 for i in $(seq $rounds); do
   for v in $a $b; do

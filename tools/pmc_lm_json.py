@@ -10,7 +10,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-source_stamp = importlib.import_module("riv-slam_amd.build").source_stamp()
+source_stamp = importlib.import_module("riv-slam_amd.registration").source_stamp()   # compiled into the library that was profiled (apdgicp_source_stamp)
 out_path, points = sys.argv[1], int(sys.argv[2])
 
 

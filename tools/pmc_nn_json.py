@@ -12,7 +12,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-source_stamp = importlib.import_module("riv-slam_amd.build").source_stamp()   # the sources the profiled library was built from
+source_stamp = importlib.import_module("riv-slam_amd.registration").source_stamp()   # compiled into the library that was profiled (apdgicp_source_stamp)   # the sources the profiled library was built from
 
 out_path, points, kind = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
