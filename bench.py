@@ -463,6 +463,14 @@ def main():
                          "kernel_ms_per_step": round(avg_nn_ms * (ticks if not lm else n_lin), 4),
                          "kernel_time_check": "kernel_ms_per_step (average launch x launches per step) <= timing.step_latency_ms: the launches of one step overlap with "
                                               "those of the other steps in flight, so it may exceed ms_per_step",
+                         # non-overlapped accounting: H steps are in flight, each on a stream of its own, and a step stays H x ms_per_step on
+                         # its stream; the search kernel's share of ALL stream time = sum of its launch times / (wall x busy streams) <= 1
+                         "concurrency": {"steps_in_flight": H if not lm else None, "busy_streams": (H if not lm else 2),
+                                         "kernel_time_over_wall_x_streams": round(avg_nn_ms * (ticks if not lm else n_lin) / (ms_per_step * (H if not lm else 2)), 4)
+                                         if not lm else None,
+                                         "note": "sum of this kernel's launch durations per step / (ms_per_step x streams in flight): the share of the busy streams' time "
+                                                 "the dominant kernel holds (<= 1); durations are those of launches that share the GPU with the other steps' kernels, "
+                                                 "so they are not additive against ms_per_step"},
                          "traffic_source": (pmc.get("source", "profiles/pmc_nn_latest.json") if traffic else None),
                          "avg_launch_ms": round(avg_nn_ms, 5), "launches_timed": nn_launches, "pairs_per_launch": round(pairs_per_launch, 2),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -493,8 +501,9 @@ def main():
                         else:
                             os.environ[k_] = v_
                 bb.set_profiling(True)
-                if H > 1 and "APDGICP_NN_MODE" not in env:
-                    bb.set_pair_groups(1)      # the timed handles' regime (k_nn_compact)
+                if H > 1:
+                    bb.set_pair_groups(1)      # the timed handles' regime: ONE launch over all the pairs of the step (k_nn_compact; the brute-force leg:
+                                               # k_nn_partial over 32 pairs -- with three pair groups it launched 10 - 11 pairs = 176 blocks on 256 CUs)
                 for _ in range(2):
                     bb.set_clouds(0, d_clouds)
                     bb.align_async(pairs_arr)
@@ -522,6 +531,7 @@ def main():
             out["roofline_bruteforce"] = {"kernel": f"k_nn_partial<{sb}> (every pair evaluated, LDS-tiled, T={tb} target splits)", "bound": "valu-fp32",
                                           "achieved": round(tf_b, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": round(tf_b / FP32_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms_b / max(1, k_b), 4),
+                                          "pairs_per_launch": round(pr_b / max(1, k_b), 2), "launches_timed": int(k_b),
                                           "note": "same results bit for bit; exact non-fused arithmetic (no FMA) caps this formulation at "
                                                   "~0.4 of the FMA-based spec peak (profiles/r01_ubench_valu.txt)"}
             del bf
@@ -690,7 +700,12 @@ def main():
                 reps_cpu = [run_cfg(int(best_threads), share) for _ in range(3)]     # three repeats at the best thread count: median + spread
                 rates = sorted(r_[0] for r_ in reps_cpu)
                 rate, done, used = rates[1], sum(r_[1] for r_ in reps_cpu), reps_cpu[0][2]
-                out["cpu_baseline"] = {"value": round(rate, 3), "unit": "registrations/s", "cores": used, "kind": "port",
+                try:   # the flags the checker was built with (oracle/Makefile: -O3 like the reference's Release build, no contraction)
+                    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+                    cxxflags = next(l.split("?=", 1)[1].strip() for l in mk.splitlines() if l.startswith("CXXFLAGS"))
+                except Exception:  # noqa: BLE001
+                    cxxflags = None
+                out["cpu_baseline"] = {"value": round(rate, 3), "unit": "registrations/s", "cores": used, "kind": "port", "build_flags": cxxflags,
                                        "repeats": {"n": 3, "statistic": "median", "min": round(rates[0], 3), "max": round(rates[2], 3),
                                                    "spread_rel": round((rates[2] - rates[0]) / rates[1], 3)},
                                        "sample": f"{done} registrations of the {P} timed pairs in three repeats at the best thread count of the sweep (same clouds, "

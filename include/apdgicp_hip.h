@@ -66,7 +66,14 @@ typedef enum {
  * what ABI versions <= 3 evaluated.  The two differ in the last ulp of a transformed coordinate: enough to resolve a
  * nearest-neighbour near-tie the other way (poses move by <= 1e-5 m, an LM run may stop one iteration earlier or later).
  * INTEGRATION.md section 7 holds a 30-line probe that tells which order an installed Eigen produces. */
-enum { APDGICP_FLAG_PLAIN_GICP = 1, APDGICP_FLAG_XF_LINEAR_CHAIN = 2 };
+/* FP32_POINT_MATH (opt-in, not the reference's arithmetic): the per-point algebra behind the nearest-neighbour search -- sin / cos of
+ * elevation and azimuth, the APD covariance A A^T, RCR = (C_B + cov_d) + R (C_A + cov_d) R^T, its inverse, the residual, M e and
+ * every J^T M J term (A:174-192, A:229-258) -- in fp32 instead of fp64.  Stays fp64: cos(AoA) and its reciprocal (it cancels near
+ * the +-x axis, A:170-171), the sums over the points, the 6x6 solve and the pose update; the search, the gate and the three fp32
+ * angles are unchanged, so correspondences are identical at a given pose.  Measured: final poses move by
+ * ~1e-6 m / 1e-7 rad against the default, a Levenberg-Marquardt run may stop an iteration earlier or later.  The default (flag
+ * clear) is the reference's precision; bench.py's headline runs with the flag clear. */
+enum { APDGICP_FLAG_PLAIN_GICP = 1, APDGICP_FLAG_XF_LINEAR_CHAIN = 2, APDGICP_FLAG_FP32_POINT_MATH = 4 };
 
 /* fast_gicp::LSQ_OPTIMIZER_TYPE, gicp/lsq_registration.hpp:13 (reference default: LM, L:17) */
 typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
@@ -190,6 +197,16 @@ int apdgicp_fitness_score(apdgicp_handle* h, const float T[16], double max_range
  * points whose nearest target point is STRICTLY closer than max_correspondence_dist (squared float distance < dist*dist
  * in double, as there), divided by the source size in float.  n_inliers may be NULL */
 int apdgicp_inlier_fraction(apdgicp_handle* h, const float T[16], double max_correspondence_dist, double* fraction, int64_t* n_inliers);
+/* The nearest target point of every T-transformed source point: what pcl::search::KdTree::nearestKSearch(T * source[i], 1, ...)
+ * returns, for all i in ONE batched search on the device -- index into the target cloud as set (a tie: the lowest index) and the
+ * fp32 squared distance (FLANN L2_Simple order on the fp32-transformed point, like A:149-153); no correspondence gate.  This is
+ * what serves the base-class calls of the nodelets -- getFitnessScore() (loop_detector.cpp:229) and
+ * getSearchMethodTarget()->nearestKSearch(aligned[i], 1, ...) (scan_matching_odometry_nodelet.cpp:697-707) -- through the search
+ * object FastAPDGICPHip installs, so that PCL never builds its CPU kd-tree.  Leaves the handle as apdgicp_linearize at T would. */
+int apdgicp_nearest_neighbours(apdgicp_handle* h, const float T[16], int32_t* index, float* sq_dist, int64_t n);
+/* the points of the source / target cloud as set, n x {x, y, z} floats in the caller's order, into host memory (the fall-back of
+ * that search object for a query that is not one of the transformed source points needs the target of a device-resident submap) */
+int apdgicp_get_points(apdgicp_handle* h, int which, float* out_xyz, int64_t n);
 int apdgicp_synchronize(apdgicp_handle* h);
 /* Ordering against the stream that PRODUCED device-resident inputs.  The handle's streams are non-blocking: without this
  * call nothing orders a kernel that still writes the cloud (on the caller's stream) against the handle's pack kernel.
@@ -225,7 +242,7 @@ int apdgicp_batch_add_cloud(apdgicp_batch* b, const float* xyz, int64_t n, int64
 int apdgicp_batch_set_cloud(apdgicp_batch* b, int32_t index, const float* xyz, int64_t n, int64_t stride_bytes, int on_device);
 /* sets clouds first_index .. first_index+count-1 in one call: xyz[i] / n[i] describe cloud first_index+i, all with the same stride.
  * on_device: one pack launch.  Host clouds (four or more, 32 k points or more in all): packed by a few host threads
- * (APDGICP_HOST_THREADS, default 4, the caller included) into one pinned region, ONE asynchronous copy, one pack launch; the
+ * (APDGICP_HOST_THREADS, default 4, the caller included; ONE pool per process, sized when first used) into one pinned region, ONE asynchronous copy, one pack launch; the
  * caller's buffers are free on return */
 int apdgicp_batch_set_clouds(apdgicp_batch* b, int32_t first_index, int32_t count, const float* const* xyz, const int64_t* n,
                              int64_t stride_bytes, int on_device);
@@ -320,8 +337,9 @@ int apdgicp_submap_destroy(apdgicp_submap* s);
  * rel_poses: n_clouds x 16 doubles, column-major 4x4 (keyframes[i].odom^-1 * keyframes.back().odom, :609), NULL = identity;
  * leaf: voxel size per axis (downsample_resolution), NULL or leaf[0] <= 0: no downsampling (downsample_method NONE);
  * n_out: number of points of the assembled cloud.  Non-finite points are skipped by the voxel filter, as PCL does for
- * non-dense clouds.  Fails with APDGICP_ERR_UNSUPPORTED when the leaf is too small for the extent (PCL's
- * "Leaf size is too small" warning, where it returns the input unfiltered). */
+ * non-dense clouds.  A leaf too small for the extent (the voxel index would overflow int32): pcl::VoxelGrid warns ("Leaf size is
+ * too small for the input dataset") and returns its input unfiltered -- so does this call: the transformed, concatenated cloud,
+ * the warning on stderr and in apdgicp_last_error(), status 0. */
 int apdgicp_submap_assemble(apdgicp_submap* s, int n_clouds, const void* const* xyz, const int64_t* n_points, int64_t stride_bytes,
                             int64_t intensity_offset_bytes, int on_device, const double* rel_poses, const float* leaf, int64_t* n_out);
 /* device pointer to the last assembled cloud: n points of {x, y, z, intensity} floats, valid until the next assemble */

@@ -815,7 +815,8 @@ int ref_knn_kdtree(void* h, int which, const float* q, int k, int* out_idx, floa
 //   filters/impl/voxel_grid.hpp VoxelGrid<PointT>::applyFilter      getMinMax3D over finite points, inverse_leaf = 1/leaf
 //       (float), min_b = floor(min*inverse_leaf), div_b = max_b - min_b + 1, idx = ijk . (1, div_b.x, div_b.x*div_b.y),
 //       std::sort on idx (operator< compares idx only), one CentroidPoint (float sums of x, y, z, intensity, then / n)
-//       per run of equal idx, in ascending idx; "Leaf size is too small" when dx*dy*dz > INT_MAX (returns -1 here).
+//       per run of equal idx, in ascending idx; "Leaf size is too small" when dx*dy*dz > INT_MAX: a warning, output = input
+//       (returned here as -(N + 1) with the unfiltered cloud in `out`).
 // clouds: n_clouds arrays of n[c] x 4 floats {x, y, z, intensity}; poses: n_clouds x 16 doubles column-major (null: identity);
 // out: room for sum(n) x 4 floats; out_idx / out_cnt (optional): voxel index and population of every output point.
 struct VoxIdx {
@@ -859,7 +860,12 @@ long long ref_submap_assemble(int n_clouds, const float* const* clouds, const lo
     min_b[a] = (int)std::floor(mn[a] * inv[a]);
     div_b[a] = (int)std::floor(mx[a] * inv[a]) - min_b[a] + 1;
   }
-  if ((double)d[0] * (double)d[1] * (double)d[2] > (double)INT32_MAX) return -1;  // PCL multiplies in int64 (wraps for absurd leaves)
+  if ((double)d[0] * (double)d[1] * (double)d[2] > (double)INT32_MAX) {  // PCL multiplies in int64 (wraps for absurd leaves)
+    // "Leaf size is too small for the input dataset. Integer indices would overflow." -- a PCL_WARN, and `output = *input_`: the
+    // unfiltered cloud.  Signalled to the caller as -(N + 1).
+    std::memcpy(out, cat.data(), cat.size() * sizeof(float));
+    return -(N + 1);
+  }
   const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
   std::vector<VoxIdx> iv;
   iv.reserve(N);

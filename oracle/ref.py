@@ -246,6 +246,7 @@ def submap_assemble(clouds, rel_poses=None, leaf=None):
     cnt = np.zeros(max(total, 1), dtype=np.int32)
     m = L.ref_submap_assemble(len(cs), ptrs, _ptr(ns), _ptr(poses) if poses is not None else None,
                               _ptr(lf) if lf is not None else None, _ptr(out), _ptr(idx), _ptr(cnt))
-    if m < 0:
-        raise RuntimeError("Leaf size is too small for the input dataset")
+    if m < 0:   # PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -- a warning; output = input
+        n = -m - 1
+        return out[:n].copy(), np.full(n, -1, dtype=np.int32), np.ones(n, dtype=np.int32)
     return out[:m].copy(), idx[:m].copy(), cnt[:m].copy()

@@ -17,11 +17,15 @@
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
 #include <pcl/registration/registration.h>
+#include <pcl/search/kdtree.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
+#include <utility>
 #include <vector>
 
 #include "apdgicp_hip.h"
@@ -67,6 +71,43 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   using Base::transformation_epsilon_;
 
  public:
+  /// The search object the class hands to its PCL base (setSearchMethodTarget(tree, force_no_recompute = true)), so that the calls the
+  /// nodelets make on the BASE class -- getFitnessScore() (loop_detector.cpp:229, scan_matching_odometry_nodelet.cpp:698) and
+  /// getSearchMethodTarget()->nearestKSearch(aligned->at(i), 1, ...) (scan_matching_odometry_nodelet.cpp:701-707) -- work
+  /// unmodified WITHOUT pcl::Registration::initCompute() ever building its FLANN kd-tree on the CPU (~1 ms per new 8k target,
+  /// tens of ms for a submap, in front of a 0.1 ms align): setInputCloud keeps the pointer and builds nothing; nearestKSearch(pt,
+  /// 1, ...) is answered from ONE batched device search of all source points at final_transformation_
+  /// (apdgicp_nearest_neighbours), run when the first query after an align arrives.  Both callers ask for the transformed source
+  /// points in order, so query number i is matched against point i (checked by position, 1e-4 relative: PCL's own
+  /// transformPointCloud may round a coordinate differently); a query that is no transformed source point, or k > 1, takes an
+  /// exact brute-force scan of the target on the host (the same fp32 distance; a device-resident target is fetched once).
+  class DeviceSearch : public pcl::search::KdTree<PointTarget> {
+   public:
+    using SearchBase = pcl::search::KdTree<PointTarget>;
+    using CloudConstPtr = typename SearchBase::PointCloudConstPtr;
+    using IndicesConstPtr = typename SearchBase::IndicesConstPtr;
+    explicit DeviceSearch(FastAPDGICPHip* owner) : owner_(owner) {}
+#if defined(APDGICP_PCL_SHIM) || PCL_VERSION < PCL_VERSION_CALC(1, 12, 0)
+    void setInputCloud(const CloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
+      this->input_ = cloud, this->indices_ = indices;  // no kd-tree: the device holds the target
+    }
+    int nearestKSearch(const PointTarget& p, int k, std::vector<int>& idx, std::vector<float>& d2) const override { return owner_->device_nn(p, k, idx, d2); }
+#else  // PCL >= 1.12: setInputCloud returns bool, indices are pcl::Indices
+    bool setInputCloud(const CloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
+      this->input_ = cloud, this->indices_ = indices;
+      return true;
+    }
+    int nearestKSearch(const PointTarget& p, int k, pcl::Indices& idx, std::vector<float>& d2) const override { return owner_->device_nn(p, k, idx, d2); }
+#endif
+   private:
+    FastAPDGICPHip* owner_;
+  };
+  struct DeviceSearchStats {
+    long batched_passes = 0;   // device searches over all source points
+    long served = 0;           // queries answered from one of them
+    long fallbacks = 0;        // queries answered by the host brute-force scan
+  };
+
   explicit FastAPDGICPHip(int device = 0) {
     reg_name_ = "FastAPDGICPHip";
     apdgicp_default_params(&params_);
@@ -76,6 +117,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     max_iterations_ = params_.max_iterations;
     transformation_epsilon_ = params_.transformation_epsilon;
     if (apdgicp_create(&params_, device, nullptr, &handle_) != 0) report("apdgicp_create");
+    setUseDeviceSearch(true);
   }
   ~FastAPDGICPHip() override {
     if (handle_) apdgicp_destroy(handle_);
@@ -121,21 +163,51 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     target_.reset();
     if (handle_) apdgicp_clear_target(handle_);
   }
+  // An empty (or null) cloud: the reference builds a kd-tree over nothing and clears the covariances (:95-97); the device side of
+  // this class then holds NO cloud -- the next align fails (hasConverged() == false, one line on stderr) instead of silently
+  // registering the cloud that was set before.
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {
     if (input_ == cloud) return;  // pointer equality keeps the cached covariances, :91-93
     Base::setInputSource(cloud);
-    if (handle_ && cloud && !cloud->empty() &&
-        apdgicp_set_source(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointSource), 0, token_of(cloud.get())) != 0)
+    nn_epoch_++;
+    if (!handle_) return;
+    if (!cloud || cloud->empty()) {
+      apdgicp_clear_source(handle_);
+      return;
+    }
+    if (apdgicp_set_source(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointSource), 0, token_of(cloud.get())) != 0)
       report("setInputSource");
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
     if (target_ == cloud) return;  // :102-104
-    Base::setInputTarget(cloud);
-    if (handle_ && cloud && !cloud->empty() &&
-        apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
+    Base::setInputTarget(cloud);   // (PCL itself refuses an empty target with an error message and keeps the old pointer)
+    nn_epoch_++;
+    device_target_n_ = 0;
+    host_target_.clear();
+    if (!handle_) return;
+    if (!cloud || cloud->empty()) {
+      apdgicp_clear_target(handle_);
+      return;
+    }
+    if (apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
       report("setInputTarget");
   }
-  /// What PCL itself does inside align(): pcl::Registration::initCompute() rebuilds the BASE class's own search tree
+  /// on (the default): the base class's search object is this class's DeviceSearch -- no CPU kd-tree is ever built, the base-class
+  /// getFitnessScore() / getSearchMethodTarget() answer from the device.  off: PCL's own pcl::search::KdTree again (a FLANN build
+  /// per new target inside align(), or none with setSkipBaseSearchTree(true)).
+  void setUseDeviceSearch(bool on) {
+    typename Base::KdTreePtr tree;
+    if (on) tree.reset(new DeviceSearch(this));
+    else tree.reset(new pcl::search::KdTree<PointTarget>());
+    Base::setSearchMethodTarget(tree, on);
+    if (!on) force_no_recompute_ = false, target_cloud_updated_ = true;
+    if (on && target_) tree_->setInputCloud(target_);
+    device_search_ = on;
+    skip_base_tree_ = false;
+  }
+  bool usesDeviceSearch() const { return device_search_; }
+  const DeviceSearchStats& deviceSearchStats() const { return nn_stats_; }
+  /// (Only with setUseDeviceSearch(false).)  What PCL itself does inside align(): pcl::Registration::initCompute() rebuilds the BASE class's own search tree
   /// (`tree_->setInputCloud(target_)`, a FLANN kd-tree, single-threaded on the CPU) for every NEW target -- ~1 ms at 8k points,
   /// tens of ms for a submap -- in front of a GPU align that takes 0.1 ms.  Nothing on this class's path reads that tree; it only
   /// serves the base-class getFitnessScore() / getSearchMethodTarget() (scan_matching_odometry_nodelet.cpp:697-707,
@@ -144,6 +216,10 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   /// whatever cloud the tree was last built from (or none) and MUST be replaced by fitnessScore() / inlierFraction() below or
   /// LoopVerifierHip, which run on the device against the real target.  on = false restores PCL's behaviour.
   void setSkipBaseSearchTree(bool on) {
+    if (device_search_) {  // nothing to skip: the device search object never builds a tree
+      skip_base_tree_ = on;
+      return;
+    }
     if (on) {
       Base::setSearchMethodTarget(tree_, true);
     } else {
@@ -162,14 +238,18 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
 
   /// scan-to-map mode: the target already lives in device memory (apdgicp_submap_points, 16-byte stride), so the
   /// setInputTarget(keyframe_cloud_s2m) of scan_matching_odometry_nodelet.cpp:615 needs no host cloud.  PCL's align()
-  /// insists on a non-null target_, which gets a ONE-POINT PLACEHOLDER far outside any scene (1e18 on every axis): the
-  /// base-class getFitnessScore() / getSearchMethodTarget() would answer about that placeholder -- an absurd 3e36, or DBL_MAX
-  /// with a max_range, never a plausible number -- so after this call use fitnessScore() / inlierFraction() instead.
+  /// insists on a non-null target_, which gets a ONE-POINT PLACEHOLDER far outside any scene (1e18 on every axis).  With the
+  /// device search object (default) the base-class getFitnessScore() / getSearchMethodTarget() answer about the REAL device
+  /// target; with PCL's own tree (setUseDeviceSearch(false)) they answer about the placeholder -- an absurd 3e36, or DBL_MAX
+  /// with a max_range, never a plausible number.
   void setInputTargetDevice(const float* device_xyz, std::size_t n, std::size_t stride_bytes) {
     typename PointCloudTarget::Ptr placeholder(new PointCloudTarget());
     placeholder->resize(1);
     placeholder->at(0).x = placeholder->at(0).y = placeholder->at(0).z = 1e18f;
     Base::setInputTarget(placeholder);
+    nn_epoch_++;
+    host_target_.clear();
+    device_target_n_ = n;
     if (handle_ && n && apdgicp_set_target(handle_, device_xyz, (int64_t)n, (int64_t)stride_bytes, 1, ++device_epoch_) != 0)
       report("setInputTargetDevice");
   }
@@ -206,11 +286,96 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     return f;
   }
 
+  /// pcl::search::KdTree::nearestKSearch for DeviceSearch (see there).  Idx: std::vector<int> or pcl::Indices.
+  template <typename Idx>
+  int device_nn(const PointTarget& p, int k, Idx& idx, std::vector<float>& d2) {
+    if (k == 1 && ensure_nn_cache()) {
+      const std::size_t n = nn_idx_.size();
+      for (int attempt = 0; attempt < 2; attempt++) {  // the expected position, else the start of a new pass over the cloud
+        const std::size_t i = attempt == 0 ? nn_cursor_ : 0;
+        if (i >= n || (attempt == 1 && nn_cursor_ == 0)) continue;
+        const float* q = &nn_xyz_[3 * i];
+        auto close = [](float a, float b) { return std::fabs(a - b) <= 1e-4f * (1.0f + std::fabs(b)); };
+        if (close(p.x, q[0]) && close(p.y, q[1]) && close(p.z, q[2])) {
+          idx.assign(1, nn_idx_[i]), d2.assign(1, nn_d2_[i]);
+          nn_cursor_ = i + 1;
+          nn_stats_.served++;
+          return nn_idx_[i] >= 0 ? 1 : 0;
+        }
+      }
+    }
+    return host_nn(p, k, idx, d2);
+  }
+
  protected:
+  // one batched device search of all source points at final_transformation_, kept until the pose or a cloud changes
+  bool ensure_nn_cache() {
+    if (!handle_ || !input_ || input_->empty()) return false;
+    const float* T = final_transformation_.data();
+    if (nn_cache_epoch_ == nn_epoch_ && std::memcmp(nn_T_, T, sizeof(nn_T_)) == 0 && nn_idx_.size() == input_->size()) return true;
+    const std::size_t n = input_->size();
+    nn_idx_.assign(n, -1), nn_d2_.assign(n, 0.f), nn_xyz_.resize(3 * n);
+    push_params();
+    if (apdgicp_nearest_neighbours(handle_, T, nn_idx_.data(), nn_d2_.data(), (int64_t)n) != 0) {
+      report("nearest neighbours");
+      nn_idx_.clear();
+      return false;
+    }
+    for (std::size_t i = 0; i < n; i++) {  // where query i is expected to be (pcl::transformPointCloud's arithmetic, up to rounding)
+      const PointSource& a = input_->points[i];
+      nn_xyz_[3 * i] = T[0] * a.x + T[4] * a.y + T[8] * a.z + T[12];
+      nn_xyz_[3 * i + 1] = T[1] * a.x + T[5] * a.y + T[9] * a.z + T[13];
+      nn_xyz_[3 * i + 2] = T[2] * a.x + T[6] * a.y + T[10] * a.z + T[14];
+    }
+    std::memcpy(nn_T_, T, sizeof(nn_T_));
+    nn_cache_epoch_ = nn_epoch_;
+    nn_cursor_ = 0;
+    nn_stats_.batched_passes++;
+    return true;
+  }
+  // exact k-NN by a scan of the target on the host (FLANN's L2_Simple order in fp32; ties: the lower index first)
+  template <typename Idx>
+  int host_nn(const PointTarget& p, int k, Idx& idx, std::vector<float>& d2) {
+    idx.clear(), d2.clear();
+    nn_stats_.fallbacks++;
+    std::size_t m = 0;
+    const float* xyz = nullptr;
+    std::size_t stride = 3;
+    if (device_target_n_) {  // the target never was on the host: fetched once
+      if (host_target_.size() != 3 * device_target_n_) {
+        host_target_.resize(3 * device_target_n_);
+        if (!handle_ || apdgicp_get_points(handle_, APDGICP_TARGET, host_target_.data(), (int64_t)device_target_n_) != 0) {
+          report("get target points");
+          host_target_.clear();
+          return 0;
+        }
+      }
+      xyz = host_target_.data(), m = device_target_n_;
+    } else if (target_ && !target_->empty()) {
+      xyz = &target_->points[0].x, m = target_->size(), stride = sizeof(PointTarget) / sizeof(float);
+    }
+    if (!m || k < 1) return 0;
+    std::vector<std::pair<float, int>> best;  // (distance, index), ascending
+    for (std::size_t j = 0; j < m; j++) {
+      const float* q = xyz + j * stride;
+      const float dx = p.x - q[0], dy = p.y - q[1], dz = p.z - q[2];
+      float d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      if ((int)best.size() < k || d < best.back().first) {
+        best.insert(std::upper_bound(best.begin(), best.end(), std::make_pair(d, (int)j)), std::make_pair(d, (int)j));
+        if ((int)best.size() > k) best.pop_back();
+      }
+    }
+    for (const auto& b : best) idx.push_back(b.second), d2.push_back(b.first);
+    return (int)best.size();
+  }
+
   // pcl::Registration::align -> this (fast_apdgicp_impl.hpp:121-130 + lsq_registration_impl.hpp:55-80)
   void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
     converged_ = false;
     final_transformation_ = guess;
+    nn_epoch_++;
     if (!handle_ || !input_ || !target_) {
       report("align (no GPU handle or no input)");
       return;
@@ -292,6 +457,14 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   Eigen::Matrix<double, 6, 6> final_hessian_ = Eigen::Matrix<double, 6, 6>::Identity();
   std::size_t host_transform_max_ = 65536;
   bool skip_base_tree_ = false;
+  bool device_search_ = false;
+  // DeviceSearch's cache: the batched search of the source at nn_T_
+  unsigned long nn_epoch_ = 1, nn_cache_epoch_ = 0;
+  float nn_T_[16] = {};
+  std::vector<int> nn_idx_;
+  std::vector<float> nn_d2_, nn_xyz_, host_target_;
+  std::size_t nn_cursor_ = 0, device_target_n_ = 0;
+  DeviceSearchStats nn_stats_;
 };
 
 }  // namespace fast_gicp

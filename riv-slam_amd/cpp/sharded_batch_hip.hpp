@@ -72,7 +72,9 @@ class ShardedBatchAlignerHip {
     apdgicp_default_params(&dflt);
     params_ = params ? *params : dflt;
     pooled_ = params_.optimizer == APDGICP_OPT_LM;
-    comms_.assign((size_t)D, nullptr);
+    comm_init_.assign((size_t)D, nullptr);
+    comms_ = std::vector<std::atomic<ncclComm_t>>((size_t)D);
+    for (auto& c : comms_) c.store(nullptr);
     if (D == 0) {
       error_ = "no devices";
       return;
@@ -105,11 +107,12 @@ class ShardedBatchAlignerHip {
       if (!pooled_)
         for (apdgicp_batch* b : k.handles) apdgicp_batch_set_pair_groups(b, slots_ > 1 ? 1 : 3);  // several handles share the GPU: one stream, larger launches each
     }
-    if (ncclCommInitAll(comms_.data(), D, devices.data()) != ncclSuccess) {
+    if (ncclCommInitAll(comm_init_.data(), D, devices.data()) != ncclSuccess) {
       error_ = "ncclCommInitAll failed";
-      comms_.assign((size_t)D, nullptr);
+      comm_init_.assign((size_t)D, nullptr);
       return;
     }
+    for (int r = 0; r < D; r++) comms_[(size_t)r].store(comm_init_[(size_t)r]);
     for (int r = 0; r < D; r++) {
       Rank& k = *ranks_[(size_t)r];
       if (hipSetDevice(devices[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&k.gstream, hipStreamNonBlocking) != hipSuccess) {
@@ -154,8 +157,10 @@ class ShardedBatchAlignerHip {
       if (k.fb_recv) (void)hipFree(k.fb_recv);
       if (k.gstream) (void)hipStreamDestroy(k.gstream);
     }
-    for (ncclComm_t c : comms_)
+    for (auto& a : comms_) {
+      const ncclComm_t c = a.exchange(nullptr);
       if (c) ncclCommDestroy(c);
+    }
   }
   ShardedBatchAlignerHip(const ShardedBatchAlignerHip&) = delete;
   ShardedBatchAlignerHip& operator=(const ShardedBatchAlignerHip&) = delete;
@@ -227,9 +232,11 @@ class ShardedBatchAlignerHip {
       std::unique_lock<std::mutex> g(k.mu);
       k.want = std::max(k.want, ticket);  // (an idle worker finishes what it has in flight up to here)
       k.cv.notify_all();
-      k.cv.wait(g, [&]() { return s.issued_seq >= ticket || k.dead; });
+      k.cv.wait(g, [&]() { return s.issued_seq >= ticket || k.dead || k.aborted; });
       if (s.issued_seq != ticket) {
-        error_text_ = k.dead ? "rank " + std::to_string(r) + ": worker stopped" : "ticket is older than the batches in flight";
+        error_text_ = k.aborted ? "rank " + std::to_string(r) + ": the communicators were aborted (a rank could not enter a record gather)"
+                      : k.dead  ? "rank " + std::to_string(r) + ": worker stopped"
+                                : "ticket is older than the batches in flight";
         return APDGICP_ERR_INVALID_ARG;
       }
       if (s.rc < 0 && rc == 0) rc = s.rc, error_text_ = "rank " + std::to_string(r) + ": " + s.msg;
@@ -290,7 +297,8 @@ class ShardedBatchAlignerHip {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<Job>> queue;
-    bool stop = false, dead = false;
+    bool stop = false, dead = false;   // dead: the worker thread has ended
+    bool aborted = false;              // abort_all ran: no collective will complete any more (the worker may still be running)
     uint64_t want = 0;
     hipStream_t gstream = nullptr;  // the all-gathers
     char* fb_send = nullptr;        // kFallbackBytes of zeros / world x kFallbackBytes: what a rank whose record buffers could not be
@@ -371,6 +379,9 @@ class ShardedBatchAlignerHip {
     const size_t rec = sizeof(apdgicp_result);
     const size_t mine = (size_t)(s.s_end - s.s_begin) * rec, block = (size_t)s.s_per * rec;
     bool gather_ok = s.send && s.recv && s.stage && block <= s.send_cap;
+    // this rank's communicator, read ONCE: abort_all (any worker thread) takes it out of the table with an atomic exchange before it
+    // aborts it -- a collective already inside RCCL with the old pointer is what ncclCommAbort exists to unblock
+    const ncclComm_t comm = comms_[(size_t)r].load();
     if (aborted_.load()) {  // the communicators are gone (abort_all): nothing to enter, the batch fails
       if (rc == 0) rc = APDGICP_ERR_HIP, msg = "the record gather was aborted";
       gather_ok = false;
@@ -394,7 +405,7 @@ class ShardedBatchAlignerHip {
       // every rank calls the collective, in ticket order; an empty or failed block contributes zeros
       if (block && world() == 1 && !gather_when_alone_) {  // one device: the "gather" is a copy
         if (hipMemcpyAsync(s.recv, s.send, block, hipMemcpyDeviceToDevice, k.gstream) != hipSuccess) gather_ok = false;
-      } else if (block && ncclAllGather(s.send, s.recv, block, ncclChar, comms_[(size_t)r], k.gstream) != ncclSuccess) {
+      } else if (block && (!comm || ncclAllGather(s.send, s.recv, block, ncclChar, comm, k.gstream) != ncclSuccess)) {
         gather_ok = false;
       }
     }
@@ -407,7 +418,7 @@ class ShardedBatchAlignerHip {
       // rank is marked dead, so that collect() returns an error everywhere instead of waiting.
       bool entered = (world() == 1 && !gather_when_alone_) || aborted_.load();
       if (!entered && block <= kFallbackBytes && k.fb_send && k.fb_recv)
-        entered = ncclAllGather(k.fb_send, k.fb_recv, block, ncclChar, comms_[(size_t)r], k.gstream) == ncclSuccess;
+        entered = comm && ncclAllGather(k.fb_send, k.fb_recv, block, ncclChar, comm, k.gstream) == ncclSuccess;
       if (!entered) abort_all("rank " + std::to_string(r) + ": could not enter the record gather");
     }
     if (!gather_ok && rc == 0) rc = APDGICP_ERR_HIP, msg = "record gather failed";
@@ -428,12 +439,14 @@ class ShardedBatchAlignerHip {
     std::lock_guard<std::mutex> ga(abort_mu_);
     if (aborted_.exchange(true)) return;
     std::fprintf(stderr, "[ShardedBatchAlignerHip] %s: aborting the communicators\n", why.c_str());
-    for (ncclComm_t& c : comms_)
-      if (c) (void)ncclCommAbort(c), c = nullptr;
-    for (auto& kp : ranks_) {
+    for (auto& a : comms_) {
+      const ncclComm_t c = a.exchange(nullptr);
+      if (c) (void)ncclCommAbort(c);
+    }
+    for (auto& kp : ranks_) {  // collect() stops waiting everywhere; the worker threads run on (their batches fail: aborted_) until shutdown
       {
         std::lock_guard<std::mutex> g(kp->mu);
-        kp->dead = true;
+        kp->aborted = true;
       }
       kp->cv.notify_all();
     }
@@ -503,7 +516,8 @@ class ShardedBatchAlignerHip {
   bool gather_when_alone_ = true;  // world size 1: still go through RCCL (set_gather_when_alone(false): a plain copy)
   apdgicp_params params_;
   std::vector<std::unique_ptr<Rank>> ranks_;
-  std::vector<ncclComm_t> comms_;
+  std::vector<ncclComm_t> comm_init_;             // as ncclCommInitAll filled it
+  std::vector<std::atomic<ncclComm_t>> comms_;    // the live table: abort_all empties it while workers read it
   uint64_t seq_ = 0;
   std::string error_, error_text_;
   std::mutex abort_mu_;

@@ -355,7 +355,6 @@ class Engine {
     if (bulk_host) e = hipHostFree(bulk_host);
     if (bulk_ev) e = hipEventDestroy(bulk_ev);
     bulk_dev.release();
-    host_pool.reset();
     if (h_poll) e = hipHostFree(h_poll);
     if (alt.h_poll) e = hipHostFree(alt.h_poll);
     if (alt.ev_poll) e = hipEventDestroy(alt.ev_poll);
@@ -396,7 +395,7 @@ class Engine {
     if (p->k_correspondences < 1) return fail(APDGICP_ERR_INVALID_ARG, "k_correspondences must be >= 1");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
-    if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
+    if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN | APDGICP_FLAG_FP32_POINT_MATH)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
     if (pool.on) APD_TRY(pool_drain());  // the batches in flight finish with the parameters they were enqueued with
     const bool cov_change = clouds.size() && (p->k_correspondences != params.k_correspondences || p->regularization != params.regularization);
     params = *p;
@@ -413,6 +412,7 @@ class Engine {
     c.optimizer = params.optimizer;
     c.regularization = params.regularization;
     c.plain_gicp = (params.flags & APDGICP_FLAG_PLAIN_GICP) ? 1 : 0;
+    c.fp32_point = (params.flags & APDGICP_FLAG_FP32_POINT_MATH) ? 1 : 0;
     c.thr2 = params.max_correspondence_distance * params.max_correspondence_distance;
     c.trans_eps = params.transformation_epsilon;
     c.rot_eps = params.rotation_epsilon;
@@ -508,7 +508,9 @@ class Engine {
           }
         });
     }
+    std::mutex run_mu;  // one run at a time (the pool is shared by every engine of the process)
     void run(int count, const std::function<void(int)>& f) {  // f(0 .. count - 1), the caller takes part; returns when all are done
+      std::lock_guard<std::mutex> run_lk(run_mu);
       {
         std::lock_guard<std::mutex> lk(m);
         fn = &f, n = count, busy = (int)th.size(), next.store(0, std::memory_order_relaxed), gen++;
@@ -527,7 +529,23 @@ class Engine {
       for (auto& t : th) t.join();
     }
   };
-  std::unique_ptr<HostPool> host_pool;
+  // ONE pool per process, created by the first batch of host clouds that wants it (APDGICP_HOST_THREADS is read then: a
+  // per-process setting) and shared by every engine: four bench handles or eight ShardedBatchAlignerHip handles per device each
+  // with three parked threads of their own were 12 - 24 idle threads.  run() is serialised by the pool's own mutex.
+  static HostPool* shared_host_pool(int* threads_out) {
+    static std::mutex mu;
+    static std::unique_ptr<HostPool> pool;
+    static int want = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!want) {
+      const char* e = getenv("APDGICP_HOST_THREADS");  // threads packing host clouds, the caller included (1: no pool)
+      const int hc = (int)std::thread::hardware_concurrency();
+      want = std::max(1, e ? atoi(e) : std::min(4, hc > 1 ? hc / 2 : 1));
+      if (want > 1) pool.reset(new HostPool()), pool->start(want - 1);
+    }
+    *threads_out = want;
+    return pool.get();
+  }
 
   struct HostStage {
     char* p = nullptr;
@@ -653,15 +671,11 @@ class Engine {
       dptr[q] = (const float*)((char*)bulk_dev.p + off);
       off += ((size_t)ns[q] + 2) * 16;
     }
-    static const int want = []() {
-      const char* e = getenv("APDGICP_HOST_THREADS");  // threads packing host clouds, the caller included (1: no pool)
-      const int hc = (int)std::thread::hardware_concurrency();
-      return std::max(1, e ? atoi(e) : std::min(4, hc > 1 ? hc / 2 : 1));
-    }();
-    if (want > 1) {
-      if (!host_pool) host_pool.reset(new HostPool()), host_pool->start(want - 1);
+    int want = 1;
+    HostPool* hp = shared_host_pool(&want);
+    if (hp) {
       const std::function<void(int)> f = [&](int i) { pack_staged_host(tasks[i].dst, tasks[i].raw, tasks[i].n, tasks[i].stride_bytes); };
-      host_pool->run(count, f);
+      hp->run(count, f);
     } else {
       for (const HostPackTask& t : tasks) pack_staged_host(t.dst, t.raw, t.n, t.stride_bytes);
     }
@@ -874,6 +888,7 @@ class Engine {
   }
 
   // calculate_covariances for every listed cloud that lacks them (A:122-127, A:303-363)
+  bool warned_select = false;
   bool defer_errflag = false;  // set by the align paths: the flag is then read together with the final status
   int compute_covariances(const std::vector<int>& ids_in, bool force = false) {
     std::vector<int> ids;
@@ -922,8 +937,18 @@ class Engine {
     long long total = 0;
     for (int i = 0; i < count; i++) nmax = std::max(nmax, clouds[ids[i]].n), total += clouds[ids[i]].n;
     if (params.k_correspondences > 2 * KNN_NC) {  // any k: selection by bisection, no lists (for experiments: ~35 sweeps of the cloud per query block)
-      hipLaunchKernelGGL(k_knn_cov_select, dim3((unsigned)((nmax + SEL_Q - 1) / SEL_Q), (unsigned)count), dim3(64), 0, st, d_desc.as<CloudDesc>(), d_list,
-                         params.k_correspondences, params.regularization, d_errflag.as<int>());
+      // O(n^2): a block of SEL_Q queries sweeps its cloud ~35 times.  One dispatch over a 500k-point submap would run for seconds and
+      // hold the device queue of every handle; the launch is cut into dispatches of at most ~2^34 point visits (~10 ms) each
+      const long long blocks = (nmax + SEL_Q - 1) / SEL_Q;
+      const long long per = std::max<long long>(1, std::min<long long>(blocks, (1ll << 34) / (36ll * std::max(1, nmax) * std::max(1, count))));
+      if (blocks > per && !warned_select) {
+        warned_select = true;
+        std::fprintf(stderr, "[apdgicp] k_correspondences = %d > 64 on a cloud of %d points: the selection kernel is O(n^2) (%lld dispatches of ~10 ms)\n",
+                     params.k_correspondences, nmax, (blocks + per - 1) / per);
+      }
+      for (long long b0 = 0; b0 < blocks; b0 += per)
+        hipLaunchKernelGGL(k_knn_cov_select, dim3((unsigned)std::min(per, blocks - b0), (unsigned)count), dim3(64), 0, st, d_desc.as<CloudDesc>(), d_list,
+                           params.k_correspondences, params.regularization, d_errflag.as<int>(), (int)b0);
     } else if (knn_pruned && params.k_correspondences <= KNN_NC) {
       // queries per wave = 64 / lanes per query: fewer queries per wave shorten the per-wave dependency chain and shrink its LDS
       // lists, which wins whenever the GPU is not already full (r01, 2 clouds of 8k: 0.10 / 0.13 / 0.21 ms for 4 / 8 / 16)
@@ -1184,9 +1209,14 @@ class Engine {
     Work w = t_work();
     w.pair0 = sp.p0;
     w.init = init_tick && mode == 2 ? d_guess.as<Rigid>() : nullptr;
-    if (mode == 2)
+    const bool f32 = (params.flags & APDGICP_FLAG_FP32_POINT_MATH) != 0;
+    if (mode == 2 && f32)
+      hipLaunchKernelGGL((k_linearize<true, true>), grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, consts(), mode);
+    else if (mode == 2)
       hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
                          consts(), mode);
+    else if (f32)
+      hipLaunchKernelGGL((k_linearize<false, true>), grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, consts(), mode);
     else
       hipLaunchKernelGGL(k_linearize<false>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
                          consts(), mode);
@@ -1598,6 +1628,11 @@ class Engine {
     pool.nmax_tgt = std::max(pool.nmax_tgt, ntgt);
     if (pool.layout_valid && n <= pool.segcap && nsrc <= pool.nmax_src) return 0;
     APD_TRY(pool_drain());
+    // every stream that may still run a poll or a no-op tick of the old layout (list 1 ticks on gstreams[0], a list that ticks alone
+    // is sliced onto gstreams[1]): the pinned headers are wiped and the list buffers possibly re-allocated below
+    for (Pool::List& li : pool.L)
+      if (li.st) APD_HIP(hipStreamSynchronize(li.st));
+    if (gstreams.size() > 1) APD_HIP(hipStreamSynchronize(gstreams[1]));
     APD_HIP(hipStreamSynchronize(stream));
     const int segcap = std::max(pool.segcap, n);
     const int nmax = std::max(pool.nmax_src, nsrc);

@@ -65,6 +65,7 @@ struct PairDesc {
 struct Consts {
   int k, max_iterations, lm_max_iterations, optimizer, regularization;
   int plain_gicp;    // APDGICP_FLAG_PLAIN_GICP: no APD covariance (upstream FastGICP cost)
+  int fp32_point;    // APDGICP_FLAG_FP32_POINT_MATH: the per-point algebra behind the search in fp32 (k_linearize<.., true>, k_error<true>)
   double thr2;       // corr_dist_threshold_^2 in double (A:156)
   double trans_eps, rot_eps, lm_init_lambda_factor;
   double dist_var_400, sin_az, sin_el;  // A:169-171: distance_variance / 400, sin(azimuth variance), sin(elevation variance)
@@ -302,6 +303,24 @@ __global__ void k_export_corr(const int* corr, const float* sqd, const int* perm
   if (out_sqd) out_sqd[o] = sqd[s];
 }
 
+// the ungated nearest neighbour of every source point as the last search + per-point pass left it (Work::nnpt: sorted target
+// index in .w, -1: none; Work::sqd), in the caller's indexing -- apdgicp_nearest_neighbours
+__global__ void k_export_nn(const float4* nnpt, const float* sqd, const int* perm_src, const int* perm_tgt, int n, int* out_idx, float* out_sqd) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int o = perm_src[s], j = __float_as_int(nnpt[s].w);
+  out_idx[o] = j >= 0 ? perm_tgt[j] : -1;
+  out_sqd[o] = sqd[s];
+}
+
+// caller's order: n x {x, y, z} floats out of a cloud's float4 copy (apdgicp_get_points)
+__global__ void k_unpack_points(const float4* opts, int n, float* out3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = opts[i];
+  out3[3 * i] = p.x, out3[3 * i + 1] = p.y, out3[3 * i + 2] = p.z;
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_knn_cov: exact k nearest neighbours of every point inside its own cloud (self included), then
 // population covariance and regularisation.  One thread per query, candidates streamed through
@@ -528,10 +547,10 @@ __global__ __launch_bounds__(KNN_BLK) void k_knn_cov(const CloudDesc* clouds, co
 // below the k-th.  About 35 sweeps of the cloud per SEL_Q queries: for experiments with k = 65 ... n, not for 10 Hz.  Exact, and
 // in the (distance, original index) order of every other covariance kernel; the sums run in curve order (compared by tolerance).
 constexpr int SEL_Q = 4;
-__global__ __launch_bounds__(64) void k_knn_cov_select(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag) {
+__global__ __launch_bounds__(64) void k_knn_cov_select(const CloudDesc* clouds, const int* cloud_ids, int k, int reg, int* err_flag, int block0) {
   const CloudDesc c = clouds[cloud_ids[blockIdx.y]];
   const int n = c.n, lane = threadIdx.x;
-  const int i0 = (int)blockIdx.x * SEL_Q;
+  const int i0 = (block0 + (int)blockIdx.x) * SEL_Q;  // (block0: the launch is cut into dispatches of bounded duration, Engine::launch_knn)
   if (i0 >= n) return;
   const float4* pts = G(c.pts);
   float qx[SEL_Q], qy[SEL_Q], qz[SEL_Q];
@@ -2427,6 +2446,166 @@ __device__ __forceinline__ double lin_term(const LinPoint& lp, int want_Hb, int 
   }
 }
 
+// ---- APDGICP_FLAG_FP32_POINT_MATH (opt-in): the same per-point algebra in fp32.  SURVEY.md 7 (hard part 5) measured what the
+// reference's fp64 buys behind the fp32 search: nothing the tolerance can see (poses move by ~1e-6 m) -- except in 1 / cos(AoA),
+// which cancels near the +-x axis, in the sums over the points and in the 6x6 solve.  So: the three fp32 angles as always; cos(AoA)
+// and its reciprocal in fp64; sin / cos of elevation and azimuth, A A^T, RCR, its inverse, e, M e and every J^T M J term in fp32
+// (contracted); each point's 29 terms are widened to fp64 before the block reduction, which, like the optimiser step, is unchanged.
+__device__ __forceinline__ void sincos_pi_f32(float x, float* so, float* co) {  // |x| <= pi (an atan2f result): Cody-Waite in two steps, minimax kernels on [-pi/4, pi/4]
+  const float fn = rintf(x * 6.36619747e-01f);
+  float r = fmaf(-fn, 1.57079637e+00f, x);   // pi/2 = 0x1.921fb6p+0 - 4.37113900e-8 (fn in -2 .. 2: both products are exact)
+  r = fmaf(-fn, -4.37113900e-08f, r);
+  const float z = r * r;                      // (cephes sinf / cosf kernels: 7e-8 absolute over [-pi, pi])
+  const float s = fmaf(r * z, fmaf(z, fmaf(z, -1.95152959e-04f, 8.33216087e-03f), -1.66666546e-01f), r);
+  const float c = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 2.44331571e-05f, -1.38873163e-03f), 4.16666457e-02f), -0.5f), 1.0f);
+  const int n = (int)fn;
+  const float sv = (n & 1) ? c : s, cv = (n & 1) ? s : c;
+  *so = (n & 2) ? -sv : sv;
+  *co = ((n + 1) & 2) ? -cv : cv;
+}
+struct Sym3f {
+  float xx, xy, xz, yy, yz, zz;
+};
+struct LinPointF {
+  Sym3f Mi;
+  float vx, vy, vz, mex, mey, mez, cost, matched;
+};
+__device__ __forceinline__ void linearize_point_f32(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst, int pair, int i,
+                                                    const float4 p, float ptx, float pty, float ptz, float m, unsigned chunk, bool tie, bool kept,
+                                                    const float4 tq_rec, const Sym3& cov_A, LinPointF& lp, const float* atan_tab) {
+  const int M = tgt.n;
+  int j = -1;
+  float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kept) {
+    tq = tq_rec;
+    j = __float_as_int(tq.w);
+  } else if (chunk != kNoChunk) {  // (as linearize_point: only brute-force search results reach the re-scan)
+    int jorig = 0x7fffffff;
+    const int g0 = tie ? 0 : (int)chunk * kChunk, g1 = tie ? M : min(g0 + kChunk, M);
+    for (int g = g0; g < g1; g++) {
+      const float4 t = tgt.pts[g];
+      if (sqdist1(t.x, t.y, t.z, ptx, pty, ptz) == m) {
+        const int o = __float_as_int(t.w);
+        if (o < jorig) jorig = o, j = g, tq = t;
+      }
+    }
+  }
+  if (w.sqd) w.sqd[(size_t)pair * w.nstride + i] = m;
+  if (!kept) w.nnpt[(size_t)pair * w.nstride + i] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+  const int corr = (j >= 0 && (double)m < cst.thr2) ? j : -1;  // A:156
+  if (w.corr) w.corr[(size_t)pair * w.nstride + i] = corr;
+  if (corr < 0) return;
+  const auto cb = G((const double*)tgt.cov);
+  const Sym3f cB{(float)cb[corr], (float)cb[M + corr], (float)cb[2 * M + corr], (float)cb[3 * M + corr], (float)cb[4 * M + corr], (float)cb[5 * M + corr]};
+  const Sym3f cA{(float)cov_A.xx, (float)cov_A.xy, (float)cov_A.xz, (float)cov_A.yy, (float)cov_A.yz, (float)cov_A.zz};
+  float aoa_f, el_f, az_f;
+  {
+#pragma clang fp contract(off)
+    aoa_f = apd_atan2f_tab(ptx, sqrtf(pty * pty + ptz * ptz), atan_tab);
+    el_f = apd_atan2f_tab(sqrtf(ptx * ptx + pty * pty), ptz, atan_tab);
+    az_f = apd_atan2f_tab(pty, ptx, atan_tab);
+  }
+  double sin_aoa, cos_aoa;
+  sincos_pi((double)aoa_f, &sin_aoa, &cos_aoa);  // fp64: cos(AoA) cancels near the +-x axis, and its reciprocal scales two of the three sigmas
+  (void)sin_aoa;
+  const float dist = sqrtf(ptx * ptx + pty * pty + ptz * ptz);
+  const float dist_c = (float)((double)dist / cos_aoa);
+  const float s_x = dist * (float)cst.dist_var_400, s_y = dist_c * (float)cst.sin_az, s_z = dist_c * (float)cst.sin_el;
+  float ce, se, caz, saz;
+  sincos_pi_f32(el_f, &se, &ce);
+  sincos_pi_f32(az_f, &saz, &caz);
+  const float a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
+  const float a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
+  const float a20 = -se * s_x, a22 = ce * s_z;
+  Sym3f cd{a00 * a00 + a01 * a01 + a02 * a02, a00 * a10 + a01 * a11 + a02 * a12, a00 * a20 + a02 * a22, a10 * a10 + a11 * a11 + a12 * a12, a10 * a20 + a12 * a22,
+           a20 * a20 + a22 * a22};
+  if (cst.plain_gicp) cd = Sym3f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float Rf[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c2 = 0; c2 < 3; c2++) Rf[3 * r + c2] = (float)T.m[4 * r + c2];
+  const Sym3f sA{cA.xx + cd.xx, cA.xy + cd.xy, cA.xz + cd.xz, cA.yy + cd.yy, cA.yz + cd.yz, cA.zz + cd.zz};
+  float rc[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const float a = Rf[3 * r], b = Rf[3 * r + 1], d = Rf[3 * r + 2];
+    rc[3 * r + 0] = a * sA.xx + b * sA.xy + d * sA.xz;
+    rc[3 * r + 1] = a * sA.xy + b * sA.yy + d * sA.yz;
+    rc[3 * r + 2] = a * sA.xz + b * sA.yz + d * sA.zz;
+  }
+  Sym3f RCR;  // (cov_B + cd) + R (cov_A + cd) R^T, A:188
+  RCR.xx = (cB.xx + cd.xx) + (rc[0] * Rf[0] + rc[1] * Rf[1] + rc[2] * Rf[2]);
+  RCR.xy = (cB.xy + cd.xy) + (rc[0] * Rf[3] + rc[1] * Rf[4] + rc[2] * Rf[5]);
+  RCR.xz = (cB.xz + cd.xz) + (rc[0] * Rf[6] + rc[1] * Rf[7] + rc[2] * Rf[8]);
+  RCR.yy = (cB.yy + cd.yy) + (rc[3] * Rf[3] + rc[4] * Rf[4] + rc[5] * Rf[5]);
+  RCR.yz = (cB.yz + cd.yz) + (rc[3] * Rf[6] + rc[4] * Rf[7] + rc[5] * Rf[8]);
+  RCR.zz = (cB.zz + cd.zz) + (rc[6] * Rf[6] + rc[7] * Rf[7] + rc[8] * Rf[8]);
+  const float c00 = RCR.yy * RCR.zz - RCR.yz * RCR.yz, c01 = RCR.yz * RCR.xz - RCR.xy * RCR.zz, c02 = RCR.xy * RCR.yz - RCR.yy * RCR.xz;
+  const float id = 1.0f / (RCR.xx * c00 + RCR.xy * c01 + RCR.xz * c02);
+  Sym3f Mi{c00 * id, c01 * id, c02 * id, (RCR.xx * RCR.zz - RCR.xz * RCR.xz) * id, (RCR.xy * RCR.xz - RCR.xx * RCR.yz) * id, (RCR.xx * RCR.yy - RCR.xy * RCR.xy) * id};
+  if (w.maha) {  // (the Mahalanobis getter and compute_error read fp64: widened here)
+    double* mo = w.maha + (size_t)pair * 6 * w.nstride + i;
+    mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
+    mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
+  }
+  // transed_mean_A and e (A:236-237), fp32 like the search's own T * p (the residual of a point 100 m away carries ~1e-5 m of
+  // rounding, random in sign over thousands of points)
+  const float tf[3] = {(float)T.m[3], (float)T.m[7], (float)T.m[11]};
+  const float vx = Rf[0] * p.x + Rf[1] * p.y + Rf[2] * p.z + tf[0];
+  const float vy = Rf[3] * p.x + Rf[4] * p.y + Rf[5] * p.z + tf[1];
+  const float vz = Rf[6] * p.x + Rf[7] * p.y + Rf[8] * p.z + tf[2];
+  const float ex = tq.x - vx, ey = tq.y - vy, ez = tq.z - vz;
+  lp.Mi = Mi;
+  lp.vx = vx, lp.vy = vy, lp.vz = vz;
+  lp.mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
+  lp.mey = Mi.xy * ex + Mi.yy * ey + Mi.yz * ez;
+  lp.mez = Mi.xz * ex + Mi.yz * ey + Mi.zz * ez;
+  lp.cost = ex * lp.mex + ey * lp.mey + ez * lp.mez;
+  lp.matched = 1.0f;
+}
+__device__ __forceinline__ double lin_term_f32(const LinPointF& lp, int want_Hb, int r) {
+  const Sym3f& Mi = lp.Mi;
+  const float vx = lp.vx, vy = lp.vy, vz = lp.vz, mex = lp.mex, mey = lp.mey, mez = lp.mez;
+  if (r == 27) return (double)lp.cost;
+  if (r == 28) return (double)lp.matched;
+  if (!want_Hb) return 0.0;
+  const float m0x = Mi.xy * vz - Mi.xz * vy, m0y = Mi.yy * vz - Mi.yz * vy, m0z = Mi.yz * vz - Mi.zz * vy;
+  const float m1x = -Mi.xx * vz + Mi.xz * vx, m1y = -Mi.xy * vz + Mi.yz * vx, m1z = -Mi.xz * vz + Mi.zz * vx;
+  const float m2x = Mi.xx * vy - Mi.xy * vx, m2y = Mi.xy * vy - Mi.yy * vx, m2z = Mi.xz * vy - Mi.yz * vx;
+  float v;
+  switch (r) {
+    case 0: v = vz * m0y - vy * m0z; break;
+    case 1: v = vz * m1y - vy * m1z; break;
+    case 2: v = vz * m2y - vy * m2z; break;
+    case 3: v = -m0x; break;
+    case 4: v = -m0y; break;
+    case 5: v = -m0z; break;
+    case 6: v = -vz * m1x + vx * m1z; break;
+    case 7: v = -vz * m2x + vx * m2z; break;
+    case 8: v = -m1x; break;
+    case 9: v = -m1y; break;
+    case 10: v = -m1z; break;
+    case 11: v = vy * m2x - vx * m2y; break;
+    case 12: v = -m2x; break;
+    case 13: v = -m2y; break;
+    case 14: v = -m2z; break;
+    case 15: v = Mi.xx; break;
+    case 16: v = Mi.xy; break;
+    case 17: v = Mi.xz; break;
+    case 18: v = Mi.yy; break;
+    case 19: v = Mi.yz; break;
+    case 20: v = Mi.zz; break;
+    case 21: v = vz * mey - vy * mez; break;
+    case 22: v = -vz * mex + vx * mez; break;
+    case 23: v = vy * mex - vx * mey; break;
+    case 24: v = -mex; break;
+    case 25: v = -mey; break;
+    default: v = -mez; break;
+  }
+  return (double)v;
+}
+
 #pragma clang fp contract(off)
 // ---- end of the fp64 contraction region
 
@@ -2488,7 +2667,7 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 #ifndef APD_LIN_WPE
 #define APD_LIN_WPE 7  // fused kernel: ask for 7 waves per SIMD (71 registers, no scratch; what the LDS of 7 blocks per CU allows): 0.7435 -> 0.7402 ms per step against 6
 #endif
-template <bool FUSED>
+template <bool FUSED, bool F32 = false>
 __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ? APD_LIN_WPE : 1, 8))) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
@@ -2505,9 +2684,15 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
   if ((int)(bx * LIN_BLK) >= N) return;
   const int i = (int)bx * LIN_BLK + tid;
 
-  LinPoint lp;
-  lp.Mi = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
+  using LP = std::conditional_t<F32, LinPointF, LinPoint>;
+  LP lp;
+  if constexpr (F32) {
+    lp.Mi = Sym3f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.f;
+  } else {
+    lp.Mi = Sym3{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
+  }
   __shared__ float s_atan[APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE];
   atan_tab_to_lds(s_atan, tid);
   __syncthreads();  // (every exit above is taken by the whole block)
@@ -2542,10 +2727,14 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     float Tf[12];
     load_Tf(T, Tf);
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), pty = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), ptz = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
-    linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
+    if constexpr (F32) linearize_point_f32(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
+    else linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
-  block_reduce_lds<29, LIN_BLK>([&](int r) { return lin_term(lp, want_Hb, r); }, red, red_scratch, tid);
+  block_reduce_lds<29, LIN_BLK>([&](int r) {
+    if constexpr (F32) return lin_term_f32(lp, want_Hb, r);
+    else return lin_term(lp, want_Hb, r);
+  }, red, red_scratch, tid);
   if (tid < 29) {
     double s = 0.0;
 #pragma unroll

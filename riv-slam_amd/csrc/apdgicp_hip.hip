@@ -585,6 +585,51 @@ int apdgicp_inlier_fraction(apdgicp_handle* h, const float T[16], double max_cor
   });
 }
 
+int apdgicp_nearest_neighbours(apdgicp_handle* h, const float T[16], int32_t* index, float* sq_dist, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h || !T || !index || !sq_dist) return fail(APDGICP_ERR_INVALID_ARG, "null argument");
+    APD_TRY(ensure_pair(h));
+    Engine& e = h->eng;
+    if (n != e.clouds[kSrc].n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the source size");
+    double T16[16], cost = 0.0;
+    for (int q = 0; q < 16; q++) T16[q] = (double)T[q];
+    APD_TRY(e.probe_linearize(T16, nullptr, nullptr, &cost, nullptr));  // search (ungated, cold) + the per-point pass that settles the exact index
+    h->have_corr = true;
+    APD_TRY(e.d_stage.ensure((size_t)n * 8));
+    int* d_i = e.d_stage.as<int>();
+    float* d_s = (float*)(d_i + n);
+    hipLaunchKernelGGL(k_export_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.work.nnpt, e.work.sqd, e.clouds[kSrc].perm.as<int>(),
+                       e.clouds[kTgt].perm.as<int>(), (int)n, d_i, d_s);
+    APD_HIP(hipMemcpyAsync(index, d_i, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipMemcpyAsync(sq_dist, d_s, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_get_points(apdgicp_handle* h, int which, float* out_xyz, int64_t n) {
+  return guarded([&]() -> int {
+    if (!h || !out_xyz || (which != kSrc && which != kTgt)) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    Engine& e = h->eng;
+    Engine::Cloud& c = e.clouds[which];
+    if (c.n <= 0) return fail(APDGICP_ERR_NO_INPUT, "cloud not set");
+    if (n != c.n) return fail(APDGICP_ERR_INVALID_ARG, "n does not match the cloud size");
+    APD_HIP(hipSetDevice(e.device));
+    if (c.staged) {  // a scan-sized host cloud still waiting in its pinned buffer for the sort: the float4 copy is right there
+      const float4* p = (const float4*)c.stage_p;
+      for (int64_t i = 0; i < n; i++) out_xyz[3 * i] = p[i].x, out_xyz[3 * i + 1] = p[i].y, out_xyz[3 * i + 2] = p[i].z;
+      return 0;
+    }
+    APD_TRY(e.upload_desc());  // (sorts what is not sorted yet: a staged cloud's opts are written by its sort)
+    APD_HIP(hipStreamSynchronize(e.stream));
+    APD_TRY(e.d_stage.ensure((size_t)n * 12));
+    hipLaunchKernelGGL(k_unpack_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, c.opts.as<float4>(), (int)n, e.d_stage.as<float>());
+    APD_HIP(hipMemcpyAsync(out_xyz, e.d_stage.p, (size_t)n * 12, hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
 int apdgicp_wait_producer(apdgicp_handle* h, void* producer_stream) {
   if (!h) return fail(APDGICP_ERR_INVALID_ARG, "handle is null");
   return h->eng.wait_producer(producer_stream);
@@ -1040,7 +1085,17 @@ int apdgicp_submap_assemble(apdgicp_submap* s, int n_clouds, const void* const* 
     APD_HIP(hipGetLastError());
     APD_HIP(hipMemcpyAsync(s->h_scal, d_total, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     APD_HIP(hipStreamSynchronize(s->stream));
-    if (s->h_scal[1] == 5) return fail(APDGICP_ERR_UNSUPPORTED, "leaf size is too small for the extent of the submap (voxel index overflows int32)");
+    if (s->h_scal[1] == 5) {
+      // pcl::VoxelGrid::applyFilter (filters/impl/voxel_grid.hpp): "Leaf size is too small for the input dataset. Integer indices would
+      // overflow." is a WARNING there and the output is the input cloud, unfiltered -- so is it here: the assembled (transformed,
+      // concatenated) cloud itself, the same line on stderr, success; apdgicp_last_error() holds the message.
+      std::fprintf(stderr, "[apdgicp_submap_assemble] Leaf size is too small for the input dataset. Integer indices would overflow.\n");
+      g_last_error = "leaf size is too small for the extent of the submap (voxel index overflows int32): the unfiltered cloud is returned, like pcl::VoxelGrid";
+      APD_HIP(hipMemsetAsync(d_err, 0, sizeof(int), s->stream));
+      s->n_last = n, s->last_is_cat = true;
+      *n_out = n;
+      return 0;
+    }
     if (s->h_scal[1]) return fail(APDGICP_ERR_INTERNAL, "voxel filter failed");
     s->n_last = s->h_scal[0], s->last_is_cat = false;
     *n_out = s->n_last;

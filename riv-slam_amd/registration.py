@@ -24,6 +24,7 @@ REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = 0, 1, 
 OPT_LM, OPT_GN = 0, 1
 FLAG_PLAIN_GICP = 1  # upstream fast_gicp::FastGICP cost (no APD covariance)
 FLAG_XF_LINEAR_CHAIN = 2  # T*p summed ((r0 x + r1 y) + r2 z) + t like Eigen 3.2 instead of pairwise like Eigen >= 3.3 (include/apdgicp_hip.h)
+FLAG_FP32_POINT_MATH = 4  # opt-in: the per-point algebra behind the search in fp32 (include/apdgicp_hip.h); not the reference's precision
 SOURCE, TARGET = 0, 1
 
 
@@ -81,7 +82,7 @@ assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 96
 # every symbol include/apdgicp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "apdgicp_abi_version", "apdgicp_source_stamp", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
-    "apdgicp_set_trace", "apdgicp_get_trace", "apdgicp_debug_atan2f",
+    "apdgicp_set_trace", "apdgicp_get_trace", "apdgicp_debug_atan2f", "apdgicp_nearest_neighbours", "apdgicp_get_points",
     "apdgicp_create", "apdgicp_destroy", "apdgicp_set_params", "apdgicp_get_params",
     "apdgicp_set_source", "apdgicp_set_target", "apdgicp_clear_source", "apdgicp_clear_target",
     "apdgicp_swap_source_and_target", "apdgicp_compute_covariances", "apdgicp_get_covariances",
@@ -153,6 +154,8 @@ def load_library(path: str | None = None):
     L.apdgicp_set_trace.argtypes = [vp, i32]
     L.apdgicp_get_trace.argtypes = [vp, i64, vp, vp, vp, vp, C.POINTER(i64), i64, vp, C.POINTER(i64)]
     L.apdgicp_debug_atan2f.argtypes = [i32, vp, vp, vp, i64]
+    L.apdgicp_nearest_neighbours.argtypes = [vp, vp, vp, vp, i64]
+    L.apdgicp_get_points.argtypes = [vp, i32, vp, i64]
     L.apdgicp_transform_source.argtypes = [vp, vp, vp, i64, i64]
     L.apdgicp_fitness_score.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
     L.apdgicp_inlier_fraction.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
@@ -501,6 +504,21 @@ class FastAPDGICP:
         _check(self.L.apdgicp_fitness_score(self.h, _ptr(Tc), max_range, C.byref(score), C.byref(cnt)))
         self.last_inliers = cnt.value
         return score.value
+
+    def nearestNeighbours(self, T=None):
+        """(index, sq_dist) of the nearest target point of every T-transformed source point (T: the last pose by default): one
+        batched device search, what pcl::search::KdTree::nearestKSearch(pt, 1, ...) returns point by point."""
+        Tc = _colmajor(self._final if T is None else T, np.float32)
+        idx = np.empty(self.n_src, dtype=np.int32)
+        sqd = np.empty(self.n_src, dtype=np.float32)
+        _check(self.L.apdgicp_nearest_neighbours(self.h, _ptr(Tc), _ptr(idx), _ptr(sqd), self.n_src))
+        return idx, sqd
+
+    def getPoints(self, which) -> np.ndarray:
+        n = self._n(which)
+        out = np.empty((n, 3), dtype=np.float32)
+        _check(self.L.apdgicp_get_points(self.h, which, _ptr(out), n))
+        return out
 
     def stream_ptr(self) -> int:
         st = C.c_void_p()

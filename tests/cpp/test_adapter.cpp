@@ -121,10 +121,11 @@ static int run_protocols(const float* s, int ns, const float* t, int nt, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// What PCL's align() adds in front of the GPU path: initCompute() rebuilds the base class's search tree for every NEW target
-// (tests/pcl_shim models it: KdTree::n_builds).  Default: one build per new target, none for a pointer-equal one, and the
-// base-class getFitnessScore() agrees with the device's fitnessScore().  setSkipBaseSearchTree(true): no build at all, the
-// base-class score goes stale (it still answers about the last tree), the device score follows the real target.
+// The base-class calls of the nodelets -- getFitnessScore() and getSearchMethodTarget()->nearestKSearch(aligned[i], 1, ...) --
+// through the search object the adapter installs (FastAPDGICPHip::DeviceSearch): no CPU kd-tree build ever (the shim counts them,
+// pcl::search::kdtree_builds_total()), answers from one batched device search per pose.  Then PCL's own tree
+// (setUseDeviceSearch(false)): what pcl::Registration::initCompute() adds in front of the GPU path -- one build per NEW target --
+// and the setSkipBaseSearchTree opt-out of round 4.
 static int run_base_tree(const float* s, int ns, const float* t, int nt, const float* guess) {
   using Reg = fast_gicp::FastAPDGICPHip<PointT, PointT>;
   auto registration = select_registration_method_hip();
@@ -136,28 +137,51 @@ static int run_base_tree(const float* s, int ns, const float* t, int nt, const f
   pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
   pcl::Registration<PointT, PointT>::Matrix4 g;
   for (int i = 0; i < 16; i++) g.data()[i] = guess[i];
-  auto builds = [&]() { return registration->getSearchMethodTarget()->n_builds; };
+  auto builds = [&]() { return pcl::search::kdtree_builds_total(); };
+  // ---- default: the device search object
+  const int uses_device = reg.usesDeviceSearch() ? 1 : 0;
   registration->setInputSource(source);
   registration->setInputTarget(A), registration->align(*aligned, g);
-  const int b1 = builds();
-  registration->setInputTarget(A), registration->align(*aligned, g);   // pointer-equal keyframe: cached on both sides
-  const int b2 = builds();
-  registration->setInputTarget(B), registration->align(*aligned, g);   // a new target object: PCL rebuilds its tree
-  const int b3 = builds();
-  const double f_pcl = registration->getFitnessScore(4.0), f_dev = reg.fitnessScore(4.0);
-  reg.setSkipBaseSearchTree(true);
-  registration->setInputTarget(D), registration->align(*aligned, g);   // new target, shifted by 0.7 m: no build
-  const int b4 = builds();
-  const int conv_skip = registration->hasConverged() ? 1 : 0;
-  const double f_pcl_stale = registration->getFitnessScore(4.0), f_dev_skip = reg.fitnessScore(4.0);
-  const bool tree_is_stale = registration->getSearchMethodTarget()->getInputCloud() == B;
-  reg.setSkipBaseSearchTree(false);
-  registration->setInputTarget(E), registration->align(*aligned, g);
-  const int b5 = builds();
-  const double f_pcl_back = registration->getFitnessScore(4.0), f_dev_back = reg.fitnessScore(4.0);
-  // a device-resident target: the base class only ever sees the far-away one-point placeholder
+  registration->setInputTarget(A), registration->align(*aligned, g);   // pointer-equal keyframe
+  registration->setInputTarget(B), registration->align(*aligned, g);   // a new target object
+  const int d_builds = builds();
+  const double d_f_pcl = registration->getFitnessScore(4.0), d_f_dev = reg.fitnessScore(4.0);       // loop_detector.cpp:229
+  const double d_f_pcl_all = registration->getFitnessScore(), d_f_dev_all = reg.fitnessScore();
+  // scan_matching_odometry_nodelet.cpp:697-712, verbatim
+  const double max_correspondence_dist = 0.5;
+  int num_inliers = 0;
+  std::vector<int> k_indices;
+  std::vector<float> k_sq_dists;
+  for (int i = 0; i < (int)aligned->size(); i++) {
+    const auto& pt = aligned->at(i);
+    registration->getSearchMethodTarget()->nearestKSearch(pt, 1, k_indices, k_sq_dists);
+    if (k_sq_dists[0] < max_correspondence_dist * max_correspondence_dist) num_inliers++;
+  }
+  const double d_inl_nodelet = static_cast<float>(num_inliers) / aligned->size(), d_inl_dev = reg.inlierFraction(0.5);
+  const long d_passes = reg.deviceSearchStats().batched_passes, d_served = reg.deviceSearchStats().served, d_fb0 = reg.deviceSearchStats().fallbacks;
+  // a query that is no transformed source point, and k = 5: the exact host scan; checked against a scan written here
+  PointT probe;
+  probe.x = t[0] + 0.013f, probe.y = t[1] - 0.021f, probe.z = t[2] + 0.004f;
+  std::vector<int> pi;
+  std::vector<float> pd;
+  const int got1 = registration->getSearchMethodTarget()->nearestKSearch(probe, 1, pi, pd);
+  int bi = -1;
+  float bd = 1e30f;
+  for (int j = 0; j < nt; j++) {
+    const float dx = probe.x - t[3 * j], dy = probe.y - t[3 * j + 1], dz = probe.z - t[3 * j + 2];
+    float d = dx * dx;
+    d = d + dy * dy;
+    d = d + dz * dz;
+    if (d < bd) bd = d, bi = j;
+  }
+  const int foreign_ok = got1 == 1 && pi[0] == bi && pd[0] == bd;
+  const int got5 = registration->getSearchMethodTarget()->nearestKSearch(probe, 5, pi, pd);
+  const int k5_ok = got5 == 5 && pi[0] == bi && pd[0] <= pd[1] && pd[1] <= pd[2] && pd[2] <= pd[3] && pd[3] <= pd[4];
+  const long d_fb1 = reg.deviceSearchStats().fallbacks;
+  // a device-resident target: the base class answers about the REAL target now
   apdgicp_submap* sm = nullptr;
-  double f_pcl_placeholder = -1.0, f_pcl_placeholder_unbounded = -1.0, f_dev_device_target = -1.0;
+  double d_f_pcl_devtgt = -1.0, d_f_dev_devtgt = -1.0;
+  int devtgt_foreign_ok = 0;
   if (apdgicp_submap_create(0, nullptr, &sm) == 0) {
     const void* xyz[1] = {&E->at(0).x};
     const int64_t cnt[1] = {(int64_t)E->size()};
@@ -166,12 +190,61 @@ static int run_base_tree(const float* s, int ns, const float* t, int nt, const f
     if (apdgicp_submap_assemble(sm, 1, xyz, cnt, sizeof(PointT), 16, 0, nullptr, nullptr, &m) == 0 && apdgicp_submap_points(sm, &dev, &m) == 0) {
       reg.setInputTargetDevice(dev, (std::size_t)m, 16);
       registration->align(*aligned, g);
+      d_f_pcl_devtgt = registration->getFitnessScore(4.0), d_f_dev_devtgt = reg.fitnessScore(4.0);
+      const int gq = registration->getSearchMethodTarget()->nearestKSearch(probe, 1, pi, pd);   // (the target is fetched from the device once)
+      devtgt_foreign_ok = gq == 1 && pi[0] == bi && pd[0] == bd;
+    }
+  }
+  const int d_builds_end = builds();
+  // an empty source cloud: the device side holds no source, the next align fails loudly instead of registering the previous one
+  pcl::PointCloud<PointT>::ConstPtr empty(new pcl::PointCloud<PointT>());
+  registration->setInputTarget(A);
+  registration->setInputSource(empty);
+  registration->align(*aligned, g);
+  const int empty_converged = registration->hasConverged() ? 1 : 0;
+  registration->setInputSource(source);
+  registration->align(*aligned, g);
+  const int back_converged = registration->hasConverged() ? 1 : 0;
+
+  // ---- PCL's own tree
+  reg.setUseDeviceSearch(false);
+  const int c0 = builds();
+  registration->setInputTarget(B), registration->align(*aligned, g);
+  const int b1 = builds() - c0;
+  registration->setInputTarget(B), registration->align(*aligned, g);   // pointer-equal keyframe: cached on both sides
+  const int b2 = builds() - c0;
+  registration->setInputTarget(A), registration->align(*aligned, g);   // a new target object: PCL rebuilds its tree
+  const int b3 = builds() - c0;
+  const double f_pcl = registration->getFitnessScore(4.0), f_dev = reg.fitnessScore(4.0);
+  reg.setSkipBaseSearchTree(true);
+  registration->setInputTarget(D), registration->align(*aligned, g);   // new target, shifted by 0.7 m: no build
+  const int b4 = builds() - c0;
+  const int conv_skip = registration->hasConverged() ? 1 : 0;
+  const double f_pcl_stale = registration->getFitnessScore(4.0), f_dev_skip = reg.fitnessScore(4.0);
+  const bool tree_is_stale = registration->getSearchMethodTarget()->getInputCloud() == A;
+  reg.setSkipBaseSearchTree(false);
+  registration->setInputTarget(E), registration->align(*aligned, g);
+  const int b5 = builds() - c0;
+  const double f_pcl_back = registration->getFitnessScore(4.0), f_dev_back = reg.fitnessScore(4.0);
+  double f_pcl_placeholder = -1.0, f_pcl_placeholder_unbounded = -1.0, f_dev_device_target = -1.0;
+  if (sm) {
+    const float* dev = nullptr;
+    int64_t m = 0;
+    if (apdgicp_submap_points(sm, &dev, &m) == 0 && m > 0) {
+      reg.setInputTargetDevice(dev, (std::size_t)m, 16);
+      registration->align(*aligned, g);
       f_pcl_placeholder = registration->getFitnessScore(4.0), f_pcl_placeholder_unbounded = registration->getFitnessScore();
       f_dev_device_target = reg.fitnessScore(4.0);
     }
     apdgicp_submap_destroy(sm);
   }
-  std::printf("{\"builds\": [%d, %d, %d, %d, %d], \"f_pcl\": %.12g, \"f_dev\": %.12g, \"f_pcl_stale\": %.12g, \"f_dev_skip\": %.12g, "
+  std::printf("{\"uses_device_search\": %d, \"device_builds\": %d, \"device_builds_end\": %d, \"d_f_pcl\": %.15g, \"d_f_dev\": %.15g, \"d_f_pcl_all\": %.15g, "
+              "\"d_f_dev_all\": %.15g, \"d_inl_nodelet\": %.9g, \"d_inl_dev\": %.9g, \"d_passes\": %ld, \"d_served\": %ld, \"d_fallbacks_before\": %ld, "
+              "\"d_fallbacks_after\": %ld, \"foreign_ok\": %d, \"k5_ok\": %d, \"d_f_pcl_devtgt\": %.15g, \"d_f_dev_devtgt\": %.15g, \"devtgt_foreign_ok\": %d, "
+              "\"empty_converged\": %d, \"back_converged\": %d, \"n_src\": %d, ",
+              uses_device, d_builds, d_builds_end, d_f_pcl, d_f_dev, d_f_pcl_all, d_f_dev_all, d_inl_nodelet, d_inl_dev, d_passes, d_served, d_fb0, d_fb1,
+              foreign_ok, k5_ok, d_f_pcl_devtgt, d_f_dev_devtgt, devtgt_foreign_ok, empty_converged, back_converged, ns);
+  std::printf("\"builds\": [%d, %d, %d, %d, %d], \"f_pcl\": %.12g, \"f_dev\": %.12g, \"f_pcl_stale\": %.12g, \"f_dev_skip\": %.12g, "
               "\"tree_is_stale\": %d, \"converged_with_skip\": %d, \"f_pcl_back\": %.12g, \"f_dev_back\": %.12g, \"f_pcl_placeholder\": %.6g, "
               "\"f_pcl_placeholder_unbounded\": %.6g, \"f_dev_device_target\": %.12g}\n",
               b1, b2, b3, b4, b5, f_pcl, f_dev, f_pcl_stale, f_dev_skip, tree_is_stale ? 1 : 0, conv_skip, f_pcl_back, f_dev_back, f_pcl_placeholder,

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""APDGICP_FLAG_FP32_POINT_MATH (opt-in) against the default (the reference's fp64 per-point algebra): the same seeded pairs as
+tests/measure/parity_sweep.py through two product handles -- pose difference, share of runs whose counts (converged, iterations,
+linearisations, compute_error evaluations) change -- and the kernel / step times of the bench workload under both.
+usage: python tests/measure/fp32_mode.py [n_pairs_per_config=60]  -> one JSON object (commit it under profiles/)"""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, torch  # noqa
+reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
+
+NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+F32 = reg.FLAG_FP32_POINT_MATH
+CONFIGS = {
+    "lm_default": dict(),
+    "lm_launch": dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0),
+    "gn10": dict(optimizer=1, max_iterations=10, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0),
+    "plain_gicp_lm": dict(flags=1, max_correspondence_distance=2.5),
+    "frobenius_k10": dict(regularization=4, k_correspondences=10, max_correspondence_distance=3.0),
+}
+rng = np.random.default_rng(123)
+out = {}
+for tag, kw in CONFIGS.items():
+    st = dict(pairs=0, max_t_diff_m=0.0, max_r_diff_rad=0.0, counts_equal=0, corr_equal_at_guess=0, max_rel_H=0.0, max_rel_b=0.0, max_rel_cost=0.0)
+    for i in range(NP):
+        n, m = int(rng.integers(300, 4000)), int(rng.integers(300, 4000))
+        src, tgt, _, guess = scene.make_pair(n, m, scene.pair_seed(40 + len(out), i), "odometry" if i % 3 else "loop")
+        a = reg.FastAPDGICP(reg.default_params(**kw)); b = reg.FastAPDGICP(reg.default_params(**dict(kw, flags=kw.get("flags", 0) | F32)))
+        for x in (a, b):
+            x.setInputSource(src); x.setInputTarget(tgt)
+        T0 = guess.astype(np.float64)
+        c1, H1, b1 = a.linearize(T0); c2, H2, b2 = b.linearize(T0)
+        st["corr_equal_at_guess"] += int(np.array_equal(a.correspondences()[0], b.correspondences()[0]))
+        st["max_rel_H"] = max(st["max_rel_H"], float(np.abs(H1 - H2).max() / np.abs(H1).max()))
+        st["max_rel_b"] = max(st["max_rel_b"], float(np.abs(b1 - b2).max() / np.abs(b1).max()))
+        st["max_rel_cost"] = max(st["max_rel_cost"], abs(c1 - c2) / abs(c1))
+        Ta, Tb = a.align(guess), b.align(guess)
+        te, re_ = scene.pose_error(Ta, Tb)
+        st["max_t_diff_m"] = max(st["max_t_diff_m"], te); st["max_r_diff_rad"] = max(st["max_r_diff_rad"], re_)
+        ra, rb = a.result, b.result
+        st["counts_equal"] += int([ra.converged, ra.iterations, ra.n_linearize, ra.n_compute_error] == [rb.converged, rb.iterations, rb.n_linearize, rb.n_compute_error])
+        st["pairs"] += 1
+    out[tag] = st
+
+# the bench workload: 32 pairs of 8192 x 8192, GN-20, both clouds fresh, one handle; ms per step under both modes, alternated
+P, n = 32, 8192
+clouds, guesses = [], []
+for p in range(P):
+    s, t, _, g = scene.make_pair(n, n, scene.pair_seed(2, p), "odometry")
+    clouds += [torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()]; guesses.append(g)
+kw = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+res, ms = {}, {0: [], F32: []}
+hs = {fl: [reg.BatchAPDGICP(reg.default_params(**dict(kw, flags=fl))) for _ in range(4)] for fl in (0, F32)}
+for fl in hs:
+    for h in hs[fl]:
+        h.set_pair_groups(1)
+pairs = hs[0][0].make_pairs([(2 * i, 2 * i + 1) for i in range(P)], guesses)
+def steps(handles, count):
+    tk = [None] * len(handles); last = None
+    for s_ in range(count + len(handles)):
+        h = s_ % len(handles)
+        if tk[h] is not None:
+            last = handles[h].align_collect(tk[h]); tk[h] = None
+        if s_ < count:
+            handles[h].set_clouds(0, clouds, producer_wait=False); tk[h] = handles[h].align_enqueue(pairs)
+    return last
+for rep in range(5):
+    for fl in (0, F32):
+        steps(hs[fl], 8); torch.cuda.synchronize()
+        t1 = time.perf_counter(); res[fl] = steps(hs[fl], 40); torch.cuda.synchronize()
+        ms[fl].append((time.perf_counter() - t1) / 40 * 1e3)
+d = [scene.pose_error(reg.result_matrix(res[0][i]), reg.result_matrix(res[F32][i])) for i in range(P)]
+out["bench_gn20_8k_x32"] = dict(ms_per_step_fp64=round(float(np.median(ms[0])), 4), ms_per_step_fp32_point_math=round(float(np.median(ms[F32])), 4),
+                                all_runs_fp64=[round(v, 4) for v in ms[0]], all_runs_fp32=[round(v, 4) for v in ms[F32]],
+                                max_t_diff_m=max(x[0] for x in d), max_r_diff_rad=max(x[1] for x in d), handles_in_flight=4)
+out["note"] = "product (default, fp64 per-point algebra = the reference's) vs product with APDGICP_FLAG_FP32_POINT_MATH on identical inputs; the flag is opt-in"
+print(json.dumps(out, indent=1))

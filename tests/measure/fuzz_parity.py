@@ -4,8 +4,9 @@ lattices (exact fp32 distance ties everywhere), duplicated points, planar and co
 clouds 3 km from the origin (fp32 resolution 0.25 mm), sizes around every block / group / tile boundary, very small clouds,
 tight and loose correspondence gates, every regularisation, k = 5 .. 40, both fp32 orders of T * p, plain GICP, GN and LM.
 Per case: both clouds' covariances (1e-9 relative to the cloud's largest entry), correspondences at the guess (exact) and their
-fp32 squared distances (bit-exact), H / b / cost (2e-5: the fp32 atan2f of the two sides may differ by an ulp), the whole
-registration (counts, pose 1e-3 m / 1e-4 rad).
+fp32 squared distances (bit-exact), H / b / cost (1e-8 relative: both sides evaluate the sensor model's fp32 angles with the same
+atan2f since round 5, include/apd_atan2f.h; until then 2e-5; the largest seen over 13 000 cases is 2.2e-9, on collinear clouds whose
+RCR is nearly singular), the whole registration (counts, pose 1e-3 m / 1e-4 rad).
 
 Two things have no single right answer in the REFERENCE either, and the fuzz recognises them point by point instead of failing:
  * a tie at the k-th neighbour distance (FLANN keeps whichever candidate its tree walk met first);
@@ -15,14 +16,16 @@ Two things have no single right answer in the REFERENCE either, and the fuzz rec
    max(1e-9, 1e-13 * s1 / (s2 - s3)).
 A cloud whose only differences are of these kinds is counted `cov_ambiguous`, the ORACLE's covariances are injected into the
 product handle (setSource/TargetCovariances) and everything downstream is still compared.  Registrations that are ill-posed --
-fewer than 20 correspondences at the guess or cond(H) > 1e6 at the guess or at the end, where the solve is decided by rounding --
-are counted `ill_posed` and only their correspondences / distances / covariances / H, b are held to the bars; registrations
-of fewer than 150 correspondences (`few_points`: cond(H) 1e5 .. 1e6, the fp32 atan2f ulp amplified to 1 .. 3e-4 rad with identical
-counts) are held to ten times the pose bars and their maxima reported apart, and so are LM runs that the ORACLE ends at
-`max_iterations` without convergence (`lm_hit_iteration_limit`: 64 steps of a trajectory that is still moving amplify the same ulp;
-seen once in 13 000 cases: a 527-point lattice, 2.4e-4 rad with identical counts).
+fewer than 20 correspondences at the guess or cond(H) > COND_ILL (1e6) at the guess or at the end, where the solve is decided by
+the last bits of fp64 sums -- are counted `ill_posed` and only their correspondences / distances / covariances / H, b are held to
+the bars; those with cond(H) below 1e8 are still measured and reported apart (`cond_1e6_1e8`: how many, how many inside the bars --
+a first round-5 run with the threshold at 1e8 had 18 of ~640 such cases, every one a collinear cloud with cond(H) 4e7 .. 1e8,
+outside the rotation bar).  Registrations of fewer than 150 correspondences (`few_points`) and LM runs that the ORACLE ends at
+`max_iterations` without convergence (`lm_hit_iteration_limit`) are counted and their maxima reported apart, but held to the
+NORMAL bars (round 4 held them to ten times the bars: the device library's atan2f ulp, amplified by cond(H) 1e5 .. 1e6, moved
+three such poses by 1.7 .. 2.4e-4 rad).
 Every failure prints its seed: `python tests/measure/fuzz_parity.py 1 <seed>` replays it.
-usage: python tests/measure/fuzz_parity.py [seconds=300] [first_seed=0]  -> one JSON object (commit it under profiles/)"""
+usage: python tests/measure/fuzz_parity.py [seconds=300] [first_seed=0] [last_seed]  -> one JSON object (commit it under profiles/)"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -32,6 +35,9 @@ import ref as R  # noqa
 
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+SEED1 = int(sys.argv[3]) if len(sys.argv) > 3 else None   # optional: stop after this seed (a committed range re-run whole, whatever the box's speed)
+COND_ILL = float(os.environ.get("FUZZ_COND_ILL", "1e6"))
+LIN_TOL = float(os.environ.get("FUZZ_LIN_TOL", "1e-8"))
 FEW = 150   # correspondences at the guess below which a registration is reported as `few_points`
 EDGE_SIZES = (21, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1024, 1025, 2047, 2049, 4095, 4097)
 KINDS = ("scene", "lattice", "dups", "planar", "line", "far", "tiny", "edge", "blob")
@@ -130,7 +136,7 @@ stats = {k: dict(cases=0, cov_fail=0, cov_ambiguous=0, corr_fail=0, sqd_fail=0, 
 failures = []
 t0 = time.time()
 seed = SEED0
-while time.time() - t0 < BUDGET:
+while time.time() - t0 < BUDGET and (SEED1 is None or seed <= SEED1):
     kind, src, tgt, guess, kw = make_case(seed)
     st = stats[kind]
     g = reg.FastAPDGICP(reg.default_params(**kw)); o = R.RefAPDGICP(R.default_params(**kw))
@@ -169,7 +175,7 @@ while time.time() - t0 < BUDGET:
     if matched and cond0 < 1e12:
         rH = max(rel(H1, H2), rel(b1, b2), abs(c1 - c2) / max(abs(c2), 1e-300))
         st["max_rel_H"] = max(st["max_rel_H"], rH)
-        if not rH <= 2e-5:
+        if not rH <= LIN_TOL:
             st["lin_fail"] += 1; bad.append(f"H/b/cost {rH:.3g}")
     T = g.align(guess); To = o.align(guess)
     r = g.result
@@ -177,11 +183,16 @@ while time.time() - t0 < BUDGET:
     info_o = [int(o.converged), o.nr_iterations, o.n_linearize, o.n_compute_error]
     Hf = o.final_hessian()
     cond1 = np.linalg.cond(Hf) if np.isfinite(Hf).all() and np.abs(Hf).max() > 0 else np.inf
-    if matched < 20 or not cond0 < 1e6 or not cond1 < 1e6 or not np.isfinite(To).all():
+    if matched < 20 or not cond0 < COND_ILL or not cond1 < COND_ILL or not np.isfinite(To).all():
         st["ill_posed"] += 1
+        if matched >= 20 and cond0 < 1e8 and cond1 < 1e8 and np.isfinite(To).all() and np.isfinite(T).all():   # measured, not held to the bars
+            te, re_ = scene.pose_error(To, T)
+            bl = st.setdefault("cond_1e6_1e8", dict(cases=0, inside_bars=0, max_t_err_m=0.0, max_r_err_rad=0.0))
+            bl["cases"] += 1; bl["inside_bars"] += int(te <= 1e-3 and re_ <= 1e-4)
+            bl["max_t_err_m"] = max(bl["max_t_err_m"], te); bl["max_r_err_rad"] = max(bl["max_r_err_rad"], re_)
     else:
         te, re_ = scene.pose_error(To, T) if np.isfinite(T).all() else (np.inf, np.inf)
-        few = matched < FEW   # a handful of points: cond(H) 1e5 .. 1e6 amplifies the atan2f ulp; ten times the bars, maxima reported apart
+        few = matched < FEW   # a handful of points (cond(H) 1e5 .. 1e6): counted and reported apart, same bars
         limit = kw.get("optimizer", 0) == 0 and not o.converged   # LM stopped by max_iterations, still moving: 64 steps of amplified rounding
         if limit:
             st["lm_hit_iteration_limit"] = st.get("lm_hit_iteration_limit", 0) + 1
@@ -192,7 +203,7 @@ while time.time() - t0 < BUDGET:
             st["few_points"] = st.get("few_points", 0) + 1
             st["few_points_max_t_err_m"] = max(st.get("few_points_max_t_err_m", 0.0), te)
             st["few_points_max_r_err_rad"] = max(st.get("few_points_max_r_err_rad", 0.0), re_)
-        if not (te <= (1e-2 if few else 1e-3) and re_ <= (1e-3 if few else 1e-4)):
+        if not (te <= 1e-3 and re_ <= 1e-4):
             st["pose_fail"] += 1; bad.append(f"pose {te:.3g} m {re_:.3g} rad (cond H {cond0:.3g} / {cond1:.3g}, matched {matched}) counts {info_g} vs {info_o}")
         else:
             if not few:
@@ -203,6 +214,6 @@ while time.time() - t0 < BUDGET:
         failures.append(dict(seed=seed, kind=kind, n=len(src), m=len(tgt), params=kw, what=bad))
         print("FAIL", failures[-1], file=sys.stderr, flush=True)
     seed += 1
-out = dict(seeds=[SEED0, seed - 1], seconds=round(time.time() - t0, 1), kinds=stats, failures=failures[:50], n_failures=len(failures))
+out = dict(bars=dict(lin_rel=LIN_TOL, pose_m=1e-3, pose_rad=1e-4, ill_posed_cond=COND_ILL, few_points_and_lm_limit="normal bars"), seeds=[SEED0, seed - 1], seconds=round(time.time() - t0, 1), kinds=stats, failures=failures[:50], n_failures=len(failures))
 print(json.dumps(out, indent=1))
 sys.exit(1 if failures else 0)

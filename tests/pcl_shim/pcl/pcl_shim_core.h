@@ -73,25 +73,51 @@ struct PointCloud {
 };
 
 namespace search {
-// pcl::search::KdTree as pcl::Registration uses it (tree_): setInputCloud is where real PCL builds a FLANN kd-tree on the CPU,
-// O(n log n), single-threaded -- counted here (n_builds) so that a test can see WHEN the base class does it.  The search itself is
-// a linear scan: the shim is test infrastructure for scan-sized clouds.
+// pcl::search::Search / pcl::search::KdTree as pcl::Registration uses them (tree_): the two virtuals a registration's search object
+// is called through -- setInputCloud(cloud, indices) and nearestKSearch(point, k, indices, sqr_distances) const, declared in
+// pcl/search/search.h and overridden by pcl/search/kdtree.h -- and the protected input_ behind getInputCloud().  In real PCL
+// KdTree::setInputCloud is where a FLANN kd-tree is built on the CPU, O(n log n), single-threaded -- counted here (n_builds,
+// process-wide total in kdtree_builds_total()) so that a test can see WHEN the base class does it.  The search itself is a linear
+// scan: the shim is test infrastructure for scan-sized clouds.
+inline int& kdtree_builds_total() {
+  static int n = 0;
+  return n;
+}
 template <typename PointT>
-class KdTree {
+class Search {
+ public:
+  using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
+  using IndicesConstPtr = std::shared_ptr<const std::vector<int>>;
+  virtual ~Search() {}
+  virtual void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) {
+    input_ = cloud;
+    indices_ = indices;
+  }
+  virtual PointCloudConstPtr getInputCloud() const { return input_; }
+  virtual int nearestKSearch(const PointT& p, int k, std::vector<int>& idx, std::vector<float>& d2) const = 0;
+
+ protected:
+  PointCloudConstPtr input_;
+  IndicesConstPtr indices_;
+};
+template <typename PointT>
+class KdTree : public Search<PointT> {
  public:
   using Ptr = std::shared_ptr<KdTree<PointT>>;
-  using PointCloudConstPtr = typename PointCloud<PointT>::ConstPtr;
-  void setInputCloud(const PointCloudConstPtr& cloud) {
-    input_ = cloud;
+  using PointCloudConstPtr = typename Search<PointT>::PointCloudConstPtr;
+  using IndicesConstPtr = typename Search<PointT>::IndicesConstPtr;
+  void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
+    this->input_ = cloud;
+    this->indices_ = indices;
     n_builds++;
+    kdtree_builds_total()++;
   }
-  PointCloudConstPtr getInputCloud() const { return input_; }
-  int nearestKSearch(const PointT& p, int k, std::vector<int>& idx, std::vector<float>& d2) const {
-    if (!input_ || input_->empty() || k != 1) return 0;
+  int nearestKSearch(const PointT& p, int k, std::vector<int>& idx, std::vector<float>& d2) const override {
+    if (!this->input_ || this->input_->empty() || k != 1) return 0;
     float best = std::numeric_limits<float>::infinity();
     int bi = -1;
-    for (std::size_t i = 0; i < input_->size(); i++) {
-      const PointT& q = input_->at(i);
+    for (std::size_t i = 0; i < this->input_->size(); i++) {
+      const PointT& q = this->input_->at(i);
       const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
       float d = dx * dx;
       d = d + dy * dy;
@@ -102,9 +128,6 @@ class KdTree {
     return 1;
   }
   int n_builds = 0;
-
- private:
-  PointCloudConstPtr input_;
 };
 }  // namespace search
 

@@ -1,1 +1,1 @@
-#include <pcl/pcl_shim_core.h>
+#include "../pcl_shim_core.h"

@@ -81,12 +81,15 @@ def test_adapter_protocol_timing_mode(scene, tmp_path):
 
 
 @pytest.mark.gpu
-def test_what_pcl_align_adds_and_the_opt_out(golden, tmp_path):
-    """pcl::Registration::align() -> initCompute() rebuilds the BASE class's kd-tree on the CPU for every new target (the shim
-    counts the builds).  Default: one build per new target object, none for a pointer-equal one, base-class getFitnessScore ==
-    device fitnessScore.  setSkipBaseSearchTree(true): no builds, the registration is unaffected, the base-class score is stale
-    (documented: use fitnessScore() / inlierFraction()), the device score follows the real target.  A device-resident target
-    leaves the base class with a far-away placeholder: its score is DBL_MAX / absurd, never plausible."""
+def test_base_class_calls_without_a_cpu_kdtree_and_what_pcl_adds_otherwise(golden, tmp_path):
+    """The nodelets call the PCL BASE class: getFitnessScore() (loop_detector.cpp:229) and getSearchMethodTarget()->nearestKSearch(
+    aligned[i], 1, ...) (scan_matching_odometry_nodelet.cpp:697-707).  Default: the adapter's DeviceSearch is the base class's search
+    object -- zero kd-tree builds over three aligns with new targets (the shim counts the builds), the base-class fitness score
+    equals the device's fitnessScore(), the nodelet's verbatim inlier loop equals inlierFraction(), every query served from one
+    batched device search per pose; a foreign query point and k = 5 take the exact host scan; a device-resident target is
+    answered about (not its placeholder); an empty source cloud makes the next align fail instead of reusing the previous one.
+    setUseDeviceSearch(false): PCL's own tree -- one build per new target inside align(), none for a pointer-equal one; with
+    setSkipBaseSearchTree(true) no build and a stale base-class score; a device target leaves the base class its placeholder."""
     import json
     exe = build_exe()
     src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
@@ -99,6 +102,17 @@ def test_what_pcl_align_adds_and_the_opt_out(golden, tmp_path):
     out = subprocess.run([exe, str(path), "--base-tree"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
+    # ---- the device search object (default)
+    assert d["uses_device_search"] == 1 and d["device_builds"] == 0 and d["device_builds_end"] == 0
+    assert abs(d["d_f_pcl"] - d["d_f_dev"]) <= 1e-9 * d["d_f_dev"] and 0 < d["d_f_dev"] < 4.0
+    assert abs(d["d_f_pcl_all"] - d["d_f_dev_all"]) <= 1e-9 * d["d_f_dev_all"]
+    assert d["d_inl_nodelet"] == d["d_inl_dev"] and 0 < d["d_inl_dev"] <= 1
+    assert d["d_fallbacks_before"] == 0 and d["d_served"] == 3 * d["n_src"] and d["d_passes"] == 1   # two scores + the inlier loop: ONE device search
+    assert d["foreign_ok"] == 1 and d["k5_ok"] == 1 and d["d_fallbacks_after"] == 2
+    assert abs(d["d_f_pcl_devtgt"] - d["d_f_dev_devtgt"]) <= 1e-9 * d["d_f_dev_devtgt"] and d["devtgt_foreign_ok"] == 1
+    assert abs(d["d_f_dev_devtgt"] - d["d_f_dev"]) <= 1e-9 * d["d_f_dev"]
+    assert d["empty_converged"] == 0 and d["back_converged"] == 1
+    # ---- PCL's own tree
     assert d["builds"] == [1, 1, 2, 2, 3]
     assert abs(d["f_pcl"] - d["f_dev"]) <= 1e-5 * d["f_dev"] and 0 < d["f_dev"] < 4.0
     assert d["converged_with_skip"] == 1 and d["tree_is_stale"] == 1

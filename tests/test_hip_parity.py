@@ -299,8 +299,8 @@ def test_align_golden(reg, golden, scene, tag, host_loop, sfx, flags):
     te, re_ = scene.pose_error(golden[f"{tag}_T"], T)
     assert te <= T_TOL and re_ <= R_TOL
     print(tag, host_loop, 'pose diff vs golden', te, re_)
-    assert te <= 1e-6 and re_ <= 1e-7, (te, re_)
-    assert rel_err(g.getFinalHessian(), golden[f"{tag}_final_hessian"]) < 1e-7
+    assert te <= 1e-9 and re_ <= 1e-10, (te, re_)      # (measured: <= 1.2e-16 m / 2.5e-18 rad, profiles/r05_trace_c4.log)
+    assert rel_err(g.getFinalHessian(), golden[f"{tag}_final_hessian"]) < 1e-10
     assert g.hasConverged() == bool(golden[f"{tag}_info"][0])
 
 
@@ -311,8 +311,9 @@ def test_optimiser_trace_golden(reg, golden, tag, host_loop, sfx, flags):
     """SURVEY 8(c) KAT-lm: the trajectory, not only its end -- per Levenberg-Marquardt trial the lambda the step was solved with,
     its gain ratio rho and the two costs it compares, per outer iteration the pose behind it (L:131-169) -- of the device state
     machine (a debug ring written by the last block of k_linearize / k_error) and of the host-driven loop, against the golden
-    traces of the two CPU restatements.  Bars (tests/trace_util.py): costs 1e-9 relative, rho and lambda 1e-9 times the
-    cancellation y0 / |y0 - yi| of the gain ratio, poses 1e-7 m."""
+    traces of the two CPU restatements.  Bars (tests/trace_util.py): costs 1e-11 relative, rho and lambda 1e-11 times the
+    cancellation y0 / |y0 - yi| of the gain ratio, poses 1e-9 m (measured: 1.3e-15 relative on radar-range clouds, 1.2e-12 on the
+    far-range rejection clouds, poses 3e-15 m / 1e-12 m; profiles/r05_trace_c4.log)."""
     kw = dict(RUNS.get(tag, {}), **(dict(lm_max_iterations=1) if tag == "fail" else {}))
     pre = "lm_loop" if tag == "lm_loop" else "rej" if tag in ("rej", "fail") else "lin"
     g = reg.FastAPDGICP(reg.default_params(flags=flags, **kw))
@@ -325,7 +326,7 @@ def test_optimiser_trace_golden(reg, golden, tag, host_loop, sfx, flags):
     assert len(tr["rho"]) == g.result.n_compute_error == len(want["rho"])
     if tag in ("rej", "fail"):
         assert np.array_equal(tr["rho"] < 0, want["rho"] < 0) and (tr["rho"] < 0).any()   # the same trials are rejected (L:156)
-    d = trace_close(tr, want)
+    d = trace_close(tr, want, tol_cost=1e-11, tol_pose=1e-9)
     print(tag + sfx, "host loop" if host_loop else "device loop", "normalised trace differences", d)
     assert max(d.values()) < 1.0, d
 

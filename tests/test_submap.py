@@ -56,8 +56,9 @@ def test_oracle_matches_numpy_restatement(scene):
         u, c2, cen = np_voxelgrid(cat, leaf)
         assert np.array_equal(idx, u) and np.array_equal(cnt, c2)
         assert np.abs(out - cen).max() < 2e-5
-    with pytest.raises(RuntimeError):
-        R.submap_assemble(clouds[:-1], poses, 1e-5)
+    # "Leaf size is too small for the input dataset. Integer indices would overflow.": PCL warns and returns its input
+    out, idx, cnt = R.submap_assemble(clouds[:-1], poses, 1e-5)
+    assert np.array_equal(out, cat) and (idx == -1).all() and (cnt == 1).all()
 
 
 # ------------------------------------------------------------------ GPU
@@ -137,8 +138,12 @@ def test_edge_cases(mods, scene):
     assert centroids_close(a.to_numpy(), exp)
     assert a.assemble([c[:0], c[:1]], None, 0.1) == 1  # an empty keyframe cloud among the inputs
     assert a.assemble([c[:0]], None, 0.1) == 0 and a.to_numpy().shape == (0, 4)
-    with pytest.raises(reg.ApdgicpError):  # PCL: "Leaf size is too small for the input dataset"
-        a.assemble([c[[0, 3]]], None, 1e-4)
+    # PCL: "Leaf size is too small for the input dataset. Integer indices would overflow." -- a warning, the cloud comes back unfiltered
+    far = np.array([[0.0, 0.0, 0.0, 1.0], [3000.0, 2000.0, 900.0, 2.0], [1.0, 1.0, 1.0, 3.0]], dtype=np.float32)
+    assert a.assemble([far[:2], far[2:]], None, 1e-4) == 3 and np.array_equal(a.to_numpy(), far)
+    want, widx, _ = R.submap_assemble([far[:2], far[2:]], None, 1e-4)          # the checker returns PCL's answer: the input, unfiltered
+    assert np.array_equal(want, far) and (widx == -1).all()
+    assert a.assemble([c], None, 0.1) == 2 and centroids_close(a.to_numpy(), exp)   # (and the handle works on)
     # all points in one voxel; duplicates
     d = np.tile(np.array([[1.5, 2.5, 3.5, 4.0]], dtype=np.float32), (1000, 1))
     assert a.assemble([d], None, 0.5) == 1 and np.array_equal(a.to_numpy(), d[:1])
