@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--host-clouds", action="store_true",
                     help="every step hands the library HOST clouds (numpy, pageable) instead of resident device buffers: the PCIe-inclusive rate "
                          "DESIGN.md quotes beside the headline -- never the headline itself")
+    ap.add_argument("--fp32-point-math", action="store_true",
+                    help="APDGICP_FLAG_FP32_POINT_MATH: the opt-in fp32 per-point algebra (NOT the reference's precision: an A/B line, never the headline)")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered records of the last step (uint8 [pairs, 96]) to this .npy file")
     return ap.parse_args()
 
@@ -204,6 +206,8 @@ def main():
 
     lm = args.optimizer == "lm"
     params = bench_params(reg, args.optimizer)
+    if args.fp32_point_math:
+        params.flags |= reg.FLAG_FP32_POINT_MATH
     # Consecutive steps are independent batches, so several of them are kept in flight: step s runs on batch handle s % H
     # (H = --handles, 4 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
     # underfed (32 pairs: three groups of latency-bound tick kernels); with several steps at different phases one handle's
@@ -429,7 +433,9 @@ def main():
                        "APD-GICP registrations/s (8k-pt pairs, Levenberg-Marquardt with the launch parameters, covariances recomputed)"),
             "value": round(value, 2), "unit": "registrations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 nearest-neighbour search + f64 covariance/Mahalanobis/Hessian", "data": "synthetic",
+            "dtype": ("f32 nearest-neighbour search + f64 covariance/Mahalanobis/Hessian" if not args.fp32_point_math else
+                      "f32 nearest-neighbour search + f32 per-point Mahalanobis/Jacobian terms (APDGICP_FLAG_FP32_POINT_MATH, opt-in: NOT the reference's precision) + f64 covariances/sums/solve"),
+            "data": "synthetic",
             "inputs": ("HOST clouds every step (numpy, pageable; packed into pinned memory by the library, read over PCIe): the PCIe-inclusive rate, NOT the headline"
                        if args.host_clouds else "resident in HBM before the timed region"),
             "config": {"workload": (f"BASELINE configs[1] (8k x 8k scan pair, 20 GN iterations) x {P} independent pairs per GPU per step "

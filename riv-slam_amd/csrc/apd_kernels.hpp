@@ -2549,13 +2549,16 @@ __device__ __forceinline__ void linearize_point_f32(const CloudDesc& src, const 
     mo[0] = Mi.xx, mo[w.nstride] = Mi.xy, mo[2 * (size_t)w.nstride] = Mi.xz;
     mo[3 * (size_t)w.nstride] = Mi.yy, mo[4 * (size_t)w.nstride] = Mi.yz, mo[5 * (size_t)w.nstride] = Mi.zz;
   }
-  // transed_mean_A and e (A:236-237), fp32 like the search's own T * p (the residual of a point 100 m away carries ~1e-5 m of
-  // rounding, random in sign over thousands of points)
-  const float tf[3] = {(float)T.m[3], (float)T.m[7], (float)T.m[11]};
-  const float vx = Rf[0] * p.x + Rf[1] * p.y + Rf[2] * p.z + tf[0];
-  const float vy = Rf[3] * p.x + Rf[4] * p.y + Rf[5] * p.z + tf[1];
-  const float vz = Rf[6] * p.x + Rf[7] * p.y + Rf[8] * p.z + tf[2];
-  const float ex = tq.x - vx, ey = tq.y - vy, ez = tq.z - vz;
+  // transed_mean_A and e (A:236-237) in fp64, then narrowed: the residual is the difference of two points 2 .. 100 m from the sensor
+  // that lie centimetres apart -- formed in fp32 it carries ~4e-6 m of rounding per point (a first version did: poses of small
+  // ill-conditioned pairs moved by up to 1.6e-3 m); formed in fp64 and THEN rounded it keeps 24 bits of its own magnitude.  Twelve
+  // fp64 operations per point.
+  const double ax = (double)p.x, ay = (double)p.y, az = (double)p.z;
+  const double vxd = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
+  const double vyd = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+  const double vzd = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+  const float vx = (float)vxd, vy = (float)vyd, vz = (float)vzd;
+  const float ex = (float)((double)tq.x - vxd), ey = (float)((double)tq.y - vyd), ez = (float)((double)tq.z - vzd);
   lp.Mi = Mi;
   lp.vx = vx, lp.vy = vy, lp.vz = vz;
   lp.mex = Mi.xx * ex + Mi.xy * ey + Mi.xz * ez;
@@ -2667,8 +2670,11 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 #ifndef APD_LIN_WPE
 #define APD_LIN_WPE 7  // fused kernel: ask for 7 waves per SIMD (71 registers, no scratch; what the LDS of 7 blocks per CU allows): 0.7435 -> 0.7402 ms per step against 6
 #endif
+#ifndef APD_LIN_WPE_F32
+#define APD_LIN_WPE_F32 6  // the fp32 per-point variant: at 7 waves per SIMD (73 registers) it spilled 44 B to scratch
+#endif
 template <bool FUSED, bool F32 = false>
-__global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ? APD_LIN_WPE : 1, 8))) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
+__global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ? (F32 ? APD_LIN_WPE_F32 : APD_LIN_WPE) : 1, 8))) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
   unsigned bx, by;

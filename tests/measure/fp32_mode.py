@@ -42,36 +42,22 @@ for tag, kw in CONFIGS.items():
         st["pairs"] += 1
     out[tag] = st
 
-# the bench workload: 32 pairs of 8192 x 8192, GN-20, both clouds fresh, one handle; ms per step under both modes, alternated
+# the bench workload (32 pairs of 8192 x 8192, GN-20, both clouds fresh): pose differences per pair; the step TIMES of the two modes come
+# from alternated bench.py runs (tools/ab_fp32.sh: one set of four handles at a time, like the headline)
 P, n = 32, 8192
 clouds, guesses = [], []
 for p in range(P):
     s, t, _, g = scene.make_pair(n, n, scene.pair_seed(2, p), "odometry")
     clouds += [torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()]; guesses.append(g)
 kw = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
-res, ms = {}, {0: [], F32: []}
-hs = {fl: [reg.BatchAPDGICP(reg.default_params(**dict(kw, flags=fl))) for _ in range(4)] for fl in (0, F32)}
-for fl in hs:
-    for h in hs[fl]:
-        h.set_pair_groups(1)
-pairs = hs[0][0].make_pairs([(2 * i, 2 * i + 1) for i in range(P)], guesses)
-def steps(handles, count):
-    tk = [None] * len(handles); last = None
-    for s_ in range(count + len(handles)):
-        h = s_ % len(handles)
-        if tk[h] is not None:
-            last = handles[h].align_collect(tk[h]); tk[h] = None
-        if s_ < count:
-            handles[h].set_clouds(0, clouds, producer_wait=False); tk[h] = handles[h].align_enqueue(pairs)
-    return last
-for rep in range(5):
-    for fl in (0, F32):
-        steps(hs[fl], 8); torch.cuda.synchronize()
-        t1 = time.perf_counter(); res[fl] = steps(hs[fl], 40); torch.cuda.synchronize()
-        ms[fl].append((time.perf_counter() - t1) / 40 * 1e3)
+res = {}
+for fl in (0, F32):
+    h = reg.BatchAPDGICP(reg.default_params(**dict(kw, flags=fl))); h.set_pair_groups(1)
+    h.set_clouds(0, clouds)
+    res[fl] = h.align([(2 * i, 2 * i + 1) for i in range(P)], guesses)
+    del h
 d = [scene.pose_error(reg.result_matrix(res[0][i]), reg.result_matrix(res[F32][i])) for i in range(P)]
-out["bench_gn20_8k_x32"] = dict(ms_per_step_fp64=round(float(np.median(ms[0])), 4), ms_per_step_fp32_point_math=round(float(np.median(ms[F32])), 4),
-                                all_runs_fp64=[round(v, 4) for v in ms[0]], all_runs_fp32=[round(v, 4) for v in ms[F32]],
-                                max_t_diff_m=max(x[0] for x in d), max_r_diff_rad=max(x[1] for x in d), handles_in_flight=4)
+out["bench_gn20_8k_x32"] = dict(max_t_diff_m=max(x[0] for x in d), max_r_diff_rad=max(x[1] for x in d),
+                                median_t_diff_m=float(np.median([x[0] for x in d])), median_r_diff_rad=float(np.median([x[1] for x in d])))
 out["note"] = "product (default, fp64 per-point algebra = the reference's) vs product with APDGICP_FLAG_FP32_POINT_MATH on identical inputs; the flag is opt-in"
 print(json.dumps(out, indent=1))
