@@ -1349,3 +1349,32 @@ def test_fp32_point_math_is_an_opt_in_inside_the_tolerance(reg, golden, scene):
         assert te <= 1e-5 and re_ <= 1e-6
         te, re_ = scene.pose_error(To, Tb)
         assert te <= T_TOL and re_ <= R_TOL
+
+
+def test_so3_exp_small_angle_branch_in_isolation(reg, golden, scene):
+    """a15: so3_exp's Taylor branch (theta^2 < 1e-10, so3.hpp:63-68) -- a Gauss-Newton step of a few microradians: the source is the
+    target moved by a rotation of 3e-6 rad and a micrometre, so the FIRST step's rotation vector is ~3e-6 (theta^2 ~ 1e-11: the
+    Taylor branch), and the steps after it are smaller still.  Device state machine and host-driven loop against the oracle's
+    trace, pose by pose; the branch that ran is read off the pose itself."""
+    tgt = golden["lin_target"]
+    Tt = scene.make_transform(np.array([1e-6, -2e-6, 0.5e-6]), 3e-6, -1e-6, 2e-6)
+    Ti = np.linalg.inv(Tt)
+    src = (tgt.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    kw = dict(optimizer=1, max_iterations=3, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=1.0)
+    o = R.RefAPDGICP(R.default_params(**kw))
+    o.setInputSource(src)
+    o.setInputTarget(tgt)
+    o.align(None)
+    want = o.trace()["poses"]
+    assert len(want) == 3
+    ang = [float(np.arccos(np.clip((np.trace(P[:3, :3]) - 1) / 2, -1, 1))) for P in want]
+    assert 1e-7 < ang[0] < 1e-5, ang     # theta^2 < 1e-10: the Taylor branch produced this rotation
+    for host_loop in (False, True):
+        g = reg.FastAPDGICP(reg.default_params(**kw))
+        g.setTrace(True)
+        g.setInputSource(src)
+        g.setInputTarget(tgt)
+        g.align(None, host_loop=host_loop)
+        got = g.trace()["poses"]
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-13, np.abs(got - want).max()
+        assert np.abs(got[0][:3, :3] - np.eye(3)).max() < 1e-5 and np.abs(got[0][:3, :3] - np.eye(3)).max() > 1e-8
