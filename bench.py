@@ -569,6 +569,14 @@ def main():
                 # ---- second object: SURVEY 8d's C4 shard -- 32 loop-closure candidates at 8192 points, aligned
                 # from the identity (loop_detector.cpp:225) by Levenberg-Marquardt with the launch parameters, both clouds fresh every
                 # batch -- on ONE handle and ONE host thread, 24 batches in flight in the handle's pair pool (two pair lists on two streams)
+                # The handles of the legs above are closed first: the HIP runtime deals a process's streams onto its hardware queues
+                # (GPU_MAX_HW_QUEUES = 8) in creation order, and with the four batch handles and the single-registration handle still
+                # alive two of the four streams this pooled handle ticks on shared a queue (round 5: 1.02 instead of 0.90 ms per batch
+                # when an earlier leg happened to create two streams fewer).  A closed handle's stream is gone; nothing below uses them.
+                for bh_ in batches:
+                    bh_.close()
+                one.close()
+                torch.cuda.synchronize()
                 F4, P4 = 24, 32
                 lm_clouds, lm_host = [], []
                 for p_ in range(P4):
