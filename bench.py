@@ -71,6 +71,7 @@ def parse_args():
                          "DESIGN.md quotes beside the headline -- never the headline itself")
     ap.add_argument("--fp32-point-math", action="store_true",
                     help="APDGICP_FLAG_FP32_POINT_MATH: the opt-in fp32 per-point algebra (NOT the reference's precision: an A/B line, never the headline)")
+    ap.add_argument("--extra-flags", type=int, default=0, help="experiments only: OR these bits into apdgicp_params.flags (e.g. 1 = plain GICP: what the sensor model costs)")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered records of the last step (uint8 [pairs, 96]) to this .npy file")
     return ap.parse_args()
 
@@ -208,6 +209,7 @@ def main():
     params = bench_params(reg, args.optimizer)
     if args.fp32_point_math:
         params.flags |= reg.FLAG_FP32_POINT_MATH
+    params.flags |= args.extra_flags
     # Consecutive steps are independent batches, so several of them are kept in flight: step s runs on batch handle s % H
     # (H = --handles, 4 by default), each handle with ONE pair group = one HIP stream.  A step alone leaves the GPU
     # underfed (32 pairs: three groups of latency-bound tick kernels); with several steps at different phases one handle's

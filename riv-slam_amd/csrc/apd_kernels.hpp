@@ -963,6 +963,92 @@ __device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, co
   return o;
 }
 
+// What every search ends with, for the wave that holds the final (merged) minima: the exact index of each point's neighbour, ties
+// settled, and the record the next search keeps its neighbour by.  Lanes without a point come in with pidx = -1 (or kept).
+template <int S>
+__device__ __forceinline__ void nn_finish(const CloudDesc& tgt, const Work& w, int pair, int lane, bool skin_on, float k_mul, float k_add, float (&px)[S],
+                                          float (&py)[S], float (&pz)[S], float (&best)[S], unsigned (&bestc)[S], int (&pidx)[S], bool (&kept)[S],
+                                          float (&g1)[S], float (&g2)[S]) {
+  const int M = tgt.n;
+  // The exact index: among the targets of the winning chunk at distance `best`, the one with the lowest ORIGINAL index (ties
+  // resolve like a linear scan in the caller's point order).  Resolved here, by the waves that searched, and handed to k_linearize through nnpt + kKeptBit: the
+  // re-scan used to run in every wave of k_linearize that held a single point without the bit, i.e. in nearly all of them
+  // even when nine points in ten had kept their neighbour.  (Equal minima in several chunks -- kTieBit -- stay with
+  // k_linearize's scan of the whole target.)
+  // Equal minima in several chunks (kTieBit: two different targets at exactly the same fp32 distance, or duplicates -- about one
+  // point search in four million on radar scans).  The wave settles it here, together: every lane looks at a 64th of the target
+  // for the lowest original index at that distance, about 10 us.  (Until round 4 the bit travelled to k_linearize, where the ONE
+  // lane that held the point walked the whole target: 1.1 ms for 8192 targets, during which its launch -- and with it the tick
+  // of every pair of a pooled batch -- stood still: one tie per batch of 32 loop-closure pairs was 1.03 -> 1.9 ms per batch.)
+  {
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      unsigned long long tmask = __ballot(pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && (bestc[s] & kTieBit) != 0);
+      while (tmask) {
+        const int l = __builtin_ctzll(tmask);
+        tmask &= tmask - 1;
+        const float qx = readlane_f(px[s], l), qy = readlane_f(py[s], l), qz = readlane_f(pz[s], l), qb = readlane_f(best[s], l);
+        unsigned long long key = ~0ull;  // (original index << 32 | sorted index) of the best candidate this lane has seen
+#pragma unroll 4
+        for (int g = lane; g < M; g += 64) {
+          const float4 t = G(tgt.pts)[g];
+          const unsigned long long k_ = ((unsigned long long)__float_as_uint(t.w) << 32) | (unsigned)g;  // (.w: the original index, >= 0)
+          if (sqdist1(t.x, t.y, t.z, qx, qy, qz) == qb && k_ < key) key = k_;
+        }
+        key = wave_min_u64(key);
+        if (lane == l && key != ~0ull) {
+          const int j = (int)(unsigned)key;
+          const float4 tq = G(tgt.pts)[j];
+          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+          bestc[s] = (unsigned)(j / kChunk) | kKeptBit;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & (kTieBit | kKeptBit));
+      if (resolve) {
+        const int c0 = (int)(bestc[s] & kChunkMask) * kChunk;
+        int j = -1, jorig = 0x7fffffff;
+        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int h = 0; h < kChunk; h += 8) {  // eight loads in flight at a time: 32 registers, not 64
+          float4 t[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; jj++) t[jj] = G(tgt.pts)[min(c0 + h + jj, M - 1)];
+#pragma unroll
+          for (int jj = 0; jj < 8; jj++) {
+            const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
+            const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
+            if (c0 + h + jj < M && d == best[s] && po < jorig) jorig = po, j = c0 + h + jj, tq = t[jj];
+          }
+        }
+        if (j >= 0) {
+          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
+          bestc[s] |= kKeptBit;
+        }
+      }
+    }
+  }
+  // what this search leaves behind for the next one (points that kept their neighbour keep their old record)
+  if (w.nnaux) {
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      const int i = pidx[s];
+      if (i < 0 || kept[s]) continue;
+      float sb = 0.f;
+      if (skin_on && !(bestc[s] & kTieBit) && bestc[s] != kNoChunk) {
+        // everything never scanned lies beyond the final pruning radius (radii only shrink); among the scanned targets the
+        // neighbour itself is g1 (if it is not, e.g. it was only ever seen as the hint, nothing is claimed)
+        if (g1[s] == best[s]) sb = fminf(g2[s], fmaf(best[s], k_mul, k_add));
+      } else if (skin_on && bestc[s] == kNoChunk) {
+        sb = fminf(g1[s], fmaf(best[s], k_mul, k_add));  // no target inside the cap: the nearest one seen, or the radius
+      }
+      w.nnaux[(size_t)pair * w.nstride + i] = make_float4(px[s], py[s], pz[s], sb);
+    }
+  }
+}
+
 // GIVEN = false: the classic form -- the W waves of the block share the points [base, base + 64 S) and warm-start them here.
 // GIVEN = true (k_nn_compact): the caller hands the points over -- px/py/pz/best/bestc/kept/hinted_in are inputs, pidx[s] is
 // the index of the point a lane works for (-1: none; such a lane must come in with kept = true).  With W == 1 the wave owns
@@ -1265,83 +1351,7 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       g1[s] = a1, g2[s] = a2;
     }
   }
-  // The exact index: among the targets of the winning chunk at distance `best`, the one with the lowest ORIGINAL index (ties
-  // resolve like a linear scan in the caller's point order).  Resolved here, by the waves that searched, and handed to k_linearize through nnpt + kKeptBit: the
-  // re-scan used to run in every wave of k_linearize that held a single point without the bit, i.e. in nearly all of them
-  // even when nine points in ten had kept their neighbour.  (Equal minima in several chunks -- kTieBit -- stay with
-  // k_linearize's scan of the whole target.)
-  // Equal minima in several chunks (kTieBit: two different targets at exactly the same fp32 distance, or duplicates -- about one
-  // point search in four million on radar scans).  The wave settles it here, together: every lane looks at a 64th of the target
-  // for the lowest original index at that distance, about 10 us.  (Until round 4 the bit travelled to k_linearize, where the ONE
-  // lane that held the point walked the whole target: 1.1 ms for 8192 targets, during which its launch -- and with it the tick
-  // of every pair of a pooled batch -- stood still: one tie per batch of 32 loop-closure pairs was 1.03 -> 1.9 ms per batch.)
-  if (wid == 0) {
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-      unsigned long long tmask = __ballot(pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && (bestc[s] & kTieBit) != 0);
-      while (tmask) {
-        const int l = __builtin_ctzll(tmask);
-        tmask &= tmask - 1;
-        const float qx = readlane_f(px[s], l), qy = readlane_f(py[s], l), qz = readlane_f(pz[s], l), qb = readlane_f(best[s], l);
-        unsigned long long key = ~0ull;  // (original index << 32 | sorted index) of the best candidate this lane has seen
-#pragma unroll 4
-        for (int g = lane; g < M; g += 64) {
-          const float4 t = G(tgt.pts)[g];
-          const unsigned long long k_ = ((unsigned long long)__float_as_uint(t.w) << 32) | (unsigned)g;  // (.w: the original index, >= 0)
-          if (sqdist1(t.x, t.y, t.z, qx, qy, qz) == qb && k_ < key) key = k_;
-        }
-        key = wave_min_u64(key);
-        if (lane == l && key != ~0ull) {
-          const int j = (int)(unsigned)key;
-          const float4 tq = G(tgt.pts)[j];
-          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
-          bestc[s] = (unsigned)(j / kChunk) | kKeptBit;
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-      const bool resolve = pidx[s] >= 0 && !kept[s] && bestc[s] != kNoChunk && !(bestc[s] & (kTieBit | kKeptBit));
-      if (resolve) {
-        const int c0 = (int)(bestc[s] & kChunkMask) * kChunk;
-        int j = -1, jorig = 0x7fffffff;
-        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-        for (int h = 0; h < kChunk; h += 8) {  // eight loads in flight at a time: 32 registers, not 64
-          float4 t[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; jj++) t[jj] = G(tgt.pts)[min(c0 + h + jj, M - 1)];
-#pragma unroll
-          for (int jj = 0; jj < 8; jj++) {
-            const float d = sqdist1(t[jj].x, t[jj].y, t[jj].z, px[s], py[s], pz[s]);
-            const int po = __float_as_int(t[jj].w);  // (the sorted points carry their original index in .w)
-            if (c0 + h + jj < M && d == best[s] && po < jorig) jorig = po, j = c0 + h + jj, tq = t[jj];
-          }
-        }
-        if (j >= 0) {
-          w.nnpt[(size_t)pair * w.nstride + pidx[s]] = make_float4(tq.x, tq.y, tq.z, __int_as_float(j));
-          bestc[s] |= kKeptBit;
-        }
-      }
-    }
-  }
-  // what this search leaves behind for the next one (points that kept their neighbour keep their old record)
-  if (w.nnaux && wid == 0) {
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-      const int i = pidx[s];
-      if (i < 0 || kept[s]) continue;
-      float sb = 0.f;
-      if (skin_on && !(bestc[s] & kTieBit) && bestc[s] != kNoChunk) {
-        // everything never scanned lies beyond the final pruning radius (radii only shrink); among the scanned targets the
-        // neighbour itself is g1 (if it is not, e.g. it was only ever seen as the hint, nothing is claimed)
-        if (g1[s] == best[s]) sb = fminf(g2[s], fmaf(best[s], k_mul, k_add));
-      } else if (skin_on && bestc[s] == kNoChunk) {
-        sb = fminf(g1[s], fmaf(best[s], k_mul, k_add));  // no target inside the cap: the nearest one seen, or the radius
-      }
-      w.nnaux[(size_t)pair * w.nstride + i] = make_float4(px[s], py[s], pz[s], sb);
-    }
-  }
+  if (wid == 0) nn_finish<S>(tgt, w, pair, lane, skin_on, k_mul, k_add, px, py, pz, best, bestc, pidx, kept, g1, g2);
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
   if (w.stats && lane == 0) {  // (W > 1: every wave of the block scanned its own share of the groups, reports it and counts as a wave)
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
@@ -1422,7 +1432,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
   const bool skin_on = !cold && w.nnaux != nullptr && w.skin_mul > 0.f;
   float Tf[12];
   load_Tf(T0, Tf);
-  const NNStart s0 = nn_warm_start(src, M, Tf, w, pair, valid ? i : N - 1, cold, skin_on);
+  NNStart s0 = nn_warm_start(src, M, Tf, w, pair, valid ? i : N - 1, cold, skin_on);
+#ifdef APD_ABL_SEARCH_KEEP_AFTER  // ABLATION builds only (wrong results by design): from linearize n on every hinted point counts as kept --
+                                  // what a step would cost if the late-tick searches were free (docs/experiments.md, round 5)
+  if (!w.init && st[pair].n_lin >= APD_ABL_SEARCH_KEEP_AFTER && s0.hinted && !s0.kept) s0.kept = true, s0.bestc |= kKeptBit;
+#endif
   unsigned long long* out = w.nnpart + (size_t)pair * w.T * w.nstride;  // T == 1 in this mode
   if (valid && s0.kept) out[i] = ((unsigned long long)__float_as_uint(s0.best) << 32) | s0.bestc;
   const bool active = valid && !s0.kept;
@@ -2021,6 +2035,12 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
     const int a = sub + L * t;
     e[t] = a < cnt ? row[a] : kKeyInf;
   }
+#ifdef APD_ABL_KNN_SKIP_C  // ABLATION builds only (wrong results by design): the first k list entries stand in for the k nearest -- what the
+                           // launch would cost without phase C's sorting network and merge rounds (docs/experiments.md, round 5)
+  int mysel[KNN_NC / L];
+#pragma unroll
+  for (int t = 0; t < KNN_NC / L; t++) mysel[t] = (sub + L * t < k && e[t] != kKeyInf) ? (int)(unsigned)e[t] : i;
+#else
   {
     auto cx = [&](int a, int b) {
       const unsigned long long x = e[a], y = e[b];
@@ -2080,6 +2100,7 @@ __device__ __forceinline__ void knn_cov_coop_wave(const CloudDesc& c, unsigned b
       }
     }
   }
+#endif  // APD_ABL_KNN_SKIP_C
   // gathers: lane sub fetches the neighbours of rank sub, sub+L, ... -- all loads in flight together
   float4 nbv[KNN_NC / L];
 #pragma unroll
