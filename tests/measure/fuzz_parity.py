@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch  # noqa
 reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
 import ref as R  # noqa
+import apdgicp_np as O  # noqa
 
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -164,6 +165,14 @@ while time.time() - t0 < BUDGET and (SEED1 is None or seed <= SEED1):
         g.setSourceCovariances(inject["source"])
     if "target" in inject:
         g.setTargetCovariances(inject["target"])
+    # apdgicp_nearest_neighbours (what serves the PCL base class's nearestKSearch, round 5): the ungated nearest target of every transformed
+    # source point -- index (lowest on ties, the lattices and duplicates have thousands) and fp32 distance -- against numpy's brute force
+    if len(src) * len(tgt) <= 6_000_000:
+        ni, nd = g.nearestNeighbours(T0.astype(np.float32))
+        wi, wd = O.nn1(O.transform_points_f32(T0.astype(np.float32).astype(np.float64), src, bool(kw.get("flags", 0) & 2)), tgt)
+        st["nn_checked"] = st.get("nn_checked", 0) + 1
+        if not (np.array_equal(ni, wi) and np.array_equal(nd.view(np.uint32), wd.view(np.uint32))):
+            st["nn_fail"] = st.get("nn_fail", 0) + 1; bad.append(f"nearest neighbours: {int((ni != wi).sum())} indices, {int((nd.view(np.uint32) != wd.view(np.uint32)).sum())} distances differ")
     c1, H1, b1 = g.linearize(T0); c2, H2, b2 = o.linearize(T0)
     cg, sg = g.correspondences(); co, so = o.correspondences()
     if not np.array_equal(cg, co):
