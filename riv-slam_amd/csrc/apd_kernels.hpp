@@ -2365,7 +2365,9 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     {  // fp32, as the reference evaluates it (float overloads, no FMA): not contracted.  apd_atan2f is glibc's generic atan2f
        // (fdlibm, include/apd_atan2f.h) restated: the device library's own atan2f is another ~1 ulp implementation
 #pragma clang fp contract(off)
-#ifdef APD_OCML_ATAN2F  // (A/B builds only, tools/ab_bench.sh: what the restated atan2f costs against the device library's)
+#if defined(APD_ABL_LIN_NO_ATAN)  // ABLATION builds only (wrong results by design): what the three atan2f cost
+#define APD_ATAN2F(y, x) ((y) * 0.01f + (x) * 0.001f)
+#elif defined(APD_OCML_ATAN2F)  // (A/B builds only, tools/ab_bench.sh: what the restated atan2f costs against the device library's)
 #define APD_ATAN2F(y, x) atan2f(y, x)
 #else
 #define APD_ATAN2F(y, x) apd_atan2f_tab(y, x, atan_tab)
@@ -2373,9 +2375,21 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       aoa = (double)APD_ATAN2F(ptx, sqrtf(pty * pty + ptz * ptz));
       elevation = (double)APD_ATAN2F(sqrtf(ptx * ptx + pty * pty), ptz);
       azimuth = (double)APD_ATAN2F(pty, ptx);
+#ifdef APD_ABL_LIN_DOUBLE_ATAN  // ABLATION builds only: the three atan2f evaluated a second time on other arguments, results never used (the
+                                // compiler cannot know): what they cost without changing a single result
+      const float a2 = APD_ATAN2F(ptx + 1.f, sqrtf(pty * pty + ptz * ptz)), e2 = APD_ATAN2F(sqrtf(ptx * ptx + pty * pty), ptz + 1.f), z2 = APD_ATAN2F(pty, ptx + 1.f);
+      if (a2 == 123.f) aoa = a2;
+      if (e2 == 123.f) elevation = e2;
+      if (z2 == 123.f) azimuth = z2;
+#endif
     }
     double sin_aoa, cos_aoa;
-    sincos_pi(aoa, &sin_aoa, &cos_aoa);
+#ifdef APD_ABL_LIN_NO_SINCOS  // ABLATION builds only (wrong results by design): what the three fp64 sin / cos pairs cost
+#define APD_SINCOS(x, s, c) (*(s) = (x), *(c) = 1.0 - 0.5 * (x) * (x))
+#else
+#define APD_SINCOS(x, s, c) sincos_pi(x, s, c)
+#endif
+    APD_SINCOS(aoa, &sin_aoa, &cos_aoa);
     (void)sin_aoa;
     // (A:169-171 divide three times -- dist * dist_var / 400, dist * sin(az) / cos(aoa), dist * sin(el) / cos(aoa); here one
     // division, dist / cos(aoa), and dist_var / 400 from the host: a rounding apart, like the contraction, 22 fp64 instructions less)
@@ -2384,8 +2398,20 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     const double s_y = dist_c * cst.sin_az;
     const double s_z = dist_c * cst.sin_el;
     double ce, se, caz, saz;
-    sincos_pi(elevation, &se, &ce);
-    sincos_pi(azimuth, &saz, &caz);
+#if defined(APD_ABL_LIN_NO_SINCOS) || defined(APD_SINCOS_NO_TABLE)  // (APD_SINCOS_NO_TABLE: A/B builds -- sincos_pi for all three angles, as until round 5)
+    APD_SINCOS(elevation, &se, &ce);
+    APD_SINCOS(azimuth, &saz, &caz);
+#else
+    sincos_tab(elevation, &se, &ce);  // rotation-matrix entries: from the table (apd_math.hpp); cos(AoA) above is a divisor and is not
+    sincos_tab(azimuth, &saz, &caz);
+#endif
+#ifdef APD_ABL_LIN_DOUBLE_SINCOS  // ABLATION builds only: three more fp64 sin / cos pairs whose results are never used
+    {
+      double s2, c2, s3, c3, s4, c4;
+      sincos_pi(elevation * 0.5, &s2, &c2), sincos_pi(azimuth * 0.5, &s3, &c3), sincos_pi(aoa * 0.5, &s4, &c4);
+      if (s2 + c2 + s3 + c3 + s4 + c4 == 123.0) se = s2;
+    }
+#endif
     // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
     const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
     const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;

@@ -70,6 +70,38 @@ APD_HD void sincos_pi(double x, double* so, double* co) {
   *co = ((n + 1) & 2) ? -cv : cv;
 }
 
+// sin and cos of an fp32-valued angle |x| <= pi from a table: x = k / 64 + d with k = rint(64 |x|) (d is EXACT: x is a float, k / 64 a
+// multiple of 2^-6 below 4), sin(k / 64) and cos(k / 64) correctly rounded (apd_sincos_tab.hpp, 202 rows, generated in 60-digit decimal
+// arithmetic), sin d and 1 - cos d from three-term series (|d| <= 2^-7: the next terms are below 4e-22), and the addition theorems written
+// around the table value: sin x = S + (C sin d - S u), cos x = C - (S sin d + C u), u = 1 - cos d.  About 23 fp64 operations and one
+// 16-byte load against ~42 operations of sincos_pi: the three pairs of a point were 42 us of a 0.73 ms step (measured by evaluating
+// them twice, docs/experiments.md round 5).  Absolute error ~1.5e-16; RELATIVE accuracy is lost next to a zero of the result (cos of
+// an angle a few ulps from pi / 2: 5e-11) -- which is why the angle of arrival, whose cosine is a DIVISOR (A:170-171), keeps sincos_pi
+// and only elevation and azimuth, whose sines and cosines are rotation-matrix entries, come from the table.
+#include "apd_sincos_tab.hpp"
+static __device__ const double apd_sincos_table[2 * APD_SINCOS_TAB_N] = APD_SINCOS_TAB_INIT;
+__device__ __forceinline__ void sincos_tab(double x, double* so, double* co) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define APD_TAB_AS1 __attribute__((address_space(1)))
+#else
+#define APD_TAB_AS1  // (the host pass only parses device functions)
+#endif
+  const double ax = fabs(x);
+  const double fk = rint(ax * 64.0);
+  const double d = fma(-fk, 0.015625, ax);
+  const int k = min((int)fk, APD_SINCOS_TAB_N - 1);
+  const double2 sc = ((const APD_TAB_AS1 double2*)apd_sincos_table)[k];
+  const double S = sc.x, C = sc.y;
+  const double z = d * d;
+  const double sd = fma(d * z, fma(z, fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01), d);
+  const double u = z * fma(z, fma(z, 1.38888888888888888889e-03, -4.16666666666666666667e-02), 0.5);
+  const double s = S + fma(C, sd, -(S * u));
+  const double c = C - fma(S, sd, C * u);
+  *so = x < 0.0 ? -s : s;
+  *co = c;
+#undef APD_TAB_AS1
+}
+
 // R * C * R^T for symmetric C (R = rows r0,r1,r2 of a Rigid)
 APD_HD Sym3 sym3_rotate(const Rigid& T, const Sym3& c) {
   // RC = R * C

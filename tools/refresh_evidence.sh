@@ -71,7 +71,7 @@ timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
 # parity beyond the test suite: the seeded sweep under both transform orders, the adversarial fuzz (five minutes of cases)
 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep.json 2> $ev/parity_sweep.err
 XF_FLAGS=2 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep_xflin.json 2>> $ev/parity_sweep.err
-timeout 500 python3 tests/measure/fuzz_parity.py 300 0 > $ev/fuzz_parity.json 2> $ev/fuzz_parity.err
+timeout 900 python3 tests/measure/fuzz_parity.py 800 0 4281 > $ev/fuzz_parity.json 2> $ev/fuzz_parity.err   # the committed seed range, whole
 timeout 400 python3 tests/measure/fuzz_batch.py 240 0 > $ev/fuzz_batch.json 2> $ev/fuzz_batch.err
 for d in $ev/p_fetch $ev/p_write $ev/p_insts $ev/p_busy $ev/p_occ $ev/p_lm_fetch $ev/p_lm_write $ev/p_lm_insts $ev/p_lm_busy $ev/ks_lm; do rm -rf $d; done
 find $ev/ks -type f ! -name "*.db" -delete
