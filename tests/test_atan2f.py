@@ -81,3 +81,19 @@ def test_device_atan2f_equals_the_host_bit_for_bit():
     host = R.atan2f(y, x)
     bad = ~_bits_equal(dev, host)
     assert not bad.any(), (int(bad.sum()), list(zip(y[bad][:10], x[bad][:10], dev[bad][:10], host[bad][:10])))
+
+
+def test_sincos_table_is_what_its_generator_writes(tmp_path):
+    """riv-slam_amd/csrc/apd_sincos_tab.hpp (sin / cos of k / 64, read by the kernels' sincos_tab) is generated: the committed file equals a
+    fresh run of tools/gen_sincos_tab.py (60-digit decimal Taylor series, no libm), and its entries are the correctly rounded values."""
+    import math
+    import re
+    import sys
+    out = tmp_path / "tab.hpp"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_sincos_tab.py"), str(out)])
+    committed = open(os.path.join(ROOT, "riv-slam_amd", "csrc", "apd_sincos_tab.hpp")).read()
+    assert out.read_text() == committed
+    vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[-+]?\d+", committed)]
+    assert len(vals) == 404
+    for k in range(202):   # (glibc's sin / cos are correctly rounded at these arguments: equality, not a tolerance)
+        assert vals[2 * k] == math.sin(k / 64) and vals[2 * k + 1] == math.cos(k / 64), k
