@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0
 VALU_WAVE_INSTR_PEAK = 62.0e12 / 64
 # the chip's theoretical VALU issue ceiling: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
 VALU_WAVE_INSTR_THEORETICAL = 1024 * 2.4e9 / 2
+SIMDS, GFX_CLOCK_HZ = 1024, 2.4e9   # (GRBM_GUI_ACTIVE / 8 XCDs / launch time under these kernels: 2.33 - 2.34 GHz, profiles/r05_pmc_occ.md)
 LM_LAUNCH = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)   # the launch file's registration parameters (LM, L:17)
 
 
@@ -418,10 +419,11 @@ def main():
                                  "time, against the measured plain-fp32 issue ceiling (62 Tlane-op/s / 64)"}
             # the whole step against the same roof: VALU instructions of every batch kernel x its launches per step / ms_per_step
             sk = pmc.get("step_kernels") or {}
-            per_step = 0.0
+            per_step, busy_units = 0.0, 0.0
             for name, cs in sk.items():
                 launches = GN_ITERS if ("k_nn_" in name or "k_linearize" in name) else 1
                 per_step += cs.get("SQ_INSTS_VALU", 0.0) * launches
+                busy_units += cs.get("SQ_ACTIVE_INST_VALU", 0.0) * launches
             if per_step > 0 and P == 32:
                 rate = per_step / (ms_per_step * 1e-3)
                 step_issue = {"bound": "valu-issue", "achieved": round(rate / 1e9, 1), "peak": round(VALU_WAVE_INSTR_PEAK / 1e9, 2),
@@ -429,7 +431,18 @@ def main():
                               "peak_theoretical": round(VALU_WAVE_INSTR_THEORETICAL / 1e9, 1), "frac_of_theoretical": round(rate / VALU_WAVE_INSTR_THEORETICAL, 4),
                               "valu_instructions_per_step": per_step, "source": pmc.get("source"),
                               "note": "sum over the step's batch kernels (search and linearize x 20 ticks, covariances, sort, pack) of their PMC "
-                                      "VALU instruction counts / ms_per_step"}
+                                      "VALU instruction counts / ms_per_step; `peak` is the ceiling of the FAST instruction class only (plain fp32 "
+                                      "add / mul / fma, integer add / logic / mov: 2.5 cycles per wave-instruction on a SIMD); everything else -- "
+                                      "min / max, compares, selects, shifts, DPP, readlane, packed fp32, all fp64 -- holds the SIMD for 4.3 "
+                                      "(tools/ubench_issue.hip, profiles/r05_ubench_issue.txt): see valu_busy"}
+                if busy_units > 0:
+                    # the profiler's own VALUBusy formula (SQ_ACTIVE_INST_VALU x 4 / SIMDs / gfx cycles) over the step: the counter advances by one
+                    # quad-cycle per vector instruction of either class, so this is an UPPER estimate by the share of fast-class instructions
+                    busy = busy_units * 4.0 / (SIMDS * GFX_CLOCK_HZ * ms_per_step * 1e-3)
+                    step_issue["valu_busy"] = round(busy, 3)
+                    step_issue["valu_busy_note"] = ("sum of SQ_ACTIVE_INST_VALU (quad-cycles) over the step's launches x 4 / (1024 SIMDs x 2.4 GHz x ms_per_step): "
+                                                    "the share of the step during which a SIMD's vector issue slot is held -- what binds the step; an upper "
+                                                    "estimate (fast-class instructions are counted at 4 cycles, they take 2.5)")
         out = {
             "metric": ("APD-GICP registrations/s (8k-pt scan pairs, GN-20, covariances recomputed)" if not lm else
                        "APD-GICP registrations/s (8k-pt pairs, Levenberg-Marquardt with the launch parameters, covariances recomputed)"),

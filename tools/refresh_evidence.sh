@@ -43,7 +43,7 @@ pass write "$PMC" WRITE_SIZE
 pass insts "$PMC" $INSTS
 pass busy "$PMC" $BUSY
 pass occ "$PMC" GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64
-dbs=$(for n in fetch write insts busy; do find $ev/p_$n -name "*.db" | head -1; done)
+dbs=$(for n in fetch write insts busy occ; do find $ev/p_$n -name "*.db" | head -1; done)
 python3 tools/pmc_nn_json.py $ev/pmc_nn_latest.json 8192 odometry $dbs > /dev/null && cp $ev/pmc_nn_latest.json profiles/pmc_nn_latest.json
 # the loop-closure regime (pooled LM ticks from the identity): the same passes
 pass lm_fetch "$LMC" FETCH_SIZE
