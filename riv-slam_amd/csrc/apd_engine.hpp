@@ -214,6 +214,7 @@ class Engine {
   Work work{};
   int nn_S = 1;
   int nn_W = 0;  // waves per block of k_nn_pruned<1, W> sharing the same 64 points (APDGICP_NN_W = 1, 2, 4; 0: by load)
+  int nn_sparse = 32;  // k_nn_compact: blocks with at most this many searching points take them one at a time (APDGICP_NN_SPARSE; 0: off)
   bool nn_pruned = true;   // exact bounding-box pruning on the Z-curve (APDGICP_NN_MODE=brute disables)
   // Neighbour keeping (nn_warm_start): a full search prunes with the squared radius r^2 (1 + skin_rel)^2 + skin_abs^2 instead of
   // r^2, which buys later iterations the right to keep the neighbour without searching while the point has moved by less than
@@ -321,6 +322,9 @@ class Engine {
     nn_skin = env_int("APDGICP_NN_SKIN", 1) != 0;
     // waves per search block: 0 = by load -- 8 / 4 while the batch is small enough to leave the GPU mostly empty (a single
     // registration: 35 -> 27 us per iteration), 2 otherwise (more lose there: every wave repeats the bounds and candidate tests)
+    // blocks of k_nn_compact with at most this many points still searching take the point-serial path (measured on the bench step,
+    // four alternations: off 0.7255, 24 / 32 / 40 / 48: 0.7136 / 0.7080 / 0.7084 / 0.7105 ms; one wave gathers the results: <= 64)
+    nn_sparse = std::min(64, std::max(0, env_int("APDGICP_NN_SPARSE", 32)));
     nn_W = env_int("APDGICP_NN_W", 0);
     if (nn_W != 1 && nn_W != 2 && nn_W != 4 && nn_W != 8) nn_W = 0;
     APD_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
@@ -1094,6 +1098,7 @@ class Engine {
     work.ticket = b_ticket.as<int>();
     work.init = nullptr;
     work.coop_search = 1;
+    work.sparse_max = nn_sparse;
     work.post = nullptr, work.post_seq = 0;
     work.pair0 = 0;
     work.npairs = npairs;
@@ -1690,6 +1695,7 @@ class Engine {
     w.stats = d_stats.as<unsigned long long>();
     w.ticket = pool.ticket.as<int>();
     w.coop_search = 1;
+    w.sparse_max = nn_sparse;
     w.pair0 = 0, w.npairs = cap;
     w.active = pool.L[0].active.as<int>();  // (t_work puts in the list that is being launched)
     nn_S = 1;  // (one source point per lane: the launch shape setup_pairs chooses for the pruned search)

@@ -162,6 +162,7 @@ struct Work {
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
   int coop_search;             // k_nn_compact: a block with at most 64 points left searches them with all of its waves
+  int sparse_max;              // k_nn_compact: ... and with at most this many, one point at a time with a whole wave (0: never)
   int xf_linear;               // fp32 summation order of T * p (A:149), see xf_row: 0 = pairwise (Eigen >= 3.3), 1 = linear chain (Eigen 3.2)
   const PollPost* post;        // non-null (k_error only): this launch is the last of a one-pair poll and writes the result record itself
                                // (post_result).  Not in k_linearize: with the record code in its last block the register allocator
@@ -947,8 +948,10 @@ __device__ __forceinline__ NNStart nn_warm_start(const CloudDesc& src, int M, co
   }
   if (skin_on) {
     const float4 a = w.nnaux[(size_t)pair * w.nstride + ii];
-    const float mv = sqrtf(sqdist1(a.x, a.y, a.z, o.px, o.py, o.pz));
-    const float lo = sqrtf(a.w) * (1.f - 4e-6f) - mv * (1.f + 4e-6f);
+    // (v_sqrt_f32 itself, 1 ulp: the library's correctly rounded sqrtf is that plus a dozen instructions of fix-up per call, and every
+    // factor of the test carries 4e-6 of slack; a denormal argument comes back as 0 -- a displacement below 1e-19 m, or no bound)
+    const float mv = __builtin_amdgcn_sqrtf(sqdist1(a.x, a.y, a.z, o.px, o.py, o.pz));
+    const float lo = __builtin_amdgcn_sqrtf(a.w) * (1.f - 4e-6f) - mv * (1.f + 4e-6f);
     // The record describes the targets OTHER than the neighbour on record, so it is only usable while that neighbour is
     // the one k_linearize last wrote: a neighbour that has left the cap (k_linearize then records "none") takes the full
     // search.  hint == -1 with a.w > 0: the last full search found no target inside the cap, and s covers every target.
@@ -1456,9 +1459,110 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     cci[pos] = make_int2((int)s0.bestc, i | (s0.hinted ? 0 : 1 << 30));
   }
   __syncthreads();
-  {
+  if (w.stats) {  // (uniform)
     const unsigned long long nkept = (unsigned long long)__popcll(__ballot(valid && s0.kept));  // (the ballot needs every lane)
-    if (w.stats && lane == 0) atomicAdd(w.stats + 6, nkept);
+    if (lane == 0) atomicAdd(w.stats + 6, nkept);
+  }
+  if (W > 1 && total > 0 && total <= w.sparse_max && M <= 64 * kGroupPts) {
+    // A FEW points left in this block (nine of 256 at tick 20 of a Gauss-Newton run, two or three dozen from tick 10 on): the
+    // cooperative search below then runs its whole machinery -- group masks, eight chunk tests and a staged LDS tile per group, the
+    // merge of four waves -- for lanes that are mostly empty: 700 wave-instructions per searching point at tick 20, what a brute-force
+    // scan of the target would cost.  Here instead the waves of the block take the points in turn (wave w: points w, w + W, ...; lane
+    // k of a wave keeps its k-th point's record) and work GROUP-major on registers: lane g holds the box of target group g (at most
+    // 64 groups) and collects, one point per trip, the bit mask of the wave's points that need it (radius: what the hint gave the
+    // point); every group some point needs is read ONCE straight from L2, two targets per lane, the next one in flight; each of its
+    // points (broadcast by readlane) takes its two distances per lane, and a lane whose distances are beyond the point's radius --
+    // nearly all of them -- drops out at one compare; the rest (the hint's target, a second candidate inside the skin) update the
+    // point's record one lane at a time.  No chunk tests, no LDS tile, no barrier before the end.  Any exact pruning gives the
+    // records of the brute-force search bit for bit (the radius only shrinks; what is never scanned lies beyond the final radius,
+    // which is also all the keep-bound of the next tick claims -- nn_finish).
+    const int ngroups = (M + kGroupPts - 1) / kGroupPts;
+    const float inf = __builtin_inff();
+    const float k_mul = skin_on ? w.skin_mul : 1.f, k_add = skin_on ? w.skin_add : 0.f;
+    float4* resv = (float4*)txy;  // [point] {best, g1, g2, bits of bestc} (the tiles are not used on this path)
+    Box mybox = G(tgt.gbox)[min(lane, ngroups - 1)];
+    if (lane >= ngroups) mybox = Box{inf, inf, inf, inf, inf, inf};
+    const int np = total > wid ? (total - wid + W - 1) / W : 0;  // points of this wave (<= 16 W / W ... at most 64 / W * ... <= 64)
+    const bool hask = lane < np;
+    const int ek = wid + W * (hask ? lane : 0);
+    unsigned n_groups = 0;
+    {
+      const float4 cp = cpt[ek];
+      const int2 ci = cci[ek];
+      const float px = cp.x, py = cp.y, pz = cp.z;
+      float best = cp.w, g1 = inf, g2 = inf;
+      unsigned bestc = (unsigned)ci.x;
+      float bestR = fmaf(best, k_mul, k_add);
+      unsigned long long pmask = 0;  // bit k: this lane's group is needed by point k of the wave
+      for (int k = 0; k < np; k++) {
+        const float qx = readlane_f(px, k), qy = readlane_f(py, k), qz = readlane_f(pz, k), qR = readlane_f(bestR, k);
+        if (lb_point_box(mybox, qx, qy, qz) <= qR) pmask |= 1ull << k;
+      }
+      unsigned long long un = __ballot(pmask != 0);
+      float4 a = make_float4(inf, inf, inf, 0.f), b = a;
+      int gcur = -1;
+      auto fetch = [&](int g) {  // (unconditional, clamped)
+        const int j = g * kGroupPts + 2 * lane;
+        a = G(tgt.pts)[min(j, M - 1)];
+        b = G(tgt.pts)[min(j + 1, M - 1)];
+        gcur = g;
+      };
+      int g = un ? __builtin_ctzll(un) : -1;
+      if (g >= 0) un &= un - 1, fetch(g);
+      while (g >= 0) {
+        float4 ca = a, cb = b;
+        const int gg = gcur;
+        if ((gg + 1) * kGroupPts > M) {  // (uniform) only the last group of a cloud can reach beyond it
+          const int j = gg * kGroupPts + 2 * lane;
+          if (j >= M) ca = make_float4(inf, inf, inf, 0.f);
+          if (j + 1 >= M) cb = make_float4(inf, inf, inf, 0.f);
+        }
+        unsigned long long pm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pmask >> 32), gg) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pmask, gg);
+        g = un ? __builtin_ctzll(un) : -1;
+        if (g >= 0) un &= un - 1, fetch(g);  // the next group travels while this one is looked at
+        n_groups++;
+        const v2f X = {ca.x, cb.x}, Y = {ca.y, cb.y}, Z = {ca.z, cb.z};
+        while (pm) {
+          const int k = __builtin_ctzll(pm);
+          pm &= pm - 1;
+          const float qx = readlane_f(px, k), qy = readlane_f(py, k), qz = readlane_f(pz, k), qR = readlane_f(bestR, k);
+          const v2f dx = X - qx, dy = Y - qy, dz = Z - qz;  // (sqdist1's operations in sqdist1's order, per target)
+          v2f r = dx * dx;
+          r = r + dy * dy;
+          r = r + dz * dz;
+          const float m = fminf(r.x, r.y), m2 = fmaxf(r.x, r.y);
+          unsigned long long hits = __ballot(m <= qR);
+          while (hits) {
+            const int l = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const float ml = readlane_f(m, l), m2l = readlane_f(m2, l);
+            const unsigned c = (unsigned)(gg * kGroupChunks + (l >> 3));  // lane l: targets 2 l and 2 l + 1 of the group
+            if (lane == k) {
+              g2 = fminf(fmaxf(g1, ml), fminf(g2, m2l));
+              g1 = fminf(g1, ml);
+              if (ml < best) best = ml, bestc = c, bestR = fmaf(ml, k_mul, k_add);
+              else if (ml == best && ml < inf && (bestc & kChunkMask) != c) bestc |= kTieBit;
+            }
+          }
+        }
+      }
+      if (hask) resv[ek] = make_float4(best, g1, g2, __uint_as_float(bestc));
+    }
+    __syncthreads();
+    if (wid != 0) return;
+    if (w.stats && lane == 0) atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 3, 1ull);
+    const bool has = lane < total;
+    const float4 cp = cpt[has ? lane : total - 1];
+    const int2 ci = cci[has ? lane : total - 1];
+    const float4 rv = resv[has ? lane : total - 1];
+    float px[1] = {cp.x}, py[1] = {cp.y}, pz[1] = {cp.z}, best[1] = {rv.x}, g1[1] = {rv.y}, g2[1] = {rv.z};
+    unsigned bestc[1] = {__float_as_uint(rv.w)};
+    int pidx[1] = {has ? (ci.y & ~(1 << 30)) : -1};
+    bool kept[1] = {!has};
+    nn_finish<1>(tgt, w, pair, lane, skin_on, k_mul, k_add, px, py, pz, best, bestc, pidx, kept, g1, g2);
+    if (has) out[pidx[0]] = ((unsigned long long)__float_as_uint(best[0]) << 32) | bestc[0];
+    return;
   }
   if (W > 1 && w.coop_search && total > 0 && total <= 64) {
     // One wave's worth of points left in this block (the usual case from the middle of a Gauss-Newton run on: 63 of 256

@@ -896,9 +896,14 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind, flags):
             # points still searching into fewer waves; a block with one wave's worth of points left searches them with all
             # four waves) -- APDGICP_NN_W=1: six pairs are too few for the engine to choose that regime by itself -- and the
             # same regime without keeping (one-wave blocks of k_nn_pruned)
-            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, {"APDGICP_NN_W": "1"})
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, {"APDGICP_NN_W": "1"},
+            # ... and its blocks with only a FEW points left: the point-serial path (targets of at most 8192 points; default: up to 32
+            # points per block) off, for every block the cooperative search would take, and for a handful of points only
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SPARSE": "0"}, {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SPARSE": "64"},
+            {"ONE_GROUP": "1", "APDGICP_NN_W": "1", "APDGICP_NN_SPARSE": "5"})
     for kw in (gn, lm):
         want = None
+        chunk_scans = {}
         for env in envs:
             env = dict(env)
             one_group = env.pop("ONE_GROUP", None)
@@ -911,6 +916,11 @@ def test_kept_neighbours_are_the_searched_neighbours(reg, scene, kind, flags):
             got = res.tobytes()
             want = want or got
             assert got == want, (env, kw is gn)
+            if "APDGICP_NN_SPARSE" in env:
+                chunk_scans[env["APDGICP_NN_SPARSE"]] = st[2]
+        if not any(os.environ.get(v) for v in ("APDGICP_NN_SKIN", "APDGICP_NN_MODE", "APDGICP_NN_SPARSE")):
+            # the point-serial path scans no chunks: the more blocks take it, the fewer chunk scans the other paths are left with
+            assert chunk_scans["64"] < chunk_scans["5"] < chunk_scans["0"], chunk_scans
             if env.get("APDGICP_NN_SKIN") == "0" or env.get("APDGICP_NN_MODE") == "brute":
                 assert st[6] == 0
             elif kw is gn and not any(os.environ.get(v) for v in ("APDGICP_NN_SKIN", "APDGICP_NN_MODE")):   # (tools/knob_matrix.sh switches that turn keeping off)
@@ -1082,7 +1092,8 @@ def test_exact_ties_resolve_to_the_lowest_original_index(reg):
     gn = dict(optimizer=1, max_iterations=3, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=3.0)
     want = None
     for env, one_group in (({"APDGICP_NN_MODE": "brute"}, False), ({}, False), ({"APDGICP_NN_W": "1"}, True), ({"APDGICP_NN_W": "2"}, False),
-                           ({"APDGICP_NN_W": "4"}, False), ({"APDGICP_NN_W": "8"}, False), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True)):
+                           ({"APDGICP_NN_W": "4"}, False), ({"APDGICP_NN_W": "8"}, False), ({"APDGICP_NN_W": "1", "APDGICP_NN_SKIN": "0"}, True),
+                           ({"APDGICP_NN_W": "1", "APDGICP_NN_SPARSE": "0"}, True), ({"APDGICP_NN_W": "1", "APDGICP_NN_SPARSE": "64"}, True)):
         b = _handle_with_env(reg, reg.BatchAPDGICP, env, **gn)
         if one_group:
             b.set_pair_groups(1)
