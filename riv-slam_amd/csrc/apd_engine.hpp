@@ -1205,7 +1205,9 @@ class Engine {
     } else if (nn_S == 2) APD_NN_LAUNCH(k_nn_partial<2>, NN_BLK);
     else APD_NN_LAUNCH(k_nn_partial<4>, NN_BLK);
 #undef APD_NN_LAUNCH
-    if (in_pool && pool.cur_timed && sp.np >= 8) pool.timed_kernel = last_nn_kernel;  // (not the few-pair tail of a draining pool: another block shape)
+    // the kernel bench.py names: that of the LARGEST timed launch so far (the few-pair tail of a draining pool gets another block shape,
+    // and whether the last timed launch of a run is such a tail is a matter of timing)
+    if (in_pool && pool.cur_timed && sp.np >= pool.timed_kernel_np) pool.timed_kernel = last_nn_kernel, pool.timed_kernel_np = sp.np;
     return 0;
   }
 
@@ -1573,7 +1575,8 @@ class Engine {
     };
     std::vector<Timed> timed;
     Timed* cur_timed = nullptr;      // set around the launch_nn that is to be timed
-    const char* timed_kernel = "";   // the search kernel of the last timed launch
+    const char* timed_kernel = "";   // the search kernel of the largest timed launch
+    int timed_kernel_np = 0;
     double nn_ms = 0;                // harvested since the last read (apdgicp_batch_last_nn_profile)
     long long nn_launches = 0, nn_pairs = 0;
   } pool;
