@@ -1463,13 +1463,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const unsigned long long nkept = (unsigned long long)__popcll(__ballot(valid && s0.kept));  // (the ballot needs every lane)
     if (lane == 0) atomicAdd(w.stats + 6, nkept);
   }
-  if (W > 1 && total > 0 && total <= w.sparse_max && M <= 64 * kGroupPts) {
+  if (W > 1 && total > 0 && total <= w.sparse_max && M <= SORT_LDS_MAX_N) {
     // A FEW points left in this block (nine of 256 at tick 20 of a Gauss-Newton run, two or three dozen from tick 10 on): the
     // cooperative search below then runs its whole machinery -- group masks, eight chunk tests and a staged LDS tile per group, the
     // merge of four waves -- for lanes that are mostly empty: 700 wave-instructions per searching point at tick 20, what a brute-force
     // scan of the target would cost.  Here instead the waves of the block take the points in turn (wave w: points w, w + W, ...; lane
-    // k of a wave keeps its k-th point's record) and work GROUP-major on registers: lane g holds the box of target group g (at most
-    // 64 groups) and collects, one point per trip, the bit mask of the wave's points that need it (radius: what the hint gave the
+    // k of a wave keeps its k-th point's record) and work GROUP-major on registers: lane g holds the box of target group g (64 groups at a
+    // time, at most 128: targets of up to 16384 points) and collects, one point per trip, the bit mask of the wave's points that need it (radius: what the hint gave the
     // point); every group some point needs is read ONCE straight from L2, two targets per lane, the next one in flight; each of its
     // points (broadcast by readlane) takes its two distances per lane, and a lane whose distances are beyond the point's radius --
     // nearly all of them -- drops out at one compare; the rest (the hint's target, a second candidate inside the skin) update the
@@ -1480,8 +1480,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const float inf = __builtin_inff();
     const float k_mul = skin_on ? w.skin_mul : 1.f, k_add = skin_on ? w.skin_add : 0.f;
     float4* resv = (float4*)txy;  // [point] {best, g1, g2, bits of bestc} (the tiles are not used on this path)
-    Box mybox = G(tgt.gbox)[min(lane, ngroups - 1)];
-    if (lane >= ngroups) mybox = Box{inf, inf, inf, inf, inf, inf};
+    const Box nobox{inf, inf, inf, inf, inf, inf};
+    Box mybox = G(tgt.gbox)[min(lane, ngroups - 1)], mybox1 = G(tgt.gbox)[min(64 + lane, ngroups - 1)];  // (both requested now)
+    if (lane >= ngroups) mybox = nobox;
+    if (64 + lane >= ngroups) mybox1 = nobox;
     const int np = total > wid ? (total - wid + W - 1) / W : 0;  // points of this wave (<= 16 W / W ... at most 64 / W * ... <= 64)
     const bool hask = lane < np;
     const int ek = wid + W * (hask ? lane : 0);
@@ -1493,56 +1495,59 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
       float best = cp.w, g1 = inf, g2 = inf;
       unsigned bestc = (unsigned)ci.x;
       float bestR = fmaf(best, k_mul, k_add);
-      unsigned long long pmask = 0;  // bit k: this lane's group is needed by point k of the wave
-      for (int k = 0; k < np; k++) {
-        const float qx = readlane_f(px, k), qy = readlane_f(py, k), qz = readlane_f(pz, k), qR = readlane_f(bestR, k);
-        if (lb_point_box(mybox, qx, qy, qz) <= qR) pmask |= 1ull << k;
-      }
-      unsigned long long un = __ballot(pmask != 0);
-      float4 a = make_float4(inf, inf, inf, 0.f), b = a;
-      int gcur = -1;
-      auto fetch = [&](int g) {  // (unconditional, clamped)
-        const int j = g * kGroupPts + 2 * lane;
-        a = G(tgt.pts)[min(j, M - 1)];
-        b = G(tgt.pts)[min(j + 1, M - 1)];
-        gcur = g;
-      };
-      int g = un ? __builtin_ctzll(un) : -1;
-      if (g >= 0) un &= un - 1, fetch(g);
-      while (g >= 0) {
-        float4 ca = a, cb = b;
-        const int gg = gcur;
-        if ((gg + 1) * kGroupPts > M) {  // (uniform) only the last group of a cloud can reach beyond it
-          const int j = gg * kGroupPts + 2 * lane;
-          if (j >= M) ca = make_float4(inf, inf, inf, 0.f);
-          if (j + 1 >= M) cb = make_float4(inf, inf, inf, 0.f);
-        }
-        unsigned long long pm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pmask >> 32), gg) << 32) |
-                                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pmask, gg);
-        g = un ? __builtin_ctzll(un) : -1;
-        if (g >= 0) un &= un - 1, fetch(g);  // the next group travels while this one is looked at
-        n_groups++;
-        const v2f X = {ca.x, cb.x}, Y = {ca.y, cb.y}, Z = {ca.z, cb.z};
-        while (pm) {
-          const int k = __builtin_ctzll(pm);
-          pm &= pm - 1;
+      for (int gb0 = 0; gb0 < ngroups; gb0 += 64) {  // (the second 64 groups with the radii the first left behind)
+        if (gb0) mybox = mybox1;
+        unsigned long long pmask = 0;  // bit k: this lane's group is needed by point k of the wave
+        for (int k = 0; k < np; k++) {
           const float qx = readlane_f(px, k), qy = readlane_f(py, k), qz = readlane_f(pz, k), qR = readlane_f(bestR, k);
-          const v2f dx = X - qx, dy = Y - qy, dz = Z - qz;  // (sqdist1's operations in sqdist1's order, per target)
-          v2f r = dx * dx;
-          r = r + dy * dy;
-          r = r + dz * dz;
-          const float m = fminf(r.x, r.y), m2 = fmaxf(r.x, r.y);
-          unsigned long long hits = __ballot(m <= qR);
-          while (hits) {
-            const int l = __builtin_ctzll(hits);
-            hits &= hits - 1;
-            const float ml = readlane_f(m, l), m2l = readlane_f(m2, l);
-            const unsigned c = (unsigned)(gg * kGroupChunks + (l >> 3));  // lane l: targets 2 l and 2 l + 1 of the group
-            if (lane == k) {
-              g2 = fminf(fmaxf(g1, ml), fminf(g2, m2l));
-              g1 = fminf(g1, ml);
-              if (ml < best) best = ml, bestc = c, bestR = fmaf(ml, k_mul, k_add);
-              else if (ml == best && ml < inf && (bestc & kChunkMask) != c) bestc |= kTieBit;
+          if (lb_point_box(mybox, qx, qy, qz) <= qR) pmask |= 1ull << k;
+        }
+        unsigned long long un = __ballot(pmask != 0);
+        float4 a = make_float4(inf, inf, inf, 0.f), b = a;
+        int gcur = -1;
+        auto fetch = [&](int g) {  // (unconditional, clamped)
+          const int j = (gb0 + g) * kGroupPts + 2 * lane;
+          a = G(tgt.pts)[min(j, M - 1)];
+          b = G(tgt.pts)[min(j + 1, M - 1)];
+          gcur = g;
+        };
+        int g = un ? __builtin_ctzll(un) : -1;
+        if (g >= 0) un &= un - 1, fetch(g);
+        while (g >= 0) {
+          float4 ca = a, cb = b;
+          const int gl = gcur, gg = gb0 + gcur;
+          if ((gg + 1) * kGroupPts > M) {  // (uniform) only the last group of a cloud can reach beyond it
+            const int j = gg * kGroupPts + 2 * lane;
+            if (j >= M) ca = make_float4(inf, inf, inf, 0.f);
+            if (j + 1 >= M) cb = make_float4(inf, inf, inf, 0.f);
+          }
+          unsigned long long pm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pmask >> 32), gl) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pmask, gl);
+          g = un ? __builtin_ctzll(un) : -1;
+          if (g >= 0) un &= un - 1, fetch(g);  // the next group travels while this one is looked at
+          n_groups++;
+          const v2f X = {ca.x, cb.x}, Y = {ca.y, cb.y}, Z = {ca.z, cb.z};
+          while (pm) {
+            const int k = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            const float qx = readlane_f(px, k), qy = readlane_f(py, k), qz = readlane_f(pz, k), qR = readlane_f(bestR, k);
+            const v2f dx = X - qx, dy = Y - qy, dz = Z - qz;  // (sqdist1's operations in sqdist1's order, per target)
+            v2f r = dx * dx;
+            r = r + dy * dy;
+            r = r + dz * dz;
+            const float m = fminf(r.x, r.y), m2 = fmaxf(r.x, r.y);
+            unsigned long long hits = __ballot(m <= qR);
+            while (hits) {
+              const int l = __builtin_ctzll(hits);
+              hits &= hits - 1;
+              const float ml = readlane_f(m, l), m2l = readlane_f(m2, l);
+              const unsigned c = (unsigned)(gg * kGroupChunks + (l >> 3));  // lane l: targets 2 l and 2 l + 1 of the group
+              if (lane == k) {
+                g2 = fminf(fmaxf(g1, ml), fminf(g2, m2l));
+                g1 = fminf(g1, ml);
+                if (ml < best) best = ml, bestc = c, bestR = fmaf(ml, k_mul, k_add);
+                else if (ml == best && ml < inf && (bestc & kChunkMask) != c) bestc |= kTieBit;
+              }
             }
           }
         }

@@ -73,6 +73,6 @@ for tag, kw in (("batch_8k_gn20", dict(optimizer=1, max_iterations=20, transform
 out["seconds"] = round(time.time() - t0, 1)
 out["transform_order"] = "linear chain (APDGICP_FLAG_XF_LINEAR_CHAIN, Eigen 3.2)" if XF & 2 else "pairwise (default, Eigen >= 3.3)"
 out["note"] = ("GPU (libapdgicp_hip.so through the C ABI) vs oracle/apdgicp_ref.cpp; info = (converged, iterations, n_linearize, n_compute_error); "
-               "a differing iteration count on an ill-conditioned LM run is possible (fp32 atan2f ulp, summation order) and is not a parity failure "
+               "a differing iteration count on an ill-conditioned LM run is possible (summation order of the 29 sums: the angles are bit-equal since round 5, include/apd_atan2f.h) and is not a parity failure "
                "as long as the pose bars hold")
 print(json.dumps(out, indent=1))
