@@ -806,6 +806,23 @@ int ref_knn_kdtree(void* h, int which, const float* q, int k, int* out_idx, floa
   return (int)heap.size();
 }
 
+// many queries at once (nq x 3): k entries per query in (distance, index) order, missing ones -1 / +inf
+int ref_knn_kdtree_batch(void* h, int which, const float* q, int nq, int k, int* out_idx, float* out_d) {
+  Ref* r = (Ref*)h;
+  Cloud& c = which == 0 ? r->src : r->tgt;
+  ensure_tree(c);
+#pragma omp parallel for schedule(guided, 8)
+  for (int i = 0; i < nq; i++) {
+    std::vector<Cand> heap;
+    c.tree.search(F3{q[3 * i], q[3 * i + 1], q[3 * i + 2]}, k, heap);
+    for (int j = 0; j < k; j++) {
+      out_idx[(size_t)i * k + j] = j < (int)heap.size() ? heap[j].idx : -1;
+      out_d[(size_t)i * k + j] = j < (int)heap.size() ? heap[j].d : __builtin_inff();
+    }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scan-to-submap target assembly, restated from
 //   /root/reference/radar_graph_slam/apps/scan_matching_odometry_nodelet.cpp:606-618 (transform + concatenate)

@@ -88,6 +88,7 @@ def lib():
         L.ref_atan2f.restype = None
         L.ref_knn_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_knn_kdtree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_knn_kdtree_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_submap_assemble.restype = C.c_longlong
         L.ref_submap_assemble.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -215,6 +216,43 @@ class RefAPDGICP:
         qq = np.ascontiguousarray(q, dtype=np.float32)
         n = self.L.ref_knn_kdtree(self.h, 0 if which == "source" else 1, _ptr(qq), k, _ptr(idx), _ptr(d))
         return idx[:n], d[:n]
+
+
+    def knn_kdtree_batch(self, which: str, q, k: int):
+        """k nearest neighbours of every row of q [nq, 3] through the restatement's kd-tree: (idx [nq, k], fp32 d2 [nq, k])."""
+        qq = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+        idx = np.empty((len(qq), k), dtype=np.int32)
+        d = np.empty((len(qq), k), dtype=np.float32)
+        self.L.ref_knn_kdtree_batch(self.h, 0 if which == "source" else 1, _ptr(qq), len(qq), k, _ptr(idx), _ptr(d))
+        return idx, d
+
+
+REF_NANOFLANN = "/root/reference/radar_graph_slam/include/scan_context/nanoflann.hpp"
+
+
+def nanoflann_lib():
+    """oracle/_ref/libnanoflann_nn.so -- the reference tree's own header-only nanoflann (ScanContext module) behind a 40-line harness
+    (oracle/nanoflann_harness.cpp), compiled from the header where it lies.  None when /root/reference is absent (the GPU box)."""
+    path = os.path.join(_HERE, "_ref", "libnanoflann_nn.so")
+    if os.path.exists(REF_NANOFLANN):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_ref/libnanoflann_nn.so"])
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.nf_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.nf_knn.restype = C.c_int
+    return L
+
+
+def nanoflann_knn(cloud, q, k: int, leaf_max_size: int = 10):
+    L = nanoflann_lib()
+    assert L is not None
+    cc = np.ascontiguousarray(cloud, dtype=np.float32).reshape(-1, 3)
+    qq = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 3)
+    idx = np.empty((len(qq), k), dtype=np.int32)
+    d = np.empty((len(qq), k), dtype=np.float32)
+    L.nf_knn(_ptr(cc), len(cc), _ptr(qq), len(qq), k, leaf_max_size, _ptr(idx), _ptr(d))
+    return idx, d
 
 
 def atan2f(y, x) -> np.ndarray:

@@ -55,6 +55,48 @@ def test_kdtree_ties_pick_lowest_index():
     assert list(idx) == [24, 25, 26]
 
 
+def _nanoflann_cases(golden):
+    """(name, target cloud, queries): the golden pair at its guess and two 8k bench pairs at theirs, the source transformed in fp32 under
+    BOTH orders Eigen can give T * p (A:137,149), plus the target against itself (the covariance k-NN, A:318)."""
+    import importlib
+    scene = importlib.import_module("riv-slam_amd.scene")
+    cases = []
+    pairs = [("golden", golden["lin_source"], golden["lin_target"], golden["lin_guess"])]
+    for p in (0, 1):
+        s, t, _, g = scene.make_pair(8192, 8192, scene.pair_seed(2, p), "odometry")
+        pairs.append((f"bench{p}", s, t, g))
+    for name, s, t, g in pairs:
+        for lin in (False, True):
+            cases.append((f"{name}/{'linear' if lin else 'pairwise'}", t, O.transform_points_f32(np.asarray(g, dtype=np.float32), s, lin)))
+        cases.append((f"{name}/self", t, t))
+    return cases
+
+
+@pytest.mark.skipif(R.nanoflann_lib() is None, reason="/root/reference (nanoflann.hpp of the ScanContext module) is not present on this box")
+def test_kdtree_against_the_reference_trees_own_nanoflann(golden):
+    """VERDICT r05 item 6.  The reference tree holds ONE exact nearest-neighbour implementation that compiles in this image:
+    radar_graph_slam/include/scan_context/nanoflann.hpp with L2_Simple_Adaptor<float> (:423-446) -- FLANN's L2_Simple accumulation
+    order.  The oracle's kd-tree (the piece SURVEY 7 hard-part 2 calls the parity risk) must return the same fp32 distances BIT FOR
+    BIT for 1-NN and 20-NN, and the same indices wherever the distance is unique among the cloud's points (ties: FLANN's order is
+    unspecified, the oracle's is the lowest index).  It is ScanContext's tree, not the path's FLANN: the cap "parity unpinned" stays."""
+    for name, tgt, q in _nanoflann_cases(golden):
+        r = R.RefAPDGICP()
+        r.setInputTarget(tgt)
+        for k in (1, 20):
+            for leaf in (10, 15):   # nanoflann's default leaf size and the one PCL's FLANN index is built with: exact either way
+                ni, nd = R.nanoflann_knn(tgt, q, k, leaf)
+                oi, od = r.knn_kdtree_batch("target", q, k)
+                assert np.array_equal(nd.view(np.uint32), od.view(np.uint32)), (name, k, leaf)
+                # a distance is unique for its query when its neighbours in the sorted list differ and nothing BEHIND the list equals the last entry
+                uniq = np.ones_like(od, dtype=bool)
+                uniq[:, 1:] &= od[:, 1:] != od[:, :-1]
+                uniq[:, :-1] &= od[:, :-1] != od[:, 1:]
+                ki, kd = r.knn_kdtree_batch("target", q, k + 1)
+                uniq[:, -1] &= kd[:, k] != od[:, -1]
+                assert np.array_equal(ni[uniq], oi[uniq]), (name, k, leaf)
+                assert uniq.mean() > 0.98, (name, k, float(uniq.mean()))
+
+
 # fp32 summation order of T * p (A:149): pairwise (Eigen >= 3.3, default) | linear chain (Eigen 3.2, flags bit 1)
 XF = (pytest.param("", 0, id="xf_pairwise"), pytest.param("_xflin", 2, id="xf_linear"))
 

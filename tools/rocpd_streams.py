@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
-"""Steady-state stream occupancy of a rocprofv3 kernel trace: for the middle part of the trace, per HIP stream the share of
-time a kernel of that stream was running, its kernels, and the share of time at least one / at least two kernels were running.
-usage: rocpd_streams.py results.db [keep=0.5]   (keep: the central fraction of the trace that is analysed)"""
+"""Steady-state stream occupancy of a rocprofv3 kernel trace: per HIP stream the share of time a kernel of that stream was
+running, its kernels, and the share of time at least one / at least two kernels were running.
+The window is anchored on the BATCHES, not on the trace's clock: the per-batch covariance launches (k_knn_cov_coop with grid y >= 8,
+one per batch of a pooled LM run) are counted, and the window runs from the start of launch number lo x count to the start of launch
+number hi x count (default 0.45 .. 0.90: behind the warm-up and the pool's ramp-up, in front of the drain; round 5's version took the
+middle half of the trace's TIME, which begins with the first kernel of the process and covered the ramp-up).  The window's length /
+batches inside it is printed as ms per batch: it must agree with the figure the traced program printed itself.
+usage: rocpd_streams.py results.db [lo=0.45] [hi=0.90]   (a trace without such launches: the central part of the time axis)"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-keep = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.45
+hi = float(sys.argv[3]) if len(sys.argv) > 3 else 0.90
 rows = db.execute("select name, start, end, stream_id, grid_y from kernels order by start").fetchall()
 t0, t1 = rows[0][1], max(r[2] for r in rows)
-a, b = t0 + (t1 - t0) * (0.5 - keep / 2), t0 + (t1 - t0) * (0.5 + keep / 2)
-rows = [r for r in rows if r[1] >= a and r[2] <= b]
+anchors = [r[1] for r in rows if "k_knn_cov_coop" in r[0] and r[4] >= 8]
+if len(anchors) >= 20:
+    i0, i1 = int(lo * len(anchors)), min(len(anchors) - 1, int(hi * len(anchors)))
+    a, b = anchors[i0], anchors[i1]
+    print(f"window: batches {i0} .. {i1} of {len(anchors)} (per-batch covariance launches): {(b - a) / 1e6 / (i1 - i0):.4f} ms per batch inside it")
+else:
+    a, b = t0 + (t1 - t0) * lo, t0 + (t1 - t0) * hi
+# a launch counts with the part of it that lies inside the window
+rows = [(n, max(s, a), min(e, b), st, gy) for n, s, e, st, gy in rows if e > a and s < b]
 span = b - a
 
 
