@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define APDGICP_ABI_VERSION 5   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots;
+#define APDGICP_ABI_VERSION 6   /* 2: + inlier_fraction, wait_producer, get_stream; 3: pooled LM batches (enqueue never blocks), + batch_pump, sparse cloud slots;
                                    4: T*p is summed pairwise by default (Eigen >= 3.3), APDGICP_FLAG_XF_LINEAR_CHAIN selects the former order;
                                    5: the three fp32 angles of the sensor model (A:168,172-173) through glibc's atan2f algorithm (apd_atan2f.h) instead of the
-                                      device library's; + source_stamp, set_trace / get_trace, debug_atan2f */
+                                      device library's; + source_stamp, set_trace / get_trace, debug_atan2f;
+                                   6: + APDGICP_FLAG_ALGEBRAIC_APD, build_flags, nearest_neighbours_of, get_trace_step_norms */
 
 typedef enum {
   APDGICP_OK = 0,
@@ -73,7 +74,19 @@ typedef enum {
  * angles are unchanged, so correspondences are identical at a given pose.  Measured: final poses move by
  * ~1e-6 m / 1e-7 rad against the default, a Levenberg-Marquardt run may stop an iteration earlier or later.  The default (flag
  * clear) is the reference's precision; bench.py's headline runs with the flag clear. */
-enum { APDGICP_FLAG_PLAIN_GICP = 1, APDGICP_FLAG_XF_LINEAR_CHAIN = 2, APDGICP_FLAG_FP32_POINT_MATH = 4 };
+/* ALGEBRAIC_APD (opt-in, not the reference's arithmetic; ABI 6): the sensor model of A:167-184 without its three fp32 atan2 calls and
+ * three fp64 sin / cos pairs.  The reference rounds the angle of arrival, the elevation (polar from +z) and the azimuth of the
+ * transformed point to fp32 and takes fp64 sines and cosines of those; everything the model USES of them are ratios of the point's own
+ * coordinates, which this mode forms directly in fp64 from the fp32 transformed point (x, y, z):
+ *     cos(az) = x / rho, sin(az) = y / rho (rho = sqrt(x^2 + y^2)),   sin(el) = rho / r, cos(el) = z / r (r = sqrt(x^2 + y^2 + z^2)),
+ *     1 / cos(AoA) = r / sqrt(y^2 + z^2), clamped to 1 / |cos(float(pi/2))| = 2.2877e7 -- the largest value the reference's fp32 angle can give,
+ * three reciprocal square roots instead of ~255 fp32 and ~120 fp64 instructions per matched point.  Conventions of atan2(0, 0) = 0 on the
+ * axes are kept (rho = 0: cos(az) = 1, sin(az) = 0).  The search, the gate and hence the correspondences at a given pose are unchanged;
+ * the APD covariance differs from the reference's by the fp32 rounding of its angles (~6e-8 relative in the rotation), final poses by
+ * ~1e-7 m (measured: DESIGN.md section 6; tests/test_hip_parity.py::test_algebraic_apd_*), a Levenberg-Marquardt run may stop an
+ * iteration earlier or later.  Exclusive with FP32_POINT_MATH.  The default (flag clear) is the reference's arithmetic and bench.py's
+ * headline runs with the flag clear. */
+enum { APDGICP_FLAG_PLAIN_GICP = 1, APDGICP_FLAG_XF_LINEAR_CHAIN = 2, APDGICP_FLAG_FP32_POINT_MATH = 4, APDGICP_FLAG_ALGEBRAIC_APD = 8 };
 
 /* fast_gicp::LSQ_OPTIMIZER_TYPE, gicp/lsq_registration.hpp:13 (reference default: LM, L:17) */
 typedef enum { APDGICP_OPT_LM = 0, APDGICP_OPT_GN = 1 } apdgicp_optimizer;
@@ -122,6 +135,11 @@ int apdgicp_abi_version(void);
  * disk before they trust a prebuilt library, and what a committed counter profile names.  "unstamped" for a build that did not
  * go through build.py. */
 const char* apdgicp_source_stamp(void);
+/* The compiler flags this library was built with (as build.py passed them; "unknown" for a hand build), then " | variant:" followed by every
+ * experiment define compiled in that changes kernels or results (APD_ABL_*: ablations, wrong by design; APD_OCML_ATAN2F, APD_SINCOS_NO_TABLE:
+ * A/B builds) -- detected by the preprocessor inside the library.  Empty after "variant:" = the product.  The Python loader refuses a variant
+ * library unless APDGICP_ALLOW_VARIANT_LIB=1; bench.py prints the string in its line. */
+const char* apdgicp_build_flags(void);
 const char* apdgicp_last_error(void);
 int apdgicp_device_count(int* count);
 void apdgicp_default_params(apdgicp_params* p);                                  /* A:14-28, L:11-24 */
@@ -182,6 +200,9 @@ int apdgicp_get_final_hessian(apdgicp_handle* h, double H[36]);                 
 int apdgicp_set_trace(apdgicp_handle* h, int enable);
 int apdgicp_get_trace(apdgicp_handle* h, int64_t trial_capacity, double* lambdas, double* rhos, double* y0s, double* yis, int64_t* n_trials,
                       int64_t pose_capacity, double* poses16, int64_t* n_poses);
+/* ... and, per trial, the norm of the step d it solved for: the "|delta|" column of the table the reference prints under setDebugPrint
+ * (L:148-154).  Same counts and order as the trials of apdgicp_get_trace. */
+int apdgicp_get_trace_step_norms(apdgicp_handle* h, int64_t capacity, double* norms, int64_t* n_trials);
 /* Debug: out[i] = atan2f(y[i], x[i]) as the kernels evaluate it on `device` (include/apd_atan2f.h: glibc's generic atan2f restated;
  * A:168,172-173 call the C library's float overload); host arrays.  For the bit-for-bit comparison with the host's evaluation. */
 int apdgicp_debug_atan2f(int device, const float* y, const float* x, float* out, int64_t n);
@@ -204,6 +225,13 @@ int apdgicp_inlier_fraction(apdgicp_handle* h, const float T[16], double max_cor
  * getSearchMethodTarget()->nearestKSearch(aligned[i], 1, ...) (scan_matching_odometry_nodelet.cpp:697-707) -- through the search
  * object FastAPDGICPHip installs, so that PCL never builds its CPU kd-tree.  Leaves the handle as apdgicp_linearize at T would. */
 int apdgicp_nearest_neighbours(apdgicp_handle* h, const float T[16], int32_t* index, float* sq_dist, int64_t n);
+/* The nearest target point of ARBITRARY query points (host memory, n x {x, y, z, ...} floats, stride_bytes >= 12) in one batched device
+ * pass: what pcl::search::Search::nearestKSearch(cloud, indices, 1, ...) returns (search.h: the batch form of the call above) --
+ * index into the target as set (a tie: the lowest index) and the fp32 squared distance (FLANN L2_Simple order), no gate.  The queries
+ * are sorted along the curve like a source cloud and searched with the same exact pruned kernel; no covariances are computed for them.
+ * This serves the search object's queries that are NOT the transformed source points (the per-query host scan of round 5 cost 500 k
+ * distance evaluations per query on a submap).  The next align / linearize of the handle sets its own pair up again. */
+int apdgicp_nearest_neighbours_of(apdgicp_handle* h, const float* queries_xyz, int64_t n, int64_t stride_bytes, int32_t* index, float* sq_dist);
 /* the points of the source / target cloud as set, n x {x, y, z} floats in the caller's order, into host memory (the fall-back of
  * that search object for a query that is not one of the transformed source points needs the target of a device-resident submap) */
 int apdgicp_get_points(apdgicp_handle* h, int which, float* out_xyz, int64_t n);

@@ -45,7 +45,7 @@ class Params:
     lm_max_iterations: int = 10
     optimizer: int = OPT_LM
     regularization: int = REG_PLANE
-    flags: int = 0   # bit 0: plain GICP (cov_dist omitted), gicp/impl/fast_gicp_impl.hpp; bit 1: T*p as a linear chain (Eigen 3.2)
+    flags: int = 0   # bit 0: plain GICP (cov_dist omitted), gicp/impl/fast_gicp_impl.hpp; bit 1: T*p as a linear chain (Eigen 3.2); bit 3: the product's opt-in algebraic sensor model (not the reference's)
     max_correspondence_distance: float = float(np.finfo(np.float32).max)
     transformation_epsilon: float = 5e-4
     rotation_epsilon: float = 2e-3
@@ -305,6 +305,14 @@ class FastAPDGICP:
             azimuth = float(azim_f[i])                                         # :173
             ce, se = math.cos(elevation), math.sin(elevation)
             ca, sa = math.cos(azimuth), math.sin(azimuth)
+            if p.flags & 8:
+                # NOT the reference: the checker of the product's opt-in APDGICP_FLAG_ALGEBRAIC_APD -- the same ratios from the coordinates
+                x, y, z = (float(v) for v in pt[i])
+                rho, yz = math.sqrt(x * x + y * y), math.sqrt(y * y + z * z)
+                inv_cos = min(dist / yz if yz > 0 else math.inf, 1.0 / 4.371138828673793e-08)
+                s_y, s_z = dist * inv_cos * sin_az, dist * inv_cos * sin_el
+                se, ce = (rho / dist, z / dist) if dist > 0 else (0.0, 0.0)
+                ca, sa = (x / rho, y / rho) if rho > 0 else (1.0, 0.0)
             Ry = np.array([[ce, 0, se], [0, 1, 0], [-se, 0, ce]])
             Rz = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.0]])
             A = (Rz @ Ry) @ np.diag([s_x, s_y, s_z])                           # :174-181

@@ -46,7 +46,7 @@ struct RefParams {  // independent mirror of include/apdgicp_hip.h:apdgicp_param
   int32_t lm_max_iterations;
   int32_t optimizer;       // 0 = LevenbergMarquardt, 1 = GaussNewton (L:17, lsq_registration.hpp:13)
   int32_t regularization;  // gicp_settings.hpp:6 NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS
-  int32_t flags;           // bit 0: plain GICP (no cov_dist), gicp/impl/fast_gicp_impl.hpp update_correspondences;
+  int32_t flags;           // (bit 3: the product's opt-in algebraic sensor model, see update_correspondences) bit 0: plain GICP (no cov_dist), gicp/impl/fast_gicp_impl.hpp update_correspondences;
                            // bit 1: T*p summed as a linear chain (Eigen 3.2) instead of pairwise (Eigen >= 3.3), see xf_row
   double max_correspondence_distance;
   double transformation_epsilon;
@@ -481,13 +481,25 @@ void update_correspondences(Ref& r, const M4& T) {
     const double s_z = dist * sin_el / std::cos(aoa);                               // A:171
     const double elevation = (double)apd::apd_atan2f(sqrtf(pt.x * pt.x + pt.y * pt.y), pt.z);  // A:172
     const double azimuth = (double)apd::apd_atan2f(pt.y, pt.x);                               // A:173
-    const double ce = std::cos(elevation), se = std::sin(elevation);
-    const double ca = std::cos(azimuth), sa = std::sin(azimuth);
+    double ce = std::cos(elevation), se = std::sin(elevation);
+    double ca = std::cos(azimuth), sa = std::sin(azimuth);
+    double s_y_ = s_y, s_z_ = s_z;
+    if (r.p.flags & 8) {
+      // NOT the reference: the checker of the product's opt-in APDGICP_FLAG_ALGEBRAIC_APD (include/apdgicp_hip.h) -- the same quantities as
+      // ratios of the point's coordinates, in plain libm double arithmetic: cos(az) = x / rho, sin(az) = y / rho, sin(el) = rho / r,
+      // cos(el) = z / r, 1 / cos(AoA) = r / sqrt(y^2 + z^2) (at most 1 / |cos((double)(float)(pi/2))|); atan2(0, 0) = 0 on the axes
+      const double x = pt.x, y = pt.y, z = pt.z;
+      const double rho = std::sqrt(x * x + y * y), yz = std::sqrt(y * y + z * z);
+      const double inv_cos = std::fmin(yz > 0 ? dist / yz : INFINITY, 1.0 / 4.371138828673793e-08);
+      s_y_ = dist * inv_cos * sin_az, s_z_ = dist * inv_cos * sin_el;
+      se = dist > 0 ? rho / dist : 0.0, ce = dist > 0 ? z / dist : 0.0;
+      ca = rho > 0 ? x / rho : 1.0, sa = rho > 0 ? y / rho : 0.0;
+    }
     M3 Ry{{{ce, 0, se}, {0, 1, 0}, {-se, 0, ce}}};
     M3 Rz{{{ca, -sa, 0}, {sa, ca, 0}, {0, 0, 1}}};
     M3 Rot = mul(Rz, Ry);  // A:174-177
     M3 Am;                 // A = R * S, A:181
-    const double s[3] = {s_x, s_y, s_z};
+    const double s[3] = {s_x, s_y_, s_z_};
     for (int p = 0; p < 3; p++)
       for (int q = 0; q < 3; q++) Am.m[p][q] = Rot.m[p][q] * s[q];
     M3 cov_r = mul(Am, transpose(Am));  // A:182

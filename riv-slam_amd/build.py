@@ -14,9 +14,9 @@ HEADERS = ["apdgicp_hip.h", "apd_atan2f.h"]  # include/: what the one translatio
 FLAGS = [*os.environ.get("APD_EXTRA_FLAGS", "").split(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
-def source_stamp() -> str:
+def source_stamp(extra: list[str] | None = None) -> str:
     """Fingerprint of everything the library is compiled from (csrc/*.hip, *.hpp, the two headers under include/, the compiler
-    flags).  It is compiled INTO the library (apdgicp_source_stamp()): the loader, the test suite and bench.py compare the
+    flags -- `extra` ones included: a variant built with -DAPD_ABL_* never carries the product's stamp).  It is compiled INTO the library (apdgicp_source_stamp()): the loader, the test suite and bench.py compare the
     loaded library's stamp with this one, and profiles/pmc_nn_latest.json carries the stamp of the library its counters were
     collected from (tools/pmc_nn_json.py) -- bench.py reports PMC-derived numbers only when all three agree."""
     import hashlib
@@ -27,7 +27,19 @@ def source_stamp() -> str:
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    if extra:
+        h.update(b"\0extra\0" + " ".join(extra).encode())
     return h.hexdigest()[:16]
+
+
+def compile_command(out: str, extra: list[str] | None = None) -> list[str]:
+    """The one hipcc command line (build() and tools/build_variant.py): flags, the stamp of sources + flags + extra flags, and the flags
+    themselves as a string the library returns from apdgicp_build_flags()."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = list(extra or [])
+    shown = " ".join(FLAGS + extra).replace('"', "'")
+    return [hipcc, *FLAGS, f'-DAPD_SOURCE_STAMP="apd-source-stamp:{source_stamp(extra)}"', f'-DAPD_BUILD_FLAGS="{shown}"', *extra, "-o", out,
+            *[os.path.join(CSRC, s) for s in SOURCES]]
 
 
 def library_stamp(path: str = LIB) -> str | None:
@@ -55,9 +67,8 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if force or needs_build():  # (another process may have built it while this one waited)
-                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
                 tmp = f"{LIB}.{os.getpid()}.tmp"
-                cmd = [hipcc, *FLAGS, f'-DAPD_SOURCE_STAMP="apd-source-stamp:{source_stamp()}"', *(extra or []), "-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+                cmd = compile_command(tmp, extra)
                 if verbose:
                     print(" ".join(cmd), file=sys.stderr)
                 try:

@@ -92,12 +92,21 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
       this->input_ = cloud, this->indices_ = indices;  // no kd-tree: the device holds the target
     }
     int nearestKSearch(const PointTarget& p, int k, std::vector<int>& idx, std::vector<float>& d2) const override { return owner_->device_nn(p, k, idx, d2); }
+    /// the batch form (pcl/search/search.h): arbitrary queries, ONE device pass for k = 1 (apdgicp_nearest_neighbours_of)
+    void nearestKSearch(const typename SearchBase::PointCloud& cloud, const std::vector<int>& indices, int k, std::vector<std::vector<int>>& k_indices,
+                        std::vector<std::vector<float>>& k_sqr_distances) const override {
+      owner_->device_nn_batch(cloud, indices, k, k_indices, k_sqr_distances);
+    }
 #else  // PCL >= 1.12: setInputCloud returns bool, indices are pcl::Indices
     bool setInputCloud(const CloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
       this->input_ = cloud, this->indices_ = indices;
       return true;
     }
     int nearestKSearch(const PointTarget& p, int k, pcl::Indices& idx, std::vector<float>& d2) const override { return owner_->device_nn(p, k, idx, d2); }
+    void nearestKSearch(const typename SearchBase::PointCloud& cloud, const pcl::Indices& indices, int k, std::vector<pcl::Indices>& k_indices,
+                        std::vector<std::vector<float>>& k_sqr_distances) const override {
+      owner_->device_nn_batch(cloud, indices, k, k_indices, k_sqr_distances);
+    }
 #endif
    private:
     FastAPDGICPHip* owner_;
@@ -106,6 +115,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     long batched_passes = 0;   // device searches over all source points
     long served = 0;           // queries answered from one of them
     long fallbacks = 0;        // queries answered by the host brute-force scan
+    long device_queries = 0;   // queries answered by a device pass of their own (batch calls; single misses against a large target)
   };
 
   explicit FastAPDGICPHip(int device = 0) {
@@ -136,11 +146,20 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   void setDistVar(double v) { params_.distance_variance = v; }
   void setRotationEpsilon(double eps) { params_.rotation_epsilon = eps; }
   void setInitialLambdaFactor(double f) { params_.lm_init_lambda_factor = f; }
-  void setDebugPrint(bool) {}
+  /// lsq_registration.hpp:37 -- the reference prints one row per LM trial inside step_lm (lsq_registration_impl.hpp:148-154); here the
+  /// device loop records them (apdgicp_set_trace) and align() prints the same table when it returns
+  void setDebugPrint(bool on) {
+    debug_print_ = on;
+    if (handle_ && apdgicp_set_trace(handle_, on ? 1 : 0) != 0) report("setDebugPrint");
+  }
   /// not in the reference (its optimizer enum is protected without a setter, lsq_registration.hpp:78)
   void setOptimizer(apdgicp_optimizer o) { params_.optimizer = o; }
   /// upstream fast_gicp::FastGICP cost (no APD covariance): the FAST_GICP branch of the factory (registrations.cpp:28-37)
   void setPlainGICP(bool on) { params_.flags = on ? (params_.flags | APDGICP_FLAG_PLAIN_GICP) : (params_.flags & ~APDGICP_FLAG_PLAIN_GICP); }
+
+  /// opt-in, NOT the reference's arithmetic (include/apdgicp_hip.h, APDGICP_FLAG_ALGEBRAIC_APD): the sensor model of fast_apdgicp_impl.hpp:167-184
+  /// from ratios of the point's coordinates instead of three fp32 atan2 and three fp64 sin / cos; poses move by ~1e-7 m
+  void setAlgebraicAPD(bool on) { params_.flags = on ? (params_.flags | APDGICP_FLAG_ALGEBRAIC_APD) : (params_.flags & ~APDGICP_FLAG_ALGEBRAIC_APD); }
 
   /// fp32 summation order of `trans_f * p.getVector4fMap()` (fast_apdgicp_impl.hpp:149), which belongs to the Eigen the reference
   /// is built against, not to the reference: EIGEN_PAIRWISE (default; Eigen >= 3.3) or EIGEN_LINEAR_CHAIN (Eigen 3.2).
@@ -153,23 +172,34 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   // ---- cache management (fast_apdgicp_impl.hpp:68-108)
   virtual void swapSourceAndTarget() {
     input_.swap(target_);
+    std::swap(source_on_device_, target_on_device_);
+    forget_search_state();
     if (handle_ && apdgicp_swap_source_and_target(handle_) != 0) report("swapSourceAndTarget");
   }
   virtual void clearSource() {
     input_.reset();
+    source_on_device_ = false;
+    forget_search_state();
     if (handle_) apdgicp_clear_source(handle_);
   }
   virtual void clearTarget() {
     target_.reset();
+    target_on_device_ = false;
+    forget_search_state();
     if (handle_) apdgicp_clear_target(handle_);
   }
   // An empty (or null) cloud: the reference builds a kd-tree over nothing and clears the covariances (:95-97); the device side of
   // this class then holds NO cloud -- the next align fails (hasConverged() == false, one line on stderr) instead of silently
   // registering the cloud that was set before.
+  // PCL's own setInputSource / setInputTarget REFUSE an empty cloud (an error message, the old pointer stays in input_ / target_).  The
+  // device side is emptied all the same -- and remembered as empty, so that handing the OLD cloud over again, which the pointer-equality
+  // shortcut below would swallow, puts it back on the device.
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {
-    if (input_ == cloud) return;  // pointer equality keeps the cached covariances, :91-93
-    Base::setInputSource(cloud);
+    if (input_ == cloud && source_on_device_) return;  // pointer equality keeps the cached covariances, :91-93
+    if (cloud && !cloud->empty()) Base::setInputSource(cloud);
+    else if (cloud) Base::setInputSource(cloud);  // (PCL prints its "Invalid or empty point cloud dataset given" and keeps input_)
     nn_epoch_++;
+    source_on_device_ = false;
     if (!handle_) return;
     if (!cloud || cloud->empty()) {
       apdgicp_clear_source(handle_);
@@ -177,13 +207,15 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     }
     if (apdgicp_set_source(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointSource), 0, token_of(cloud.get())) != 0)
       report("setInputSource");
+    else source_on_device_ = true;
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
-    if (target_ == cloud) return;  // :102-104
-    Base::setInputTarget(cloud);   // (PCL itself refuses an empty target with an error message and keeps the old pointer)
+    if (target_ == cloud && target_on_device_) return;  // :102-104
+    if (cloud) Base::setInputTarget(cloud);   // (PCL itself refuses an empty target with an error message and keeps the old pointer)
     nn_epoch_++;
     device_target_n_ = 0;
     host_target_.clear();
+    target_on_device_ = false;
     if (!handle_) return;
     if (!cloud || cloud->empty()) {
       apdgicp_clear_target(handle_);
@@ -191,6 +223,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     }
     if (apdgicp_set_target(handle_, &cloud->at(0).x, (int64_t)cloud->size(), (int64_t)sizeof(PointTarget), 0, token_of(cloud.get())) != 0)
       report("setInputTarget");
+    else target_on_device_ = true;
   }
   /// on (the default): the base class's search object is this class's DeviceSearch -- no CPU kd-tree is ever built, the base-class
   /// getFitnessScore() / getSearchMethodTarget() answer from the device.  off: PCL's own pcl::search::KdTree again (a FLANN build
@@ -250,8 +283,10 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     nn_epoch_++;
     host_target_.clear();
     device_target_n_ = n;
+    target_on_device_ = false;
     if (handle_ && n && apdgicp_set_target(handle_, device_xyz, (int64_t)n, (int64_t)stride_bytes, 1, ++device_epoch_) != 0)
       report("setInputTargetDevice");
+    else target_on_device_ = handle_ && n;
   }
   virtual void setSourceCovariances(const CovVector& covs) {
     if (handle_ && apdgicp_set_covariances(handle_, APDGICP_SOURCE, covs[0].data(), (int64_t)covs.size()) != 0) report("setSourceCovariances");
@@ -304,10 +339,58 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
         }
       }
     }
+    // Not a transformed source point in order (or k > 1).  Said once: this is the slow side of the search object.
+    if (!warned_fallback_) {
+      warned_fallback_ = true;
+      std::fprintf(stderr, "[FastAPDGICPHip] nearestKSearch: a query that is not the next transformed source point (or k > 1) -- answered one at a time "
+                           "(%s); hand a batch of such queries to getSearchMethodTarget()->nearestKSearch(cloud, indices, 1, ...) for ONE device pass\n",
+                   target_size() > kDeviceSingleQueryMin ? "a device pass per query" : "an exact host scan of the target per query");
+    }
+    if (k == 1 && handle_ && target_on_device_ && target_size() > kDeviceSingleQueryMin) {  // a submap: 500 k distances on the host per query
+      int32_t j = -1;
+      float d = 0.f;
+      const float q[3] = {p.x, p.y, p.z};
+      if (apdgicp_nearest_neighbours_of(handle_, q, 1, 12, &j, &d) == 0) {
+        nn_stats_.device_queries++;
+        nn_cache_epoch_ = 0;  // (the handle's pair was set up for the query: the cached pass is still right, the NEXT one re-arms the pair)
+        idx.assign(1, j), d2.assign(1, d);
+        return j >= 0 ? 1 : 0;
+      }
+      report("nearest neighbour of a query");
+    }
     return host_nn(p, k, idx, d2);
+  }
+  /// pcl::search::Search::nearestKSearch(cloud, indices, k, ...): every listed point of `cloud` (all of them when `indices` is empty)
+  template <typename Cloud, typename IdxIn, typename IdxOut>
+  void device_nn_batch(const Cloud& cloud, const IdxIn& indices, int k, std::vector<IdxOut>& k_indices, std::vector<std::vector<float>>& k_sqr_distances) {
+    const std::size_t n = indices.empty() ? cloud.size() : indices.size();
+    k_indices.assign(n, IdxOut()), k_sqr_distances.assign(n, std::vector<float>());
+    if (!n) return;
+    if (k == 1 && handle_ && target_on_device_) {
+      std::vector<float> q(3 * n), d(n);
+      std::vector<int32_t> j(n);
+      for (std::size_t i = 0; i < n; i++) {
+        const auto& pt = cloud.points[indices.empty() ? i : (std::size_t)indices[i]];
+        q[3 * i] = pt.x, q[3 * i + 1] = pt.y, q[3 * i + 2] = pt.z;
+      }
+      if (apdgicp_nearest_neighbours_of(handle_, q.data(), (int64_t)n, 12, j.data(), d.data()) == 0) {
+        nn_stats_.device_queries += (long)n;
+        for (std::size_t i = 0; i < n; i++) k_indices[i].assign(1, j[i]), k_sqr_distances[i].assign(1, d[i]);
+        return;
+      }
+      report("nearest neighbours of a batch of queries");
+    }
+    for (std::size_t i = 0; i < n; i++) host_nn(cloud.points[indices.empty() ? i : (std::size_t)indices[i]], k, k_indices[i], k_sqr_distances[i]);
   }
 
  protected:
+  static constexpr std::size_t kDeviceSingleQueryMin = 32768;  // targets above this size: a single stray query goes to the device (~60 us) instead of a host scan
+  std::size_t target_size() const { return device_target_n_ ? device_target_n_ : (target_ ? target_->size() : 0); }
+  void forget_search_state() {  // swap / clear: the cached pass, a device target's host copy and its size belong to the old clouds
+    nn_epoch_++;
+    device_target_n_ = 0;
+    host_target_.clear();
+  }
   // one batched device search of all source points at final_transformation_, kept until the pose or a cloud changes
   bool ensure_nn_cache() {
     if (!handle_ || !input_ || input_->empty()) return false;
@@ -336,7 +419,10 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   // exact k-NN by a scan of the target on the host (FLANN's L2_Simple order in fp32; ties: the lower index first)
   template <typename Idx>
   int host_nn(const PointTarget& p, int k, Idx& idx, std::vector<float>& d2) {
-    idx.clear(), d2.clear();
+    // (on failure the outputs keep one slot of {-1, FLT_MAX}: the callers this object serves -- scan_matching_odometry_nodelet.cpp:701-703,
+    // PCL's getFitnessScore -- read k_sq_dists[0] without looking at the return value)
+    const std::size_t slots = (std::size_t)std::max(k, 1);
+    idx.assign(slots, -1), d2.assign(slots, std::numeric_limits<float>::max());
     nn_stats_.fallbacks++;
     std::size_t m = 0;
     const float* xyz = nullptr;
@@ -347,7 +433,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
         if (!handle_ || apdgicp_get_points(handle_, APDGICP_TARGET, host_target_.data(), (int64_t)device_target_n_) != 0) {
           report("get target points");
           host_target_.clear();
-          return 0;
+          return 0;  // (idx / d2: {-1, FLT_MAX})
         }
       }
       xyz = host_target_.data(), m = device_target_n_;
@@ -355,6 +441,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
       xyz = &target_->points[0].x, m = target_->size(), stride = sizeof(PointTarget) / sizeof(float);
     }
     if (!m || k < 1) return 0;
+    idx.clear(), d2.clear();
     std::vector<std::pair<float, int>> best;  // (distance, index), ascending
     for (std::size_t j = 0; j < m; j++) {
       const float* q = xyz + j * stride;
@@ -388,6 +475,7 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     for (int i = 0; i < 16; i++) final_transformation_.data()[i] = result_.T[i];  // both column-major
     converged_ = result_.converged != 0;
     nr_iterations_ = result_.iterations;
+    if (debug_print_) print_lm_table();
     if (result_.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // lsq_registration_impl.hpp:72
     // pcl::transformPointCloud(*input_, output, final_transformation_), :79.  The reference does this on the host, and for a
     // scan-sized cloud so does this class: the source is already here, and one pass over it (a few microseconds) is cheaper
@@ -448,6 +536,31 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
     }
     return out;
   }
+  // The table step_lm prints under lm_debug_print_ (lsq_registration_impl.hpp:148-154), from the trace the device loop kept
+  // (apdgicp_get_trace, apdgicp_get_trace_step_norms): "--- LM optimization ---" and the header in front of the first trial of every call
+  // of step_lm (= every new linearisation: y0 changes), one row per trial -- i, y0, yi, rho, lambda, |delta|, dec ('x' when rho > 0).
+  // The reference prints while it iterates; here the rows appear when align() returns.
+  void print_lm_table() {
+    int64_t nt = 0, np = 0;
+    if (apdgicp_get_trace(handle_, 0, nullptr, nullptr, nullptr, nullptr, &nt, 0, nullptr, &np) != 0) return report("setDebugPrint trace");
+    if (nt == 0) return;
+    std::vector<double> lam(nt), rho(nt), y0(nt), yi(nt), dn(nt, 0.0);
+    int64_t nt2 = 0;
+    if (apdgicp_get_trace(handle_, nt, lam.data(), rho.data(), y0.data(), yi.data(), &nt, 0, nullptr, &np) != 0 ||
+        apdgicp_get_trace_step_norms(handle_, nt, dn.data(), &nt2) != 0)
+      return report("setDebugPrint trace");
+    nt = std::min<int64_t>(nt, (int64_t)lam.size());
+    int64_t i_in_call = 0;
+    for (int64_t t = 0; t < nt; t++) {
+      // (a trial that follows a REJECTED one belongs to the same call of step_lm; after an accepted one -- rho >= 0 -- the next call starts)
+      if (t == 0 || !(rho[t - 1] < 0)) {
+        std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
+        i_in_call = 0;
+      }
+      std::printf("%5d %15g %15g %15g %15g %15g %5c\n", (int)i_in_call++, y0[t], yi[t], rho[t], lam[t], dn[t], rho[t] > 0.0 ? 'x' : ' ');
+    }
+    std::fflush(stdout);
+  }
   void report(const char* what) const { std::fprintf(stderr, "[FastAPDGICPHip] %s failed: %s\n", what, apdgicp_last_error()); }
 
   uint64_t device_epoch_ = 0x5375624d61700000ull;  // tokens of device targets (never equal to a host cloud's address)
@@ -458,6 +571,9 @@ class FastAPDGICPHip : public pcl::Registration<PointSource, PointTarget, float>
   std::size_t host_transform_max_ = 65536;
   bool skip_base_tree_ = false;
   bool device_search_ = false;
+  bool debug_print_ = false;
+  bool warned_fallback_ = false;
+  bool source_on_device_ = false, target_on_device_ = false;  // the device holds the cloud input_ / target_ points at
   // DeviceSearch's cache: the batched search of the source at nn_T_
   unsigned long nn_epoch_ = 1, nn_cache_epoch_ = 0;
   float nn_T_[16] = {};

@@ -158,6 +158,13 @@ struct CachedTable {
   }
   template <typename T>
   T* as() const { return (T*)dev.p; }
+  CachedTable() = default;
+  CachedTable(const CachedTable&) = delete;
+  CachedTable& operator=(const CachedTable&) = delete;
+  void swap(CachedTable& o) {
+    std::swap(dev, o.dev), host.swap(o.host), std::swap(cur, o.cur);
+    for (int i = 0; i < 2; i++) std::swap(pin[i], o.pin[i]), std::swap(pin_cap[i], o.pin_cap[i]), std::swap(ev[i], o.ev[i]);
+  }
 };
 
 class Engine {
@@ -170,6 +177,7 @@ class Engine {
     bool sorted = false;
     bool cov_valid = false;
     uint64_t token = 0;
+    int prep_lane = -1;  // the cloud stream (pool: cloud lane) the last operation on this cloud was enqueued on; -1: known to be complete
     // a host cloud of the tiled-sort size class stays in this pinned buffer until the sort has read it (TileJob::staged)
     char* stage_p = nullptr;
     char* stage_dev = nullptr;
@@ -378,9 +386,16 @@ class Engine {
       if (j.pin) e = hipHostFree(j.pin);
       j.d_recs.release();
     }
-    for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.L[0].active, &pool.L[0].nactive, &pool.L[1].active, &pool.L[1].nactive, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
+    for (DevBuf* b : {&pool.state, &pool.pairs, &pool.guess, &pool.results, &pool.ticket, &pool.nnpart, &pool.corr,
                       &pool.nnpt, &pool.nnaux, &pool.sqd, &pool.maha, &pool.blkpart, &pool.errpart})
       b->release();
+    for (Pool::List& li : pool.L) li.active.release(), li.nactive.release();
+    if (pool.cstream2) e = hipStreamSynchronize(pool.cstream2), e = hipStreamDestroy(pool.cstream2);
+    if (pool.ev_cross) e = hipEventDestroy(pool.ev_cross);
+    for (CachedTable* t : {&lane2.desc, &lane2.ids, &lane2.packjobs, &lane2.sortjobs, &lane2.tilejobs[0], &lane2.tilejobs[1], &lane2.tilejobs[2]}) t->dev.release();
+    lane2.tkeys.release(), lane2.bulk_dev.release();
+    if (lane2.bulk_host) e = hipHostFree(lane2.bulk_host);
+    if (lane2.bulk_ev) e = hipEventDestroy(lane2.bulk_ev);
     if (pool.host) e = hipHostFree(pool.host);
     if (pool.cstream) e = hipStreamDestroy(pool.cstream);
     for (HostStage& hs : h_stage) {
@@ -399,7 +414,9 @@ class Engine {
     if (p->k_correspondences < 1) return fail(APDGICP_ERR_INVALID_ARG, "k_correspondences must be >= 1");
     if (p->regularization < 0 || p->regularization > 4) return fail(APDGICP_ERR_UNSUPPORTED, "unknown regularization method");
     if (p->optimizer != APDGICP_OPT_LM && p->optimizer != APDGICP_OPT_GN) return fail(APDGICP_ERR_INVALID_ARG, "unknown optimizer");
-    if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN | APDGICP_FLAG_FP32_POINT_MATH)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
+    if (p->flags & ~(APDGICP_FLAG_PLAIN_GICP | APDGICP_FLAG_XF_LINEAR_CHAIN | APDGICP_FLAG_FP32_POINT_MATH | APDGICP_FLAG_ALGEBRAIC_APD)) return fail(APDGICP_ERR_INVALID_ARG, "unknown bit in params.flags");
+    if ((p->flags & APDGICP_FLAG_FP32_POINT_MATH) && (p->flags & APDGICP_FLAG_ALGEBRAIC_APD))
+      return fail(APDGICP_ERR_INVALID_ARG, "APDGICP_FLAG_FP32_POINT_MATH and APDGICP_FLAG_ALGEBRAIC_APD are exclusive");
     if (pool.on) APD_TRY(pool_drain());  // the batches in flight finish with the parameters they were enqueued with
     const bool cov_change = clouds.size() && (p->k_correspondences != params.k_correspondences || p->regularization != params.regularization);
     params = *p;
@@ -437,6 +454,7 @@ class Engine {
     APD_HIP(hipEventRecord(ev_producer, (hipStream_t)producer));
     APD_HIP(hipStreamWaitEvent(stream, ev_producer, 0));
     if (cstream != stream) APD_HIP(hipStreamWaitEvent(cstream, ev_producer, 0));
+    if (pool.on && pool.cstream2) APD_HIP(hipStreamWaitEvent(pool.cstream2, ev_producer, 0));
     return 0;
   }
 
@@ -569,8 +587,13 @@ class Engine {
     roctx_range rr("apdgicp:pack");
     if ((int)clouds.size() <= slot) clouds.resize(slot + 1);
     Cloud& c = clouds[slot];
+    lane_touch(c);
+    APD_TRY(lane_order());
     // the previous contents may still be in use by queued kernels on this stream; stream order protects us
-    if ((size_t)n * 16 > c.opts.cap) APD_HIP(hipStreamSynchronize(cstream));
+    if ((size_t)n * 16 > c.opts.cap) {
+      APD_HIP(hipStreamSynchronize(cstream));
+      if (pool.on && pool.cstream2) APD_HIP(hipStreamSynchronize(pool.cstream2));
+    }
     APD_TRY(c.opts.ensure((size_t)n * 16));
     const char* raw = (const char*)xyz;
     c.staged = false;
@@ -703,8 +726,13 @@ class Engine {
       if (!xyz[q] || ns[q] <= 0 || ns[q] > (1 << 30)) return fail(APDGICP_ERR_INVALID_ARG, "cloud is null, empty or too large");
       grew |= (size_t)ns[q] * 16 > clouds[first + q].opts.cap;
       nmax = std::max<int>(nmax, (int)ns[q]);
+      lane_touch(clouds[first + q]);
     }
-    if (grew) APD_HIP(hipStreamSynchronize(cstream));  // a buffer about to be re-allocated may still be in use
+    APD_TRY(lane_order());
+    if (grew) {  // a buffer about to be re-allocated may still be in use
+      APD_HIP(hipStreamSynchronize(cstream));
+      if (pool.on && pool.cstream2) APD_HIP(hipStreamSynchronize(pool.cstream2));
+    }
     std::vector<PackJob> jobs(count);
     for (int q = 0; q < count; q++) {
       Cloud& c = clouds[first + q];
@@ -750,9 +778,14 @@ class Engine {
       any = true;
       const size_t n = c.n, nch = (n + 15) / 16, ngr = (n + kGroupPts - 1) / kGroupPts, nsup = (ngr + kSuperGroups - 1) / kSuperGroups;
       grew |= n * 16 > c.pts.cap || n * 4 > c.perm.cap || nch * sizeof(Box) > c.cbox.cap || (ngr + nsup) * sizeof(Box) > c.gbox.cap;
+      lane_touch(c);
     }
     if (!any) return 0;
-    if (grew) APD_HIP(hipStreamSynchronize(cstream));  // old buffers may still be read by queued kernels
+    APD_TRY(lane_order());
+    if (grew) {  // old buffers may still be read by queued kernels
+      APD_HIP(hipStreamSynchronize(cstream));
+      if (pool.on && pool.cstream2) APD_HIP(hipStreamSynchronize(pool.cstream2));
+    }
     roctx_range rr("apdgicp:sort");
     for (size_t i = 0; i < clouds.size(); i++) {
       Cloud& c = clouds[i];
@@ -822,6 +855,7 @@ class Engine {
       int np2 = VOX_TILE;
       while (np2 < n) np2 <<= 1;
       APD_HIP(hipStreamSynchronize(cstream));
+      if (pool.on && pool.cstream2) APD_HIP(hipStreamSynchronize(pool.cstream2));  // (d_keys / d_box6 are shared by the lanes)
       APD_TRY(d_keys.ensure((size_t)np2 * 8));
       APD_TRY(d_box6.ensure(6 * sizeof(int)));
       const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, (int)0x807fffff, (int)0x807fffff, (int)0x807fffff};  // +inf x3, -inf x3 (ordered-int)
@@ -853,7 +887,14 @@ class Engine {
 
   int upload_desc() {
     APD_TRY(sort_clouds());
-    if (!desc_dirty) return 0;
+    if (!desc_dirty) {
+      const int ln = pool.on ? pool.clane : 0;
+      if (pool.nclanes > 1 && pool.desc_gen_lane[ln] != desc_gen) {  // this lane's device table is an older generation
+        APD_TRY(d_desc.upload(h_desc.data(), h_desc.size() * sizeof(CloudDesc), cstream));
+        pool.desc_gen_lane[ln] = desc_gen;
+      }
+      return 0;
+    }
     std::vector<CloudDesc>& h = h_desc;
     h.resize(clouds.size());
     for (size_t i = 0; i < clouds.size(); i++) {
@@ -869,6 +910,8 @@ class Engine {
     }
     APD_TRY(d_desc.upload(h.data(), h.size() * sizeof(CloudDesc), cstream));
     desc_dirty = false;
+    desc_gen++;
+    pool.desc_gen_lane[pool.on ? pool.clane : 0] = desc_gen;
     return 0;
   }
 
@@ -936,6 +979,10 @@ class Engine {
   // one covariance launch for the clouds ids[0..count) (device copy of the list: d_list) on stream `st`
   int launch_knn(const int* ids, const int* d_list, int count, hipStream_t st) {
     if (count <= 0) return 0;
+    if (st == cstream) {
+      for (int i = 0; i < count; i++) lane_touch(clouds[ids[i]]);
+      APD_TRY(lane_order());
+    }
     roctx_range rr("apdgicp:knn_cov");
     int nmax = 0;
     long long total = 0;
@@ -998,7 +1045,8 @@ class Engine {
   int max_groups = 1 << 30;  // apdgicp_batch_set_pair_groups: a caller that keeps several batches (handles) in flight wants one group each
   int ngroups_for_first_tick() const { return group_count(); }
   int group_count() const { return std::max(1, std::min<int>(std::min<int>(ngroups_cfg, max_groups), (npairs + 4) / 8)); }
-  int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false) {
+  // need_cov = false: the pairs are searched only (apdgicp_nearest_neighbours_of): no covariance launch for clouds that lack them
+  int setup_pairs(const apdgicp_pair* pairs, int64_t n, bool with_guess, bool pipeline_cov = false, bool need_cov = true) {
     if (n <= 0 || n > 65536) return fail(APDGICP_ERR_INVALID_ARG, "n_pairs must be in [1, 65536]");
     APD_HIP(hipSetDevice(device));
     APD_TRY(pool_leave());
@@ -1042,7 +1090,7 @@ class Engine {
         APD_TRY(d_ids.upload(cov_list.data(), cov_list.size() * sizeof(int), stream));
         APD_TRY(launch_knn(cov_list.data(), d_ids.as<int>(), cov_group_off[1], stream));  // clouds shared between groups: now
       }
-    } else {
+    } else if (need_cov) {
       defer_errflag = true;
       const int rc_cov = compute_covariances(need);
       defer_errflag = false;
@@ -1127,7 +1175,7 @@ class Engine {
   bool trace_on = false;
   DevBuf d_trace;
   int trace_cap_trial = 0, trace_cap_pose = 0;
-  size_t trace_bytes() const { return 16 + ((size_t)4 * trace_cap_trial + (size_t)12 * trace_cap_pose) * sizeof(double); }
+  size_t trace_bytes() const { return 16 + ((size_t)5 * trace_cap_trial + (size_t)12 * trace_cap_pose) * sizeof(double); }
   int trace_reset() {  // in front of an align: capacities from the current parameters, counts zero
     if (!trace_on) return 0;
     trace_cap_pose = std::max(1, params.max_iterations);
@@ -1217,7 +1265,12 @@ class Engine {
     w.pair0 = sp.p0;
     w.init = init_tick && mode == 2 ? d_guess.as<Rigid>() : nullptr;
     const bool f32 = (params.flags & APDGICP_FLAG_FP32_POINT_MATH) != 0;
-    if (mode == 2 && f32)
+    const bool alg = (params.flags & APDGICP_FLAG_ALGEBRAIC_APD) != 0;
+    if (alg && mode == 2)
+      hipLaunchKernelGGL((k_linearize<true, false, true>), grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, consts(), mode);
+    else if (alg)
+      hipLaunchKernelGGL((k_linearize<false, false, true>), grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, consts(), mode);
+    else if (mode == 2 && f32)
       hipLaunchKernelGGL((k_linearize<true, true>), grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w, consts(), mode);
     else if (mode == 2)
       hipLaunchKernelGGL(k_linearize<true>, grid, dim3(LIN_BLK), 0, sp.st, d_desc.as<CloudDesc>(), t_pairs(), t_state(), w,
@@ -1546,7 +1599,8 @@ class Engine {
     // streams that forked behind every poll and joined in front of the next -- 13 % of the time no kernel ran at all.  Two pooled
     // handles on two host threads showed what independence is worth, tools/lm_threads.py: 1.03 -> 0.96 ms per batch of 32 loop
     // pairs with sixteen batches in flight, 0.91 with thirty-two.)
-    static constexpr int kLists = 2;
+    static constexpr int kMaxLists = 4;
+    int nlists = 2;  // APDGICP_POOL_LISTS (1 .. 4), read when the pool is first entered
     struct List {
       DevBuf active, nactive;          // the device-side list of running pairs and its length
       hipStream_t st = nullptr;        // list 0: the engine's stream; list 1: gstreams[0]
@@ -1555,8 +1609,17 @@ class Engine {
       int adm[kPoolRing] = {};
       int ub = 0;                      // upper bound of the device's list length behind the last ENQUEUED poll
       int kill_mask = 0;
-    } L[kLists];
+    } L[kMaxLists];
     int cur = 0;                       // the list whose ticks are being launched (t_work)
+    // TWO cloud lanes (round 6): the preparation of consecutive batches -- pack, sort, covariances -- alternates between two streams, each
+    // with its own job tables (descriptor table, id list, pack / sort / tile jobs, tile keys, bulk staging), so that the chain of batch
+    // n + 1 (five launches of which four leave most of the GPU empty) runs beside the covariance launch of batch n.  The engine's
+    // d_desc / d_ids / ... members always are those of the CURRENT lane; pool_swap_cloud_lane() exchanges them with the parked set.
+    int nclanes = 1;                   // APDGICP_POOL_CLOUD_STREAMS (1 or 2)
+    int clane = 0;                     // the current lane
+    hipStream_t cstream2 = nullptr;    // the parked lane's stream
+    hipEvent_t ev_cross = nullptr;     // orders one lane behind the other when a batch touches a cloud the other lane prepared
+    uint64_t desc_gen_lane[2] = {0, 0};
     int ticks_per_chunk = 1;  // APDGICP_POOL_TICKS
     // measured (tools/pool_sweep.sh, docs/experiments.md): chunks two deep, the list cut into two slices from 24 pairs on
     static constexpr int groups = 2, group_min = 24;
@@ -1588,6 +1651,43 @@ class Engine {
   // batches of one handle that may be in flight at once (round 4, two lists: 8 / 16 / 24 / 32 in flight: 1.08 / 0.91 / 0.87 / 0.86 ms per 32 loop
   // pairs; round 3, one list: 8 / 12 / 16 / 24 / 32: 1.27 / 1.13 / 1.07 / 1.03 / 1.01)
   static int pool_lanes_cfg() { return std::max(1, std::min(kPoolLanes, env_int("APDGICP_POOL_LANES", 24))); }
+  // the parked cloud lane's tables (the current lane's are the engine's own members)
+  struct ParkedLane {
+    CachedTable desc, ids, packjobs, sortjobs, tilejobs[3];
+    DevBuf tkeys, bulk_dev;
+    char* bulk_host = nullptr;
+    size_t bulk_cap = 0;
+    hipEvent_t bulk_ev = nullptr;
+  } lane2;
+  uint64_t desc_gen = 0;  // counts the rebuilds of h_desc: a lane's device table is current when it has uploaded this generation
+  void pool_swap_cloud_lane() {
+    if (pool.nclanes < 2 || !pool.on) return;
+    d_desc.swap(lane2.desc), d_ids.swap(lane2.ids), d_packjobs.swap(lane2.packjobs), d_sortjobs.swap(lane2.sortjobs);
+    for (int i = 0; i < 3; i++) d_tilejobs[i].swap(lane2.tilejobs[i]);
+    std::swap(d_tkeys, lane2.tkeys), std::swap(bulk_dev, lane2.bulk_dev);
+    std::swap(bulk_host, lane2.bulk_host), std::swap(bulk_cap, lane2.bulk_cap), std::swap(bulk_ev, lane2.bulk_ev);
+    std::swap(pool.cstream, pool.cstream2);
+    cstream = pool.cstream;
+    pool.clane ^= 1;
+  }
+  // In front of operations on clouds on the current cloud stream: `touch` every cloud involved, then `lane_order`.  A cloud whose last
+  // operation went to the OTHER lane (and is not known to be complete) puts the current lane behind everything the other lane holds.
+  bool lane_cross = false;
+  void lane_touch(Cloud& c) {
+    if (pool.on && pool.nclanes > 1) {
+      if (c.prep_lane >= 0 && c.prep_lane != pool.clane) lane_cross = true;
+      c.prep_lane = pool.clane;
+    } else {
+      c.prep_lane = -1;  // (one cloud stream: stream order)
+    }
+  }
+  int lane_order() {
+    if (!lane_cross) return 0;
+    lane_cross = false;
+    APD_HIP(hipEventRecord(pool.ev_cross, pool.cstream2));
+    APD_HIP(hipStreamWaitEvent(pool.cstream, pool.ev_cross, 0));
+    return 0;
+  }
   PoolHdr* pool_hdr(int l, uint64_t seq) const { return (PoolHdr*)(pool.host + (size_t)pool.cap * sizeof(ResultRec)) + (size_t)l * kPoolRing + seq % kPoolRing; }
   bool pool_busy() const {
     for (const PoolJob& j : pool.jobs)
@@ -1602,8 +1702,16 @@ class Engine {
       APD_HIP(hipStreamCreateWithFlags(&pool.cstream, hipStreamNonBlocking));
       for (Pool::List& li : pool.L)
         for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&li.ev[i], hipEventDisableTiming));
-      APD_TRY(ensure_group_streams(3));  // gstreams[0]: the second list; gstreams[1]: the slice stream of a list that ticks alone
-      pool.L[0].st = stream, pool.L[1].st = gstreams[0];
+      // measured (round 6, docs/experiments.md): lists 2 / 3 / 4 and cloud streams 1 / 2 on the C4 shard
+      pool.nlists = std::max(1, std::min(Pool::kMaxLists, env_int("APDGICP_POOL_LISTS", 2)));
+      pool.nclanes = std::max(1, std::min(2, env_int("APDGICP_POOL_CLOUD_STREAMS", 1)));
+      if (pool.nclanes > 1) {
+        APD_HIP(hipStreamCreateWithFlags(&pool.cstream2, hipStreamNonBlocking));
+        APD_HIP(hipEventCreateWithFlags(&pool.ev_cross, hipEventDisableTiming));
+      }
+      APD_TRY(ensure_group_streams(pool.nlists + 1));  // gstreams[l - 1]: list l; gstreams[nlists - 1]: the slice stream of a list that ticks alone
+      pool.L[0].st = stream;
+      for (int l = 1; l < pool.nlists; l++) pool.L[l].st = gstreams[l - 1];
       for (PoolJob& j : pool.jobs) APD_HIP(hipEventCreateWithFlags(&j.ev_pro, hipEventDisableTiming));
       // measured on the two-list pool (docs/experiments.md, round 4): ticks per chunk 1 / 2 / 3 / 4 -> 0.931 / 0.962 / 1.018 / 1.065 ms per batch of
       // 32 loop pairs (16 in flight, two chunks ahead); chunks ahead 1 / 2 / 3 / 4 -> 0.906 / 0.933 / 0.951 / 0.970 (one tick per chunk): a poll
@@ -1615,6 +1723,7 @@ class Engine {
     }
     cstream = pool.cstream;
     pool.on = true;
+    for (Cloud& c : clouds) c.prep_lane = -1;  // (the main stream was synchronised above)
     return 0;
   }
   // back to one stream: every other entry point (Gauss-Newton batches, fitness, probes) prepares clouds and ticks in stream order
@@ -1622,6 +1731,9 @@ class Engine {
     if (!pool.on) return 0;
     APD_TRY(pool_drain());
     APD_HIP(hipStreamSynchronize(pool.cstream));
+    if (pool.cstream2) APD_HIP(hipStreamSynchronize(pool.cstream2));
+    if (pool.clane != 0) pool_swap_cloud_lane();  // (the engine's own tables are lane 0's again)
+    for (Cloud& c : clouds) c.prep_lane = -1;
     for (Pool::List& li : pool.L)
       if (li.st) APD_HIP(hipStreamSynchronize(li.st));
     APD_HIP(hipStreamSynchronize(stream));
@@ -1640,7 +1752,7 @@ class Engine {
     // is sliced onto gstreams[1]): the pinned headers are wiped and the list buffers possibly re-allocated below
     for (Pool::List& li : pool.L)
       if (li.st) APD_HIP(hipStreamSynchronize(li.st));
-    if (gstreams.size() > 1) APD_HIP(hipStreamSynchronize(gstreams[1]));
+    for (hipStream_t gs : gstreams) APD_HIP(hipStreamSynchronize(gs));
     APD_HIP(hipStreamSynchronize(stream));
     const int segcap = std::max(pool.segcap, n);
     const int nmax = std::max(pool.nmax_src, nsrc);
@@ -1666,7 +1778,7 @@ class Engine {
     APD_TRY(pool.maha.ensure((size_t)cap * 6 * ns * 8));
     APD_TRY(pool.blkpart.ensure((size_t)cap * nblk * kRed * 8));
     APD_TRY(pool.errpart.ensure((size_t)cap * nblk * 8));
-    const size_t host_bytes = (size_t)cap * sizeof(ResultRec) + (size_t)Pool::kLists * kPoolRing * sizeof(PoolHdr);
+    const size_t host_bytes = (size_t)cap * sizeof(ResultRec) + (size_t)Pool::kMaxLists * kPoolRing * sizeof(PoolHdr);
     if (host_bytes > pool.host_cap) {
       if (pool.host) APD_HIP(hipHostFree(pool.host));
       pool.host = pool.host_dev = nullptr, pool.host_cap = 0;
@@ -1715,8 +1827,12 @@ class Engine {
 
   void pool_job_finished(PoolJob& j) {
     j.state = PoolJob::DONE;
-    for (int id : j.cloud_ids)
+    for (int id : j.cloud_ids) {
       if (id < (int)pool.cloud_busy.size() && pool.cloud_busy[id] > 0) pool.cloud_busy[id]--;
+      // (its ticks ran behind the event behind its clouds' preparation: whatever lane that was on, it is complete -- unless the cloud has
+      // not been given covariances yet by a LATER enqueue, which cannot be: a cloud a batch in flight reads is never replaced)
+      if (id < (int)clouds.size() && clouds[id].cov_valid && clouds[id].sorted) clouds[id].prep_lane = -1;
+    }
   }
 
   // one chunk of list l: the poll (completions of everything enqueued before, admissions) and ticks_per_chunk ticks over the list
@@ -1763,9 +1879,11 @@ class Engine {
       // A list that ticks ALONE (a single batch in flight, or its sister list is empty) is cut into two slices on two streams
       // between its polls, like the one list of round 3: its head holds few pairs with many iterations to go, a latency-bound
       // chain of small launches, its tail the young wide ones.  With both lists busy every list is one stream of its own.
-      const int other = pool.L[l ^ 1].ub;
+      int other = 0;
+      for (int o = 0; o < pool.nlists; o++)
+        if (o != l) other += pool.L[o].ub;
       const int G = other == 0 && li.ub >= pool.group_min ? std::max(1, std::min(pool.groups, env_int("APDGICP_POOL_GROUPS", pool.groups))) : 1;
-      hipStream_t slice = gstreams[1];
+      hipStream_t slice = gstreams[pool.nlists - 1];
       if (G > 1) {
         APD_HIP(hipEventRecord(ev_main, li.st));
         APD_HIP(hipStreamWaitEvent(slice, ev_main, 0));
@@ -1797,8 +1915,8 @@ class Engine {
         pool.n_pair_ticks += (long long)nt * (p1 - p0);
       }
       if (G > 1) {
-        APD_HIP(hipEventRecord(gevents[1], slice));
-        APD_HIP(hipStreamWaitEvent(li.st, gevents[1], 0));
+        APD_HIP(hipEventRecord(gevents[pool.nlists - 1], slice));
+        APD_HIP(hipStreamWaitEvent(li.st, gevents[pool.nlists - 1], 0));
       }
       pool.n_ticks += pool.ticks_per_chunk;
     }
@@ -1848,7 +1966,7 @@ class Engine {
   int pool_topup() {
     for (;;) {
       bool any = false;
-      for (int l = 0; l < Pool::kLists; l++) {
+      for (int l = 0; l < pool.nlists; l++) {
         Pool::List& li = pool.L[l];
         if ((int)(li.seq_enq - li.seq_seen) >= pool.depth) continue;
         bool pending = li.kill_mask != 0;
@@ -1867,7 +1985,7 @@ class Engine {
     APD_HIP(hipSetDevice(device));
     auto arrived = [&]() -> int {  // processes every header that is there; > 0 when there was one
       int n = 0;
-      for (int l = 0; l < Pool::kLists; l++) {
+      for (int l = 0; l < pool.nlists; l++) {
         Pool::List& li = pool.L[l];
         while (li.seq_seen < li.seq_enq && *(volatile int*)&pool_hdr(l, li.seq_seen + 1)->seq == (int)(li.seq_seen + 1)) {
           const int rc = pool_process(l, li.seq_seen + 1);
@@ -1888,8 +2006,9 @@ class Engine {
       for (int ln = 0; ln < pool.lanes; ln++)
         st += " [" + std::to_string(ln) + ": state " + std::to_string((int)pool.jobs[ln].state) + " list " + std::to_string(pool.jobs[ln].list) + " ticket " +
               std::to_string(pool.jobs[ln].ticket) + " np " + std::to_string(pool.jobs[ln].np) + " admitted at " + std::to_string(pool.jobs[ln].admit_seq) + "]";
-      return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for (chunks " + std::to_string(pool.L[0].seq_enq) + " / " + std::to_string(pool.L[1].seq_enq) +
-                                            ", list bounds " + std::to_string(pool.L[0].ub) + " / " + std::to_string(pool.L[1].ub) + ";" + st + ")");
+      std::string ls;
+      for (int l = 0; l < pool.nlists; l++) ls += " [list " + std::to_string(l) + ": chunks " + std::to_string(pool.L[l].seq_enq) + ", bound " + std::to_string(pool.L[l].ub) + "]";
+      return fail(APDGICP_ERR_INTERNAL, "pool: nothing in flight to wait for (" + ls + ";" + st + ")");
     }
     {
       roctx_range rr("apdgicp:pool_wait");
@@ -1901,7 +2020,8 @@ class Engine {
       }
       if (got < 0) return got;
       if (got == 0) {  // a GPU that takes this long gets the sleeping wait: the older outstanding poll of the two lists
-        int l = pool.L[0].seq_seen < pool.L[0].seq_enq ? 0 : 1;
+        int l = 0;
+        while (l + 1 < pool.nlists && !(pool.L[l].seq_seen < pool.L[l].seq_enq)) l++;
         const uint64_t want = pool.L[l].seq_seen + 1;
         APD_HIP(hipEventSynchronize(pool.L[l].ev[want % kPoolRing]));
         if (*(volatile int*)&pool_hdr(l, want)->seq != (int)want) return fail(APDGICP_ERR_INTERNAL, "pool: a poll finished without posting its header");
@@ -1949,15 +2069,21 @@ class Engine {
       if (rank < best_rank || (rank == best_rank && c.ticket < best_ticket)) lane = l, best_rank = rank, best_ticket = c.ticket;
     }
     // the pair list the batch joins: the one with fewer pairs pending or running
-    int load[Pool::kLists] = {0, 0};
+    int load[Pool::kMaxLists] = {0, 0, 0, 0};
     for (const PoolJob& c : pool.jobs)
       if (c.state == PoolJob::PENDING || c.state == PoolJob::RUNNING) load[c.list] += c.np;
-    const int list = load[1] < load[0] ? 1 : 0;
+    int list = 0;
+    for (int l = 1; l < pool.nlists; l++)
+      if (load[l] < load[list]) list = l;
     while (pool.jobs[lane].state == PoolJob::PENDING || pool.jobs[lane].state == PoolJob::RUNNING) APD_TRY(pool_pump(true));  // (the oldest batch: its lane is next)
     PoolJob& j = pool.jobs[lane];
     // the clouds of this batch, on the cloud stream: sort, covariances of those that lack them, descriptor table
     std::vector<int> ids;
     APD_TRY(filter_cov_ids(need, false, ids));
+    // every cloud the batch reads: one the other lane prepared (a keyframe shared with the previous batch) puts this lane behind it, so
+    // that the event below covers it
+    for (int id : need) lane_touch(clouds[id]);
+    APD_TRY(lane_order());
     APD_TRY(upload_desc());
     if (!ids.empty()) {
       APD_TRY(d_ids.upload(ids.data(), ids.size() * sizeof(int), cstream));
@@ -2000,6 +2126,7 @@ class Engine {
     j.layout_gen = pool.layout_gen;
     pool.last_lane = lane;
     *ticket = j.ticket;
+    pool_swap_cloud_lane();  // the next batch's clouds are prepared on the other cloud stream
     return pool_pump(false);
   }
 

@@ -2423,6 +2423,17 @@ struct LinPoint {
 // The per-point part of update_correspondences + linearize (A:137-258) once the 1-NN search has produced the
 // minimum distance m and the chunk it was found in: exact index, gate, APD covariance, RCR^-1, e, J, H, b.
 // lp receives this point's quantities (left all zero when it has no correspondence); lin_term turns them into the 29 sums.
+// reciprocal square root of a positive double: the hardware's estimate (v_rsq_f64) and two Newton steps (~1e-16 relative); +inf for 0
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  const double h = 0.5 * x;
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return x > 0.0 ? y : __builtin_inf();
+}
+
+// ALG: APDGICP_FLAG_ALGEBRAIC_APD -- the sensor model's ratios straight from the point's coordinates (see include/apdgicp_hip.h)
+template <bool ALG = false>
 __device__ __forceinline__ void linearize_point(const CloudDesc& src, const CloudDesc& tgt, const Rigid& T, const Work& w, const Consts& cst,
                                                 int pair, int i, const float4 p, float ptx, float pty, float ptz, float m, unsigned chunk,
                                                 bool tie, bool kept, const float4 tq_rec /* nnpt[i], read by the caller */,
@@ -2469,6 +2480,24 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     const auto cb = G((const double*)tgt.cov);
     const Sym3 cov_B{cb[corr], cb[M + corr], cb[2 * M + corr], cb[3 * M + corr], cb[4 * M + corr], cb[5 * M + corr]};
     // APD sensor-noise covariance from the transformed point (A:167-184)
+    double s_x, s_y, s_z, ce, se, caz, saz;
+    if constexpr (ALG) {
+      // no angles: every quantity the model takes from them is a ratio of the point's coordinates (fp64, from the fp32 point)
+      const double x = (double)ptx, y = (double)pty, z = (double)ptz;
+      const double xx = x * x, yy = y * y, zz = z * z;
+      const double rho2 = xx + yy, yz2 = yy + zz, r2 = rho2 + zz;
+      const double ir = r2 > 0.0 ? rsqrt_nr(r2) : 0.0;            // the origin: dist = 0, the model vanishes
+      const double irho = rho2 > 0.0 ? rsqrt_nr(rho2) : 0.0;      // on the z axis: azimuth = atan2(0, 0) = 0
+      const double dist = r2 * ir;
+      // 1 / cos(AoA) = r / sqrt(y^2 + z^2), at most 1 / |cos((double)(float)(pi/2))|: what the reference's fp32 angle can give at most
+      const double inv_cos = fmin(dist * rsqrt_nr(yz2), 1.0 / 4.371138828673793e-08);
+      const double dist_c = dist * inv_cos;
+      s_x = dist * cst.dist_var_400;
+      s_y = dist_c * cst.sin_az;
+      s_z = dist_c * cst.sin_el;
+      se = rho2 * irho * ir, ce = z * ir;
+      caz = rho2 > 0.0 ? x * irho : 1.0, saz = y * irho;
+    } else {
     const double dist = sqrt((double)ptx * (double)ptx + (double)pty * (double)pty + (double)ptz * (double)ptz);
     double aoa, elevation, azimuth;
     {  // fp32, as the reference evaluates it (float overloads, no FMA): not contracted.  apd_atan2f is glibc's generic atan2f
@@ -2502,11 +2531,10 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
     (void)sin_aoa;
     // (A:169-171 divide three times -- dist * dist_var / 400, dist * sin(az) / cos(aoa), dist * sin(el) / cos(aoa); here one
     // division, dist / cos(aoa), and dist_var / 400 from the host: a rounding apart, like the contraction, 22 fp64 instructions less)
-    const double s_x = dist * cst.dist_var_400;
+    s_x = dist * cst.dist_var_400;
     const double dist_c = dist / cos_aoa;
-    const double s_y = dist_c * cst.sin_az;
-    const double s_z = dist_c * cst.sin_el;
-    double ce, se, caz, saz;
+    s_y = dist_c * cst.sin_az;
+    s_z = dist_c * cst.sin_el;
 #if defined(APD_ABL_LIN_NO_SINCOS) || defined(APD_SINCOS_NO_TABLE)  // (APD_SINCOS_NO_TABLE: A/B builds -- sincos_pi for all three angles, as until round 5)
     APD_SINCOS(elevation, &se, &ce);
     APD_SINCOS(azimuth, &saz, &caz);
@@ -2521,6 +2549,7 @@ __device__ __forceinline__ void linearize_point(const CloudDesc& src, const Clou
       if (s2 + c2 + s3 + c3 + s4 + c4 == 123.0) se = s2;
     }
 #endif
+    }  // (!ALG)
     // A = (Rz(azimuth) * Ry(elevation)) * diag(s)
     const double a00 = caz * ce * s_x, a01 = -saz * s_y, a02 = caz * se * s_z;
     const double a10 = saz * ce * s_x, a11 = caz * s_y, a12 = saz * se * s_z;
@@ -2829,7 +2858,7 @@ __device__ __forceinline__ bool last_block_of_pair(int* ticket, int nblk, int ti
 #ifndef APD_LIN_WPE_F32
 #define APD_LIN_WPE_F32 6  // the fp32 per-point variant: at 7 waves per SIMD (73 registers) it spilled 44 B to scratch
 #endif
-template <bool FUSED, bool F32 = false>
+template <bool FUSED, bool F32 = false, bool ALG = false>
 __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ? (F32 ? APD_LIN_WPE_F32 : APD_LIN_WPE) : 1, 8))) void k_linearize(const CloudDesc* clouds, const PairDesc* pairs, PairState* st, Work w, Consts cst,
                                                        int want_Hb) {
   __shared__ double red[(LIN_BLK / 64) * 29];
@@ -2856,8 +2885,10 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     lp.vx = lp.vy = lp.vz = lp.mex = lp.mey = lp.mez = lp.cost = lp.matched = 0.0;
   }
   __shared__ float s_atan[APD_ATAN_TAB_ROWS * APD_ATAN_TAB_STRIDE];
-  atan_tab_to_lds(s_atan, tid);
-  __syncthreads();  // (every exit above is taken by the whole block)
+  if constexpr (!ALG) {
+    atan_tab_to_lds(s_atan, tid);
+    __syncthreads();  // (every exit above is taken by the whole block)
+  }
 
   if (i < N) {
     // everything that depends on the point index alone is requested FIRST -- the point, its covariance, the neighbour on
@@ -2890,7 +2921,7 @@ __global__ __launch_bounds__(LIN_BLK) __attribute__((amdgpu_waves_per_eu(FUSED ?
     load_Tf(T, Tf);
     const float ptx = xf_row(Tf + 0, p.x, p.y, p.z, w.xf_linear), pty = xf_row(Tf + 4, p.x, p.y, p.z, w.xf_linear), ptz = xf_row(Tf + 8, p.x, p.y, p.z, w.xf_linear);
     if constexpr (F32) linearize_point_f32(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
-    else linearize_point(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
+    else linearize_point<ALG>(src, tgt, T, w, cst, pair, i, p, ptx, pty, ptz, m, chunk, tie, kept, tq_rec, cov_A, lp, s_atan);
   }
   __shared__ double red_scratch[(LIN_BLK / 64) * RED_LDS_WAVE];
   block_reduce_lds<29, LIN_BLK>([&](int r) {
@@ -3027,12 +3058,18 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
 // debugger stepping through L:64-76 / L:127-173 would write down -- per LM trial the lambda it was solved with and its rho
 // and the two costs it compares (L:137-146: y0 from linearize, yi from compute_error at the trial pose), per completed outer
 // iteration the pose x0 behind it (L:119 / L:166).  Layout: {int n_trial, n_pose, cap_trial, cap_pose} (16 bytes),
-// lambda[cap_trial], rho[cap_trial], y0[cap_trial], yi[cap_trial], pose[cap_pose][12] (row-major 3x4).  Counts keep counting
-// past the capacity; only what fits is stored.
-__device__ __forceinline__ void trace_trial(double* tr, double lambda, double rho, double y0, double yi) {
+// lambda[cap_trial], rho[cap_trial], y0[cap_trial], yi[cap_trial], pose[cap_pose][12] (row-major 3x4), then (round 6, behind the rest so
+// that nothing moved) dnorm[cap_trial]: |d| of the trial's step, the "|delta|" column of the reference's debug table (L:148-154).
+// Counts keep counting past the capacity; only what fits is stored.
+__device__ __forceinline__ void trace_trial(double* tr, double lambda, double rho, double y0, double yi, const double* d6) {
   int* h = (int*)tr;
   const int n = h[0], cap = h[2];
-  if (n < cap) tr[2 + n] = lambda, tr[2 + cap + n] = rho, tr[2 + 2 * cap + n] = y0, tr[2 + 3 * cap + n] = yi;
+  if (n < cap) {
+    tr[2 + n] = lambda, tr[2 + cap + n] = rho, tr[2 + 2 * cap + n] = y0, tr[2 + 3 * cap + n] = yi;
+    double nn = 0.0;
+    for (int q = 0; q < 6; q++) nn += d6[q] * d6[q];
+    tr[2 + 4 * cap + 12 * h[3] + n] = sqrt(nn);
+  }
   h[0] = n + 1;
 }
 __device__ __forceinline__ void trace_pose(double* tr, const Rigid& x) {
@@ -3140,7 +3177,7 @@ __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, con
   double den = 0.0;
   for (int q = 0; q < 6; q++) den += s.d[q] * (s.lambda * s.d[q] - s.b[q]);
   const double rho = (s.y0 - yi) / den;  // L:146
-  if (tr) trace_trial(tr, s.lambda, rho, s.y0, yi);
+  if (tr) trace_trial(tr, s.lambda, rho, s.y0, yi, s.d);
   if (rho < 0) {                         // L:156-164
     if (is_converged(s.delta, c.rot_eps, c.trans_eps)) {
       step_done(s, c, true, tr);  // returns true WITHOUT applying delta

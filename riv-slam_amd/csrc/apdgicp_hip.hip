@@ -16,7 +16,7 @@ struct apdgicp_handle {
   int n_src_at_corr = 0;
   // apdgicp_set_trace: the trace of the last apdgicp_align_host_loop (apdgicp_align leaves its own on the device, Engine::d_trace)
   bool trace_from_host_loop = false;
-  std::vector<double> tr_lambda, tr_rho, tr_y0, tr_yi, tr_poses;  // poses: 16 doubles each, column-major
+  std::vector<double> tr_lambda, tr_rho, tr_y0, tr_yi, tr_dnorm, tr_poses;  // poses: 16 doubles each, column-major
 };
 
 struct apdgicp_batch {
@@ -91,6 +91,43 @@ int guarded(F&& f) {
 extern "C" {
 
 int apdgicp_abi_version(void) { return APDGICP_ABI_VERSION; }
+// What this library was compiled with: the compiler flags build.py passed ("unknown" for a hand build), then " | variant:" and every
+// experiment define that CHANGES RESULTS OR KERNELS -- detected here by the preprocessor, so no build script can leave one out.  A
+// library that lists a variant is an ablation / A-B build (some are wrong by design): the Python loader and the C++ adapter's self-check
+// refuse it unless APDGICP_ALLOW_VARIANT_LIB=1.
+#ifndef APD_BUILD_FLAGS
+#define APD_BUILD_FLAGS "unknown"
+#endif
+#define APD_STR2(x) #x
+#define APD_STR(x) APD_STR2(x)
+const char* apdgicp_build_flags(void) {
+  return APD_BUILD_FLAGS " | variant:"
+#ifdef APD_ABL_KNN_SKIP_C
+      " APD_ABL_KNN_SKIP_C"
+#endif
+#ifdef APD_ABL_LIN_DOUBLE_ATAN
+      " APD_ABL_LIN_DOUBLE_ATAN"
+#endif
+#ifdef APD_ABL_LIN_DOUBLE_SINCOS
+      " APD_ABL_LIN_DOUBLE_SINCOS"
+#endif
+#ifdef APD_ABL_LIN_NO_ATAN
+      " APD_ABL_LIN_NO_ATAN"
+#endif
+#ifdef APD_ABL_LIN_NO_SINCOS
+      " APD_ABL_LIN_NO_SINCOS"
+#endif
+#ifdef APD_ABL_SEARCH_KEEP_AFTER
+      " APD_ABL_SEARCH_KEEP_AFTER=" APD_STR(APD_ABL_SEARCH_KEEP_AFTER)
+#endif
+#ifdef APD_OCML_ATAN2F
+      " APD_OCML_ATAN2F"
+#endif
+#ifdef APD_SINCOS_NO_TABLE
+      " APD_SINCOS_NO_TABLE"
+#endif
+      ;
+}
 #ifndef APD_SOURCE_STAMP
 #define APD_SOURCE_STAMP "unstamped"
 #endif
@@ -355,7 +392,7 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
     double final_H[36];
     for (int q = 0; q < 36; q++) final_H[q] = (q % 7 == 0) ? 1.0 : 0.0;
     double y0 = 0.0;
-    h->tr_lambda.clear(), h->tr_rho.clear(), h->tr_y0.clear(), h->tr_yi.clear(), h->tr_poses.clear();
+    h->tr_lambda.clear(), h->tr_rho.clear(), h->tr_y0.clear(), h->tr_yi.clear(), h->tr_dnorm.clear(), h->tr_poses.clear();
     h->trace_from_host_loop = true;
     for (int it = 0; it < p.max_iterations && !converged; it++) {  // L:67
       nr_iterations = it;
@@ -389,7 +426,11 @@ int apdgicp_align_host_loop(apdgicp_handle* h, const float guess[16], apdgicp_re
           double den = 0.0;
           for (int q = 0; q < 6; q++) den += d[q] * (lambda * d[q] - b[q]);
           const double rho = (y0 - yi) / den;
-          if (e.trace_on) h->tr_lambda.push_back(lambda), h->tr_rho.push_back(rho), h->tr_y0.push_back(y0), h->tr_yi.push_back(yi);
+          if (e.trace_on) {
+            double nn = 0.0;
+            for (int q = 0; q < 6; q++) nn += d[q] * d[q];
+            h->tr_lambda.push_back(lambda), h->tr_rho.push_back(rho), h->tr_y0.push_back(y0), h->tr_yi.push_back(yi), h->tr_dnorm.push_back(std::sqrt(nn));
+          }
           if (rho < 0) {
             if (is_converged(delta, p.rotation_epsilon, p.transformation_epsilon)) {
               ok = true;
@@ -476,6 +517,30 @@ int apdgicp_get_trace(apdgicp_handle* h, int64_t trial_capacity, double* lambdas
       memcpy(r.m, &buf[2 + 4 * (size_t)hdr[2] + 12 * (size_t)q], sizeof(r.m));
       rigid_to_colmajor(r, poses16 + 16 * q);
     }
+    return 0;
+  });
+}
+
+int apdgicp_get_trace_step_norms(apdgicp_handle* h, int64_t capacity, double* norms, int64_t* n_trials) {
+  return guarded([&]() -> int {
+    if (!h || !n_trials || capacity < 0 || (capacity > 0 && !norms)) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+    Engine& e = h->eng;
+    if (!e.trace_on) return fail(APDGICP_ERR_NO_INPUT, "tracing is off (apdgicp_set_trace)");
+    if (h->trace_from_host_loop) {
+      *n_trials = (int64_t)h->tr_dnorm.size();
+      const int64_t nt = std::min<int64_t>(*n_trials, capacity);
+      if (nt) memcpy(norms, h->tr_dnorm.data(), nt * sizeof(double));
+      return 0;
+    }
+    if (!e.d_trace.p) return fail(APDGICP_ERR_NO_INPUT, "no align has run since tracing was enabled");
+    std::vector<double> buf(e.trace_bytes() / sizeof(double));
+    APD_HIP(hipMemcpyAsync(buf.data(), e.d_trace.p, e.trace_bytes(), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    int hdr[4];
+    memcpy(hdr, buf.data(), sizeof(hdr));
+    *n_trials = hdr[0];
+    const int64_t nt = std::min<int64_t>(std::min(hdr[0], hdr[2]), capacity);
+    if (nt) memcpy(norms, &buf[2 + 4 * (size_t)hdr[2] + 12 * (size_t)hdr[3]], nt * sizeof(double));
     return 0;
   });
 }
@@ -599,6 +664,35 @@ int apdgicp_nearest_neighbours(apdgicp_handle* h, const float T[16], int32_t* in
     int* d_i = e.d_stage.as<int>();
     float* d_s = (float*)(d_i + n);
     hipLaunchKernelGGL(k_export_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.work.nnpt, e.work.sqd, e.clouds[kSrc].perm.as<int>(),
+                       e.clouds[kTgt].perm.as<int>(), (int)n, d_i, d_s);
+    APD_HIP(hipMemcpyAsync(index, d_i, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipMemcpyAsync(sq_dist, d_s, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    APD_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  });
+}
+
+int apdgicp_nearest_neighbours_of(apdgicp_handle* h, const float* queries_xyz, int64_t n, int64_t stride_bytes, int32_t* index, float* sq_dist) {
+  return guarded([&]() -> int {
+    if (!h || !queries_xyz || !index || !sq_dist || n <= 0) return fail(APDGICP_ERR_INVALID_ARG, "null argument or no queries");
+    Engine& e = h->eng;
+    constexpr int kQry = 2;  // a scratch cloud slot behind source and target
+    if (e.clouds.size() < 2 || e.clouds[kTgt].n <= 0) return fail(APDGICP_ERR_NO_INPUT, "target cloud is not set");
+    APD_TRY(e.set_cloud(kQry, queries_xyz, n, stride_bytes, 0, 0));
+    apdgicp_pair p;
+    p.source_cloud = kQry, p.target_cloud = kTgt;
+    identity16(p.guess);
+    h->pair_ready = false, h->have_corr = false;  // the handle's own pair is set up again by whoever needs it next
+    APD_TRY(e.setup_pairs(&p, 1, true, false, /*need_cov=*/false));
+    // the ungated cold search + the per-point pass that settles the exact index (the queries' covariances are whatever the buffer holds:
+    // the pass computes a cost nobody reads)
+    const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double cost = 0.0;
+    APD_TRY(e.probe_linearize(I16, nullptr, nullptr, &cost, nullptr));
+    APD_TRY(e.d_stage.ensure((size_t)n * 8));
+    int* d_i = e.d_stage.as<int>();
+    float* d_s = (float*)(d_i + n);
+    hipLaunchKernelGGL(k_export_nn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.work.nnpt, e.work.sqd, e.clouds[kQry].perm.as<int>(),
                        e.clouds[kTgt].perm.as<int>(), (int)n, d_i, d_s);
     APD_HIP(hipMemcpyAsync(index, d_i, n * sizeof(int), hipMemcpyDeviceToHost, e.stream));
     APD_HIP(hipMemcpyAsync(sq_dist, d_s, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
@@ -879,6 +973,7 @@ int apdgicp_batch_synchronize(apdgicp_batch* b) {
   return guarded([&]() -> int {
     if (b->eng.pool.on) APD_TRY(b->eng.pool_drain());  // (pooled LM batches: every batch in flight runs to its end)
     if (b->eng.cstream != b->eng.stream) APD_HIP(hipStreamSynchronize(b->eng.cstream));
+    if (b->eng.pool.on && b->eng.pool.cstream2) APD_HIP(hipStreamSynchronize(b->eng.pool.cstream2));
     APD_HIP(hipStreamSynchronize(b->eng.stream));
     return 0;
   });

@@ -25,6 +25,7 @@ OPT_LM, OPT_GN = 0, 1
 FLAG_PLAIN_GICP = 1  # upstream fast_gicp::FastGICP cost (no APD covariance)
 FLAG_XF_LINEAR_CHAIN = 2  # T*p summed ((r0 x + r1 y) + r2 z) + t like Eigen 3.2 instead of pairwise like Eigen >= 3.3 (include/apdgicp_hip.h)
 FLAG_FP32_POINT_MATH = 4  # opt-in: the per-point algebra behind the search in fp32 (include/apdgicp_hip.h); not the reference's precision
+FLAG_ALGEBRAIC_APD = 8  # opt-in: the sensor model's sines / cosines as coordinate ratios, no atan2f / sincos (include/apdgicp_hip.h); not the reference's arithmetic
 SOURCE, TARGET = 0, 1
 
 
@@ -81,8 +82,8 @@ assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 96
 
 # every symbol include/apdgicp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "apdgicp_abi_version", "apdgicp_source_stamp", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
-    "apdgicp_set_trace", "apdgicp_get_trace", "apdgicp_debug_atan2f", "apdgicp_nearest_neighbours", "apdgicp_get_points",
+    "apdgicp_abi_version", "apdgicp_source_stamp", "apdgicp_build_flags", "apdgicp_last_error", "apdgicp_device_count", "apdgicp_default_params",
+    "apdgicp_set_trace", "apdgicp_get_trace", "apdgicp_get_trace_step_norms", "apdgicp_debug_atan2f", "apdgicp_nearest_neighbours", "apdgicp_nearest_neighbours_of", "apdgicp_get_points",
     "apdgicp_create", "apdgicp_destroy", "apdgicp_set_params", "apdgicp_get_params",
     "apdgicp_set_source", "apdgicp_set_target", "apdgicp_clear_source", "apdgicp_clear_target",
     "apdgicp_swap_source_and_target", "apdgicp_compute_covariances", "apdgicp_get_covariances",
@@ -124,10 +125,24 @@ def load_library(path: str | None = None):
     L.apdgicp_source_stamp.restype = C.c_char_p
     if path is None and os.environ.get("APDGICP_ALLOW_STALE_LIB", "0") != "1":
         from . import build as _build
-        have, want = L.apdgicp_source_stamp().decode(), _build.source_stamp()
-        if have != want:
+        try:
+            want = _build.source_stamp()
+        except OSError:
+            want = None   # a deployment that ships the library and this package without csrc/ and include/: nothing to compare with
+        have = L.apdgicp_source_stamp().decode()
+        if want is not None and have != want:
             raise RuntimeError(f"{p} was compiled from other sources (stamp {have}) than the ones on disk ({want}): rebuild it "
                                "(`python -c 'import __graft_entry__ as g; g.build()'`)")
+    # ... and how it was compiled: a library that lists an experiment define (APD_ABL_*: ablations that are wrong by design; APD_OCML_ATAN2F,
+    # APD_SINCOS_NO_TABLE: A/B builds) behind "variant:" is not the product, whatever its stamp says (tools/ab_bench.sh sets the override)
+    try:
+        L.apdgicp_build_flags.restype = C.c_char_p
+        flags = L.apdgicp_build_flags().decode()
+    except AttributeError as e:
+        raise RuntimeError(f"{p} does not export apdgicp_build_flags (ABI < 6): rebuild it") from e
+    variant = flags.split("| variant:", 1)[1].strip() if "| variant:" in flags else "?"
+    if variant and os.environ.get("APDGICP_ALLOW_VARIANT_LIB", "0") != "1":
+        raise RuntimeError(f"{p} is an experiment build ({variant}), not the product: rebuild it, or set APDGICP_ALLOW_VARIANT_LIB=1 for an A/B run")
     L.apdgicp_abi_version.restype = i32
     L.apdgicp_last_error.restype = C.c_char_p
     L.apdgicp_device_count.argtypes = [C.POINTER(i32)]
@@ -153,8 +168,10 @@ def load_library(path: str | None = None):
     L.apdgicp_get_final_hessian.argtypes = [vp, vp]
     L.apdgicp_set_trace.argtypes = [vp, i32]
     L.apdgicp_get_trace.argtypes = [vp, i64, vp, vp, vp, vp, C.POINTER(i64), i64, vp, C.POINTER(i64)]
+    L.apdgicp_get_trace_step_norms.argtypes = [vp, i64, vp, C.POINTER(i64)]
     L.apdgicp_debug_atan2f.argtypes = [i32, vp, vp, vp, i64]
     L.apdgicp_nearest_neighbours.argtypes = [vp, vp, vp, vp, i64]
+    L.apdgicp_nearest_neighbours_of.argtypes = [vp, vp, i64, i64, vp, vp]
     L.apdgicp_get_points.argtypes = [vp, i32, vp, i64]
     L.apdgicp_transform_source.argtypes = [vp, vp, vp, i64, i64]
     L.apdgicp_fitness_score.argtypes = [vp, vp, dbl, C.POINTER(dbl), C.POINTER(i64)]
@@ -196,6 +213,11 @@ def load_library(path: str | None = None):
 def source_stamp() -> str:
     """The fingerprint of the sources the loaded library was compiled from (apdgicp_source_stamp)."""
     return load_library().apdgicp_source_stamp().decode()
+
+
+def build_flags() -> str:
+    """The compiler flags of the loaded library and, behind "| variant:", its experiment defines (apdgicp_build_flags; empty = the product)."""
+    return load_library().apdgicp_build_flags().decode()
 
 
 def debug_atan2f(y, x, device: int = 0) -> np.ndarray:
@@ -339,6 +361,11 @@ class FastAPDGICP:
     def setTransformOrder(self, linear_chain: bool):
         """fp32 summation order of T * p (A:149): False = pairwise (Eigen >= 3.3, default), True = linear chain (Eigen 3.2); include/apdgicp_hip.h"""
         self.params.flags = (self.params.flags | FLAG_XF_LINEAR_CHAIN) if linear_chain else (self.params.flags & ~FLAG_XF_LINEAR_CHAIN)
+        self._push()
+
+    def setAlgebraicAPD(self, on: bool):
+        """APDGICP_FLAG_ALGEBRAIC_APD (opt-in, include/apdgicp_hip.h): the sensor model of A:167-184 from coordinate ratios instead of fp32 angles"""
+        self.params.flags = (self.params.flags | FLAG_ALGEBRAIC_APD) if on else (self.params.flags & ~FLAG_ALGEBRAIC_APD)
         self._push()
 
     def setInitialLambdaFactor(self, v):
@@ -512,6 +539,15 @@ class FastAPDGICP:
         idx = np.empty(self.n_src, dtype=np.int32)
         sqd = np.empty(self.n_src, dtype=np.float32)
         _check(self.L.apdgicp_nearest_neighbours(self.h, _ptr(Tc), _ptr(idx), _ptr(sqd), self.n_src))
+        return idx, sqd
+
+    def nearestNeighboursOf(self, queries):
+        """(index, sq_dist) of the nearest target point of arbitrary host query points [n, >= 3] float32: one batched device pass
+        (apdgicp_nearest_neighbours_of), what pcl::search::Search::nearestKSearch(cloud, indices, 1, ...) returns."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        idx = np.empty(len(q), dtype=np.int32)
+        sqd = np.empty(len(q), dtype=np.float32)
+        _check(self.L.apdgicp_nearest_neighbours_of(self.h, _ptr(q), len(q), q.strides[0], _ptr(idx), _ptr(sqd)))
         return idx, sqd
 
     def getPoints(self, which) -> np.ndarray:

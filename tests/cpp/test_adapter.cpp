@@ -252,6 +252,92 @@ static int run_base_tree(const float* s, int ns, const float* t, int nt, const f
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6 boundary items: setDebugPrint's LM table (lsq_registration_impl.hpp:148-154), the batch form of the search object's
+// nearestKSearch (one device pass for arbitrary queries), the one-line warning of the per-query fall-back, an empty target followed
+// by the OLD target again (pointer-equal: must reach the device), and the shape of the outputs when a search cannot be answered.
+static int run_boundary(const float* s, int ns, const float* t, int nt, const float* guess) {
+  using Reg = fast_gicp::FastAPDGICPHip<PointT, PointT>;
+  auto registration = select_registration_method_hip();
+  Reg& reg = *dynamic_cast<Reg*>(registration.get());
+  pcl::PointCloud<PointT>::ConstPtr A = make_cloud(t, nt), source = make_cloud(s, ns);
+  pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
+  pcl::Registration<PointT, PointT>::Matrix4 g;
+  for (int i = 0; i < 16; i++) g.data()[i] = guess[i];
+  registration->setInputSource(source), registration->setInputTarget(A);
+  reg.setDebugPrint(true);
+  std::printf("TABLE-BEGIN\n");
+  registration->align(*aligned, g);
+  std::printf("TABLE-END\n");
+  reg.setDebugPrint(false);
+  const int n_lin = reg.lastResult().n_linearize, n_err = reg.lastResult().n_compute_error, conv0 = registration->hasConverged() ? 1 : 0;
+  // ---- batch queries: 700 points that are no transformed source points
+  pcl::PointCloud<PointT> queries;
+  queries.resize(700);
+  for (int i = 0; i < 700; i++) {
+    const int j = (i * 37) % nt;
+    queries.at(i).x = t[3 * j] + 0.011f * (float)(i % 7 - 3), queries.at(i).y = t[3 * j + 1] - 0.017f * (float)(i % 5 - 2), queries.at(i).z = t[3 * j + 2] + 0.003f * (float)(i % 3);
+  }
+  auto brute = [&](const PointT& q, int& bi, float& bd) {
+    bi = -1, bd = 1e30f;
+    for (int j = 0; j < nt; j++) {
+      const float dx = q.x - t[3 * j], dy = q.y - t[3 * j + 1], dz = q.z - t[3 * j + 2];
+      float d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      if (d < bd) bd = d, bi = j;
+    }
+  };
+  std::vector<std::vector<int>> bi_out;
+  std::vector<std::vector<float>> bd_out;
+  const long fb0 = reg.deviceSearchStats().fallbacks;
+  registration->getSearchMethodTarget()->nearestKSearch(queries, std::vector<int>(), 1, bi_out, bd_out);
+  int batch_ok = bi_out.size() == 700 ? 1 : 0;
+  for (int i = 0; i < 700 && batch_ok; i++) {
+    int bi;
+    float bd;
+    brute(queries.at(i), bi, bd);
+    batch_ok = bi_out[i].size() == 1 && bd_out[i].size() == 1 && bi_out[i][0] == bi && bd_out[i][0] == bd;
+  }
+  std::vector<int> sub = {5, 17, 699};
+  registration->getSearchMethodTarget()->nearestKSearch(queries, sub, 1, bi_out, bd_out);
+  int sub_ok = bi_out.size() == 3 ? 1 : 0;
+  for (int i = 0; i < 3 && sub_ok; i++) {
+    int bi;
+    float bd;
+    brute(queries.at(sub[i]), bi, bd);
+    sub_ok = bi_out[i][0] == bi && bd_out[i][0] == bd;
+  }
+  const long batch_device_queries = reg.deviceSearchStats().device_queries, batch_fallbacks = reg.deviceSearchStats().fallbacks - fb0;
+  // the handle still registers after serving foreign queries (its own pair is set up again)
+  registration->align(*aligned, g);
+  const int conv_after_batch = registration->hasConverged() ? 1 : 0, iters_after_batch = reg.lastResult().n_linearize;
+  // ---- two single foreign queries: the warning appears ONCE on stderr (the Python side counts the lines)
+  std::vector<int> pi;
+  std::vector<float> pd;
+  registration->getSearchMethodTarget()->nearestKSearch(queries.at(3), 1, pi, pd);
+  registration->getSearchMethodTarget()->nearestKSearch(queries.at(4), 1, pi, pd);
+  // ---- an empty target, then the OLD target object again
+  pcl::PointCloud<PointT>::ConstPtr empty(new pcl::PointCloud<PointT>());
+  registration->setInputTarget(empty);
+  registration->align(*aligned, g);
+  const int conv_empty_target = registration->hasConverged() ? 1 : 0;
+  registration->setInputTarget(A);  // pointer-equal to what PCL still holds in target_
+  registration->align(*aligned, g);
+  const int conv_old_target_again = registration->hasConverged() ? 1 : 0;
+  // ---- a search that cannot be answered: no target at all
+  reg.clearTarget();
+  pi.clear(), pd.clear();
+  const int got = registration->getSearchMethodTarget()->nearestKSearch(queries.at(0), 1, pi, pd);
+  const int unanswered_shape_ok = got == 0 && pi.size() == 1 && pd.size() == 1 && pi[0] == -1 && pd[0] > 1e38f;
+  std::printf("{\"n_linearize\": %d, \"n_compute_error\": %d, \"converged\": %d, \"batch_ok\": %d, \"sub_ok\": %d, \"batch_device_queries\": %ld, "
+              "\"batch_fallbacks\": %ld, \"conv_after_batch\": %d, \"n_linearize_after_batch\": %d, \"conv_empty_target\": %d, \"conv_old_target_again\": %d, "
+              "\"unanswered_shape_ok\": %d}\n",
+              n_lin, n_err, conv0, batch_ok, sub_ok, batch_device_queries, batch_fallbacks, conv_after_batch, iters_after_batch, conv_empty_target,
+              conv_old_target_again, unanswered_shape_ok);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("compile-only\n");
@@ -267,6 +353,7 @@ int main(int argc, char** argv) {
   std::fclose(f);
   if (argc > 2 && std::string(argv[2]) == "--protocol") return run_protocols(s.data(), n[0], t.data(), n[1], guess);
   if (argc > 2 && std::string(argv[2]) == "--base-tree") return run_base_tree(s.data(), n[0], t.data(), n[1], guess);
+  if (argc > 2 && std::string(argv[2]) == "--boundary") return run_boundary(s.data(), n[0], t.data(), n[1], guess);
 
   auto registration = select_registration_method_hip();
   auto source = make_cloud(s.data(), n[0]);

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""APDGICP_FLAG_FP32_POINT_MATH (opt-in) against the default (the reference's fp64 per-point algebra): the same seeded pairs as
-tests/measure/parity_sweep.py through two product handles -- pose difference, share of runs whose counts (converged, iterations,
-linearisations, compute_error evaluations) change -- and the kernel / step times of the bench workload under both.
-usage: python tests/measure/fp32_mode.py [n_pairs_per_config=60]  -> one JSON object (commit it under profiles/)"""
+"""An opt-in arithmetic mode -- APDGICP_FLAG_FP32_POINT_MATH (default) or, with `algebraic` as the second argument,
+APDGICP_FLAG_ALGEBRAIC_APD -- against the default (the reference's arithmetic): the same seeded pairs as tests/measure/parity_sweep.py
+through two product handles -- pose difference, share of runs whose counts (converged, iterations, linearisations, compute_error
+evaluations) change -- then the 32 bench pairs (GN-20) and the 32 loop pairs (LM, launch parameters, identity guess) under both, the
+mode's poses also against the CPU ORACLE'S DEFAULT arithmetic on eight of each (north-star tolerance 1e-3 m / 1e-4 rad).
+usage: python tests/measure/fp32_mode.py [n_pairs_per_config=60] [fp32|algebraic]  -> one JSON object (commit it under profiles/)"""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -10,7 +12,10 @@ import numpy as np, torch  # noqa
 reg = importlib.import_module("riv-slam_amd.registration"); scene = importlib.import_module("riv-slam_amd.scene")
 
 NP = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-F32 = reg.FLAG_FP32_POINT_MATH
+MODE = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+F32 = reg.FLAG_ALGEBRAIC_APD if MODE == "algebraic" else reg.FLAG_FP32_POINT_MATH   # (the bit under test)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref as R_  # noqa  (the checker: poses of the mode against the reference's arithmetic)
 CONFIGS = {
     "lm_default": dict(),
     "lm_launch": dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0),
@@ -59,5 +64,36 @@ for fl in (0, F32):
 d = [scene.pose_error(reg.result_matrix(res[0][i]), reg.result_matrix(res[F32][i])) for i in range(P)]
 out["bench_gn20_8k_x32"] = dict(max_t_diff_m=max(x[0] for x in d), max_r_diff_rad=max(x[1] for x in d),
                                 median_t_diff_m=float(np.median([x[0] for x in d])), median_r_diff_rad=float(np.median([x[1] for x in d])))
-out["note"] = "product (default, fp64 per-point algebra = the reference's) vs product with APDGICP_FLAG_FP32_POINT_MATH on identical inputs; the flag is opt-in"
+def vs_oracle(kind, seed_base, kw_, count=8):
+    worst = [0.0, 0.0]
+    changed = 0
+    for p in range(count):
+        s, t, _, g = scene.make_pair(n, n, scene.pair_seed(seed_base, p), kind)
+        if kind == "loop":
+            g = np.eye(4, dtype=np.float32)
+        a = reg.FastAPDGICP(reg.default_params(**dict(kw_, flags=F32))); o = R_.RefAPDGICP(R_.default_params(**kw_))
+        for x in (a, o):
+            x.setInputSource(s); x.setInputTarget(t)
+        te, re_ = scene.pose_error(o.align(g), a.align(g))
+        worst = [max(worst[0], te), max(worst[1], re_)]
+        changed += int(a.result.n_linearize != o.n_linearize)
+    return dict(pairs=count, max_t_err_m=worst[0], max_r_err_rad=worst[1], iteration_count_changed=changed)
+out["bench_gn20_8k_vs_oracle_default"] = vs_oracle("odometry", 2, kw)
+LM = dict(max_correspondence_distance=2.0, transformation_epsilon=0.1, azimuth_variance_deg=1.0)
+out["loop_lm_8k_vs_oracle_default"] = vs_oracle("loop", 4, LM)
+lclouds = []
+for p in range(P):
+    s, t, _, _ = scene.make_pair(n, n, scene.pair_seed(4, p), "loop")
+    lclouds += [torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()]
+lres = {}
+for fl in (0, F32):
+    h = reg.BatchAPDGICP(reg.default_params(**dict(LM, flags=fl)))
+    h.set_clouds(0, lclouds)
+    lres[fl] = h.align([(2 * i, 2 * i + 1) for i in range(P)], [np.eye(4, dtype=np.float32)] * P)
+    del h
+d = [scene.pose_error(reg.result_matrix(lres[0][i]), reg.result_matrix(lres[F32][i])) for i in range(P)]
+out["loop_lm_8k_x32"] = dict(max_t_diff_m=max(x[0] for x in d), max_r_diff_rad=max(x[1] for x in d), median_t_diff_m=float(np.median([x[0] for x in d])),
+                             iteration_count_changed=int((lres[0]["n_linearize"] != lres[F32]["n_linearize"]).sum()), pairs=P)
+out["mode"] = "APDGICP_FLAG_ALGEBRAIC_APD" if MODE == "algebraic" else "APDGICP_FLAG_FP32_POINT_MATH"
+out["note"] = "product (default = the reference's arithmetic) vs product with the opt-in flag on identical inputs; *_vs_oracle_default: the flagged product against the CPU oracle WITHOUT the flag"
 print(json.dumps(out, indent=1))

@@ -95,6 +95,15 @@ class Search {
   }
   virtual PointCloudConstPtr getInputCloud() const { return input_; }
   virtual int nearestKSearch(const PointT& p, int k, std::vector<int>& idx, std::vector<float>& d2) const = 0;
+  // pcl/search/search.h + impl/search.hpp: the batch form -- every listed point of `cloud` (all of them when `indices` is empty), by
+  // default one single-point search after the other
+  using PointCloud = pcl::PointCloud<PointT>;
+  virtual void nearestKSearch(const PointCloud& cloud, const std::vector<int>& indices, int k, std::vector<std::vector<int>>& k_indices,
+                              std::vector<std::vector<float>>& k_sqr_distances) const {
+    const std::size_t n = indices.empty() ? cloud.size() : indices.size();
+    k_indices.resize(n), k_sqr_distances.resize(n);
+    for (std::size_t i = 0; i < n; i++) nearestKSearch(cloud.points[indices.empty() ? i : (std::size_t)indices[i]], k, k_indices[i], k_sqr_distances[i]);
+  }
 
  protected:
   PointCloudConstPtr input_;
@@ -106,6 +115,7 @@ class KdTree : public Search<PointT> {
   using Ptr = std::shared_ptr<KdTree<PointT>>;
   using PointCloudConstPtr = typename Search<PointT>::PointCloudConstPtr;
   using IndicesConstPtr = typename Search<PointT>::IndicesConstPtr;
+  using Search<PointT>::nearestKSearch;  // (pcl/search/kdtree.h does the same: the batch form stays visible)
   void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override {
     this->input_ = cloud;
     this->indices_ = indices;
@@ -147,7 +157,10 @@ class Registration {
 
   Registration() : tree_(new KdTree()) { final_transformation_.setIdentity(); }
   virtual ~Registration() {}
-  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) { input_ = cloud; }
+  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) {  // registration.hpp: "Invalid or empty point cloud dataset given!" -- the old cloud stays
+    if (!cloud || cloud->empty()) return;
+    input_ = cloud;
+  }
   virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) {  // registration.hpp: keeps the pointer, flags the tree as stale
     if (!cloud || cloud->empty()) return;
     target_ = cloud;

@@ -26,7 +26,47 @@ def test_library_exports_every_declared_symbol(reg):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/apdgicp_hip.h but not exported"
     assert sorted(reg.SYMBOLS) == declared
-    assert L.apdgicp_abi_version() == 5
+    assert L.apdgicp_abi_version() == 6
+
+
+def test_the_library_says_how_it_was_built_and_variants_are_refused(reg, monkeypatch):
+    """apdgicp_build_flags(): the product lists no experiment define; a library compiled with one (here APD_OCML_ATAN2F, an A/B build) carries
+    ANOTHER source stamp than the product (the stamp hashes the extra flags), names the define itself, and the loader refuses it unless
+    APDGICP_ALLOW_VARIANT_LIB=1 -- whatever APDGICP_ALLOW_STALE_LIB says (VERDICT r05 item 7 iii)."""
+    import importlib
+    import subprocess
+    import sys
+    build = importlib.import_module("riv-slam_amd.build")
+    flags = reg.build_flags()
+    assert "--offload-arch=gfx950" in flags and "-ffp-contract=off" in flags
+    assert flags.split("| variant:")[1].strip() == ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "cputest_variant", "-DAPD_OCML_ATAN2F"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    path = os.path.join(ROOT, "riv-slam_amd", "_cputest_variant.bin")
+    try:
+        assert build.library_stamp(path) not in (None, build.source_stamp())
+        assert build.library_stamp(path) == build.source_stamp(["-DAPD_OCML_ATAN2F"])
+        monkeypatch.setenv("APDGICP_ALLOW_STALE_LIB", "1")
+        monkeypatch.delenv("APDGICP_ALLOW_VARIANT_LIB", raising=False)
+        with pytest.raises(RuntimeError, match="APD_OCML_ATAN2F"):
+            reg.load_library(path)
+        monkeypatch.setenv("APDGICP_ALLOW_VARIANT_LIB", "1")
+        L = reg.load_library(path)
+        L.apdgicp_build_flags.restype = ctypes.c_char_p
+        assert L.apdgicp_build_flags().decode().split("| variant:")[1].strip() == "APD_OCML_ATAN2F"
+    finally:
+        os.remove(path)
+
+
+def test_the_loader_works_without_the_sources_beside_it(reg, monkeypatch):
+    """A deployment that ships libapdgicp_hip.so and the Python package only: the stamp check has nothing to compare with and is skipped
+    instead of failing with a bare FileNotFoundError."""
+    import importlib
+    build = importlib.import_module("riv-slam_amd.build")
+    monkeypatch.setattr(build, "CSRC", os.path.join(ROOT, "riv-slam_amd", "no_such_dir"))
+    monkeypatch.setattr(reg, "_lib", None)
+    assert reg.load_library() is not None
 
 
 def test_default_params_match_reference_defaults(reg):

@@ -1362,6 +1362,94 @@ def test_fp32_point_math_is_an_opt_in_inside_the_tolerance(reg, golden, scene):
         assert te <= T_TOL and re_ <= R_TOL
 
 
+def test_algebraic_apd_is_an_opt_in_inside_the_tolerance(reg, golden, scene):
+    """APDGICP_FLAG_ALGEBRAIC_APD (A:167-184 without atan2f / sincos): the search is untouched -- same correspondences
+    and fp32 distances at a pose; M / H / b / cost equal the CHECKER OF THE MODE (oracle flags bit 3: the same ratios in libm arithmetic) to
+    1e-10, and differ from the default's only by the fp32 rounding of the reference's three angles (< 1e-5 relative, > 1e-12: the flag does
+    reach the kernel); final poses against the ORACLE'S DEFAULT (the reference's arithmetic) inside the north-star tolerance -- asserted a
+    thousand times tighter; the flag is exclusive with the fp32 per-point mode."""
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    ALG = reg.FLAG_ALGEBRAIC_APD
+    for xf in (0, 2):
+        for kw in (LAUNCH, {}, dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0)):
+            a = reg.FastAPDGICP(reg.default_params(flags=xf, **kw))
+            b = reg.FastAPDGICP(reg.default_params(flags=xf | ALG, **kw))
+            o = R.RefAPDGICP(R.default_params(flags=xf, **kw))
+            oa = R.RefAPDGICP(R.default_params(flags=xf | 8, **kw))
+            for x in (a, b, o, oa):
+                x.setInputSource(src)
+                x.setInputTarget(tgt)
+            T0 = guess.astype(np.float64)
+            c1, H1, b1 = a.linearize(T0)
+            c2, H2, b2 = b.linearize(T0)
+            c3, H3, b3 = oa.linearize(T0)
+            assert np.array_equal(a.correspondences()[0], b.correspondences()[0])
+            assert np.array_equal(a.correspondences()[1].view(np.uint32), b.correspondences()[1].view(np.uint32))
+            assert rel_err(H2, H3) < HB_TOL and rel_err(b2, b3) < HB_TOL and abs(c2 - c3) < HB_TOL * c3
+            assert rel_err(b.mahalanobis(), oa.mahalanobis()) < HB_TOL
+            e2, e3 = b.compute_error(T0), oa.compute_error(T0)
+            assert abs(e2 - e3) < HB_TOL * e3
+            assert 1e-12 < rel_err(H2, H1) < 1e-5 and rel_err(b2, b1) < 1e-4 and abs(c2 - c1) < 1e-5 * c1
+            Ta, Tb, To, Toa = a.align(guess), b.align(guess), o.align(guess), oa.align(guess)
+            assert info_of(b) == [int(oa.converged), oa.nr_iterations, oa.n_linearize, oa.n_compute_error]
+            te, re_ = scene.pose_error(Toa, Tb)
+            assert te <= 1e-9 and re_ <= 1e-9, (te, re_)
+            te, re_ = scene.pose_error(To, Tb)
+            print("algebraic sensor model vs the oracle's default arithmetic:", te, re_, "counts", info_of(a), info_of(b))
+            assert te <= 1e-3 * T_TOL and re_ <= 5e-2 * R_TOL, (te, re_)   # (observed 3e-8 m / 1.3e-6 rad: a few ulps of the fp32 result matrix)
+    with pytest.raises(reg.ApdgicpError):
+        reg.FastAPDGICP(reg.default_params(flags=ALG | reg.FLAG_FP32_POINT_MATH))
+
+
+def test_algebraic_apd_on_axis_points_follow_the_atan2_conventions(reg):
+    """Points exactly on the sensor's axes, where the ratios are 0 / 0: the origin (the model vanishes), the z axis (azimuth = atan2(0, 0)
+    = 0), the x axis (1 / cos(AoA) clamped to what the reference's fp32 pi/2 gives) -- the mode's kernel equals its checker and stays finite."""
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-20, 20, size=(600, 3)).astype(np.float32)
+    tgt[:8] = [[0, 0, 0], [0, 0, 7], [0, 0, -7], [9, 0, 0], [-9, 0, 0], [0, 4, 0], [1e-30, 0, 3], [5, 1e-38, 0]]
+    src = tgt.copy()
+    kw = dict(max_correspondence_distance=1.0, flags=reg.FLAG_ALGEBRAIC_APD)
+    g = reg.FastAPDGICP(reg.default_params(**kw))
+    o = R.RefAPDGICP(R.default_params(**dict(kw, flags=8)))
+    for x in (g, o):
+        x.setInputSource(src)
+        x.setInputTarget(tgt)
+    c1, H1, b1 = g.linearize(np.eye(4))
+    c2, H2, b2 = o.linearize(np.eye(4))
+    assert np.array_equal(g.correspondences()[0][:8], np.arange(8))
+    assert np.isfinite(H1).all() and np.isfinite(g.mahalanobis()).all()
+    assert rel_err(g.mahalanobis()[:8], o.mahalanobis()[:8]) < 1e-9
+    assert rel_err(H1, H2) < 1e-9
+
+
+def test_algebraic_apd_sweep_and_bench_pairs(reg, scene):
+    """The mode over seeded small pairs (odometry and loop, LM with the launch parameters and GN-20) and four 8k bench pairs against the
+    ORACLE'S DEFAULT arithmetic: every pose inside 1e-3 m / 1e-4 rad (observed ~1e-7 m); prints the share of LM pairs whose iteration
+    count changes.  (tests/measure/algebraic_apd.py runs the 300-pair sweep and the 32 bench pairs: profiles/r06_algebraic_apd.json.)"""
+    worst_t = worst_r = 0.0
+    changed = total = 0
+    GN = dict(optimizer=1, max_iterations=20, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0)
+    cases = [(kind, 1500 + 97 * i, 1400 + 131 * i, scene.pair_seed(7, i), kw) for i, (kind, kw) in enumerate([("odometry", LAUNCH), ("loop", LAUNCH), ("odometry", GN)] * 8)]
+    cases += [("odometry", 8192, 8192, scene.pair_seed(2, p), GN) for p in range(2)] + [("loop", 8192, 8192, scene.pair_seed(4, p), LAUNCH) for p in range(2)]
+    for kind, n, m, seed, kw in cases:
+        src, tgt, _, guess = scene.make_pair(n, m, seed, kind)
+        if kind == "loop":
+            guess = np.eye(4, dtype=np.float32)
+        g = reg.FastAPDGICP(reg.default_params(flags=reg.FLAG_ALGEBRAIC_APD, **kw))
+        o = R.RefAPDGICP(R.default_params(**kw))
+        for x in (g, o):
+            x.setInputSource(src)
+            x.setInputTarget(tgt)
+        T, To = g.align(guess), o.align(guess)
+        te, re_ = scene.pose_error(To, T)
+        worst_t, worst_r = max(worst_t, te), max(worst_r, re_)
+        assert te <= T_TOL and re_ <= R_TOL, (kind, n, te, re_)
+        if kw is LAUNCH:
+            total += 1
+            changed += int(g.result.n_linearize != o.n_linearize)
+    print(f"algebraic sensor model, {len(cases)} pairs vs the oracle's default: max {worst_t:.3e} m / {worst_r:.3e} rad; LM iteration count changed in {changed} of {total}")
+
+
 def test_so3_exp_small_angle_branch_in_isolation(reg, golden, scene):
     """a15: so3_exp's Taylor branch (theta^2 < 1e-10, so3.hpp:63-68) -- a Gauss-Newton step of a few microradians: the source is the
     target moved by a rotation of 3e-6 rad and a micrometre, so the FIRST step's rotation vector is ~3e-6 (theta^2 ~ 1e-11: the

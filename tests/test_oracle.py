@@ -97,6 +97,26 @@ def test_kdtree_against_the_reference_trees_own_nanoflann(golden):
                 assert uniq.mean() > 0.98, (name, k, float(uniq.mean()))
 
 
+def test_algebraic_sensor_model_checker(golden):
+    """flags bit 3 of both restatements is the checker of the product's opt-in APDGICP_FLAG_ALGEBRAIC_APD (NOT the reference's arithmetic):
+    the two writings agree with each other, and the mode differs from the reference's arithmetic only by the fp32 rounding of its angles."""
+    src, tgt, T0 = golden["lin_source"], golden["lin_target"], golden["lin_guess"].astype(np.float64)
+    r0, r8 = R.RefAPDGICP(R.default_params(**LAUNCH)), R.RefAPDGICP(R.default_params(flags=8, **LAUNCH))
+    n8 = O.FastAPDGICP(O.Params(flags=8, **LAUNCH))
+    for x in (r0, r8, n8):
+        x.setInputSource(src)
+        x.setInputTarget(tgt)
+    n8.source_covs, n8.target_covs = golden["lin_source_cov"], golden["lin_target_cov"]   # (the numpy writing's covariances take minutes)
+    c0, H0, b0 = r0.linearize(T0)
+    c8, H8, b8 = r8.linearize(T0)
+    cn, Hn, bn = n8.linearize(T0)
+    assert np.array_equal(r0.correspondences()[0], r8.correspondences()[0])
+    assert rel_err(H8, Hn) < 1e-12 and rel_err(b8, bn) < 1e-11 and abs(c8 - cn) < 1e-12 * cn
+    assert 1e-12 < rel_err(H8, H0) < 1e-5 and abs(c8 - c0) < 1e-5 * c0
+    Ta, Tb = r0.align(golden["lin_guess"]), r8.align(golden["lin_guess"])
+    assert np.abs(Ta - Tb).max() < 1e-6
+
+
 # fp32 summation order of T * p (A:149): pairwise (Eigen >= 3.3, default) | linear chain (Eigen 3.2, flags bit 1)
 XF = (pytest.param("", 0, id="xf_pairwise"), pytest.param("_xflin", 2, id="xf_linear"))
 

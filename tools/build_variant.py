@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 b = importlib.import_module("riv-slam_amd.build")
 name, extra = sys.argv[1], sys.argv[2:]
 out = os.path.join(b.HERE, f"_{name}.bin")
-cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *b.FLAGS, f'-DAPD_SOURCE_STAMP="apd-source-stamp:{b.source_stamp()}"', *extra, "-o", out,
-       *[os.path.join(b.CSRC, s) for s in b.SOURCES]]
-subprocess.check_call(cmd)
+# (the stamp compiled in covers the extra flags: a variant never carries the product's stamp, and the library lists its experiment defines
+# itself -- apdgicp_build_flags(); the loader refuses such a library unless APDGICP_ALLOW_VARIANT_LIB=1)
+subprocess.check_call(b.compile_command(out, extra))
 print(out)

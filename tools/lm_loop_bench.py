@@ -66,6 +66,8 @@ for F in [int(x) for x in os.environ.get("F_LIST", "1,2,3,4").split(",")]:
         its = [int(x) for x in res["n_linearize"]]
         out["n_linearize"] = {"min": min(its), "median": float(np.median(its)), "max": max(its), "sum": sum(its)}
         out["n_compute_error_sum"] = int(res["n_compute_error"].sum())
+        import hashlib
+        out["records_sha"] = hashlib.sha256(want).hexdigest()[:12]   # (equal across pool configurations: lists, cloud streams, lanes)
     assert res.tobytes() == want
     out[f"pool_{F}_in_flight_ms_per_batch"] = round(ms, 3)
 if os.environ.get("NO_POLLED", "0") != "1":
