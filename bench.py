@@ -132,6 +132,22 @@ def load_pmc(path=None, stamp=None):
     return pmc, None
 
 
+def scaling_efficiency(value, world, args, lm):
+    """value / (world x the committed one-GPU value of the same workload): profiles/r06_bench.json for the default line, profiles/r06_bench_lm_loop.json for
+    --kind loop --optimizer lm.  None when the workload differs from the committed one (pairs per GPU, points, host clouds, shared GPU)."""
+    if args.ranks_share_gpu or args.host_clouds or args.points != N_PTS or args.pairs_per_gpu != 32:
+        return {"value": None, "reason": "not a scaling point: ranks share one GPU, host clouds, or another workload than the committed one-GPU line"}
+    name = "r06_bench_lm_loop.json" if lm and args.kind == "loop" else ("r06_bench.json" if not lm and args.kind == "odometry" else None)
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            one = json.loads(fh.read().strip().splitlines()[-1])
+        if one.get("n_gpus") != 1:
+            return None
+        return {"value": round(value / (world * one["value"]), 4), "one_gpu_value": one["value"], "one_gpu_source": "profiles/" + name}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def percentiles(xs):
     import numpy as np
     a = np.asarray(xs, dtype=np.float64)
@@ -292,6 +308,8 @@ def main():
     # once made every rank wait for the slowest rank's same step, every step; this way ranks may drift by a few steps.
     gather_done = {}   # slot -> event behind its last all-gather
     lat = []           # submit -> collect of every step of the timed region, seconds
+    gather_ev = []     # (event in front, event behind) of the all-gathers of the timed region (RCCL: on torch's current stream)
+    gather_host = []   # gloo: host seconds inside the gather call (the collective is complete when it returns)
 
     def collect_step(h, ticket, t_submit):
         bh = slots[h][0]
@@ -303,7 +321,17 @@ def main():
         else:
             local = bh.align_collect(ticket, device=True)    # zero-copy view of that step's records on the device
         lat.append(time.perf_counter() - t_submit)
+        timed_gather = use_dist and not gloo and len(gather_ev) < 256
+        if timed_gather:
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(torch.cuda.current_stream())
+        t_g = time.perf_counter()
         out = aligner.gather(local, total_pairs, wait=False)
+        if use_dist and gloo:
+            gather_host.append(time.perf_counter() - t_g)
+        if timed_gather:
+            g1.record(torch.cuda.current_stream())
+            gather_ev.append((g0, g1))
         if use_dist and not gloo:
             if ev is None:
                 ev = gather_done[h] = torch.cuda.Event()
@@ -344,7 +372,10 @@ def main():
     ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(H + 1)] for _ in range(R)]
     nn_acc[:] = [0.0, 0, 0]
     lat.clear()
+    gather_ev.clear()
+    gather_host.clear()
     gathered = None
+    pool0 = batch.pool_counters() if lm else (0, 0, 0)
     for r in range(R):
         sync_all()
         ev0[r].record(hstreams[0])           # the GPU is idle: this timestamp is the start of the region on the device clock
@@ -356,11 +387,24 @@ def main():
         sync_all()
         host_s.append(time.perf_counter() - t0)
         event_ms.append(max(ev0[r].elapsed_time(e) for e in ev1[r][:len(hstreams) + 1]))
+    pool1 = batch.pool_counters() if lm else (0, 0, 0)
+    slot_ticks_per_step = (pool1[2] - pool0[2]) / float(R * K) if lm else None
     nn_ms, nn_launches, nn_pairs = nn_acc
     host_t = torch.tensor(host_s, dtype=torch.float64, device="cpu" if gloo else "cuda")
+    per_rank = None
     if use_dist:
+        # every rank's own median time per step (before the MAX): the imbalance between ranks, for the first real SCALE run
+        mine = torch.tensor([float(np.median(host_s)) / K * 1e3], dtype=torch.float64, device=host_t.device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(float(v.item()), 4) for v in allr]
         dist.all_reduce(host_t, op=dist.ReduceOp.MAX)     # per repetition: the slowest rank
     host_s = [float(v) for v in host_t.cpu()]
+    if gather_ev:
+        torch.cuda.synchronize()
+        gather_ms = [a.elapsed_time(b) for a, b in gather_ev]
+    else:
+        gather_ms = [t * 1e3 for t in gather_host]
     elapsed = float(np.median(host_s))
     ms_per_step = elapsed / K * 1e3
     value = total_pairs * K / elapsed
@@ -406,6 +450,28 @@ def main():
         # PMC numbers come from a separate committed profiling run (rocprofv3 --pmc passes cannot run inside this process):
         # reported only when that run had this launch shape, and tagged with where they come from
         step_issue = None
+        if lm and pmc and issue and slot_ticks_per_step and P == 32 and n == N_PTS:
+            # the pooled LM batch against the vector issue slots: per listed pair slot the tick kernels' SQ_ACTIVE_INST_VALU (pmc_lm_loop.json) x the
+            # slots the pool's tick launches covered per batch (apdgicp_batch_pool_counters, THIS run) + the batch's cloud kernels -- pack, sort,
+            # merge, boxes, covariance k-NN, regularisation over 64 clouds of 8192 points: the launch shapes of pmc_nn_latest.json's step_kernels
+            cloud_pmc, _why = load_pmc(None)
+            tick_busy = sum(cs.get("SQ_ACTIVE_INST_VALU", 0.0) for cs in pmc["per_slot"].values()) * slot_ticks_per_step
+            tick_insts = sum(cs.get("SQ_INSTS_VALU", 0.0) for cs in pmc["per_slot"].values()) * slot_ticks_per_step
+            cloud_busy = cloud_insts = 0.0
+            for name, cs in ((cloud_pmc or {}).get("step_kernels") or {}).items():
+                if "k_nn_" in name or "k_linearize" in name:
+                    continue
+                cloud_busy += cs.get("SQ_ACTIVE_INST_VALU", 0.0)
+                cloud_insts += cs.get("SQ_INSTS_VALU", 0.0)
+            if cloud_busy > 0:
+                busy = (tick_busy + cloud_busy) * 4.0 / (SIMDS * GFX_CLOCK_HZ * ms_per_step * 1e-3)
+                step_issue = {"bound": "valu-issue", "valu_busy": round(busy, 3), "slot_ticks_per_batch": round(slot_ticks_per_step, 1),
+                              "valu_instructions_per_batch": {"ticks": tick_insts, "clouds": cloud_insts},
+                              "busy_quad_cycles_per_batch": {"ticks": tick_busy, "clouds": cloud_busy},
+                              "sources": [pmc.get("source"), (cloud_pmc or {}).get("source", "profiles/pmc_nn_latest.json")],
+                              "valu_busy_note": "sum of SQ_ACTIVE_INST_VALU (quad-cycles) over a batch's launches x 4 / (1024 SIMDs x 2.4 GHz x ms per batch): tick kernels per "
+                                                "listed pair slot (committed profile of this workload) x the slots this run's tick launches covered, plus the cloud kernels "
+                                                "of 64 clouds (committed profile of the same launch shapes, odometry clouds: the covariance work does not depend on the pose)"}
         if not lm and pmc and pmc.get("points") == n and pmc.get("pairs_per_launch") == round(pairs_per_launch) and pmc.get("nn_mode", "pruned") == nn_mode \
                 and pmc.get("kind", "odometry") == args.kind and pmc.get("kernel", "").replace(" ", "") == nn_kernel.replace(" ", ""):
             traffic = pmc.get("hbm_bytes_per_launch")
@@ -474,16 +540,26 @@ def main():
                        "registrations_per_s": {"p10": round(total_pairs * K / float(np.percentile(host_s, 90)), 1),
                                                "p90": round(total_pairs * K / float(np.percentile(host_s, 10)), 1)}},
             "ms_per_gn_iter_batched": round(ms_per_step / GN_ITERS, 4) if not lm else None,
+            "multi_rank": ({"ranks": world, "ms_per_step_per_rank": per_rank, "ms_per_step_min": min(per_rank), "ms_per_step_max": max(per_rank),
+                            "imbalance": round(max(per_rank) / min(per_rank) - 1.0, 4),
+                            "gather_ms": (percentiles(gather_ms) if gather_ms else None),
+                            "gather_note": ("one all_gather_into_tensor of the 96-byte records per step (RCCL): HIP events around the collective on the stream that carries it"
+                                            if not gloo else "gloo self-test: host time inside the gather call (CPU tensors)"),
+                            "weak_scaling_efficiency": scaling_efficiency(value, world, args, lm),
+                            "note": "value = all ranks' pairs / the slowest rank's time (MAX over ranks per repetition); per-rank figures are each rank's own median"}
+                           if use_dist else None),
             "roofline": {"kernel": nn_kernel + (" (exact fp32 nearest neighbour: Hilbert-sorted clouds, bounding-box pruning, LDS-staged target "
                                                 "groups, neighbours kept while provably unchanged)" if nn_mode != "brute" else
                                                 " (brute-force fp32 nearest neighbour, LDS-tiled)"),
-                         "bound": "hbm", "achieved": round(nn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "bound": "hbm", "bound_note": "the roof the contract asks the line to be priced against; the roof that BINDS this kernel and the step is vector "
+                                                       "instruction issue -- binding_roof, roofline_issue, roofline_issue_step.valu_busy",
+                         "achieved": round(nn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(nn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_over_algorithmic": (round(traffic / bytes_per_launch, 3) if traffic and bytes_per_launch else None),
                          "binding_roof": "instruction issue (vector + scalar), not HBM: see roofline_issue; the HBM fraction is the north star's extra",
                          "kernel_ms_per_step": round(avg_nn_ms * (ticks if not lm else n_lin), 4),
-                         "kernel_time_check": "kernel_ms_per_step (average launch x launches per step) <= timing.step_latency_ms: the launches of one step overlap with "
-                                              "those of the other steps in flight, so it may exceed ms_per_step",
+                         "concurrency_note": "kernel_ms_per_step (average launch x launches per step) is NOT additive against ms_per_step: the launches of one step overlap "
+                                             "with those of the other steps in flight (it is bounded by timing.step_latency_ms, not by ms_per_step); a statement, not a check",
                          # non-overlapped accounting: H steps are in flight, each on a stream of its own, and a step stays H x ms_per_step on
                          # its stream; the search kernel's share of ALL stream time = sum of its launch times / (wall x busy streams) <= 1
                          "concurrency": {"steps_in_flight": H if not lm else None, "busy_streams": (H if not lm else 2),
@@ -502,6 +578,7 @@ def main():
             "roofline_issue": issue,
             "roofline_issue_step": step_issue,
             "library_source_stamp": importlib.import_module("riv-slam_amd.registration").source_stamp(),
+            "library_build_flags": importlib.import_module("riv-slam_amd.registration").build_flags(),
             "pmc_profile": ({"source_stamp": pmc.get("source_stamp"), "file": "profiles/pmc_lm_loop.json" if lm else "profiles/pmc_nn_latest.json"} if pmc else {"rejected": pmc_rejected}),
             "roofline_step_hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_registration": b_reg,

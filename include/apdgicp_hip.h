@@ -348,7 +348,15 @@ int apdgicp_batch_last_nn_kernel(apdgicp_batch* b, char* name, int capacity);
  * resets them.  [0..3] nearest neighbour: groups scanned, chunks tested, chunks scanned, waves;
  * [4..9] covariance k-NN: groups loaded, (NN: batches of 64 group boxes visited), (NN: points that kept their neighbour without a search), waves sampled, list tightenings, (query, group) steps;
  * [10..15] sampled phase timers (s_memtime ticks) of whichever of the two kernels ran last (tools/prune_stats.py, tools/knn_time.py) */
+/* Measurement: what the pair pool of a Levenberg-Marquardt batch handle has enqueued since it was created -- chunks (polls), ticks, and
+ * slot-ticks = the sum over the tick launches of the pair slots they covered (grid y; slots behind the end of a list execute nothing).
+ * bench.py turns per-slot counter profiles into a per-batch figure with it (the LM line's valu_busy).  Zeros for a handle without a pool. */
+int apdgicp_batch_pool_counters(apdgicp_batch* b, int64_t* chunks, int64_t* ticks, int64_t* slot_ticks);
 int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]);
+/* APDGICP_STATS=2 and a library built with -DAPD_BLOCK_TIMELINE (a diagnostics variant: tools/build_variant.py) only: {start, end} (100 MHz wall-clock ticks) and the index of every block of the LAST one-pair dense search launch
+ * (k_nn_pruned), three words per block, up to 8192 blocks; reading resets.  For tools/c5_blocks.py: where the time of a 100k x 500k
+ * iteration goes -- the blocks' own durations or the order they are dealt in. */
+int apdgicp_batch_debug_block_timeline(apdgicp_batch* b, unsigned long long* out, int64_t capacity_blocks, int64_t* n_blocks);
 
 /* ------------------------------------------------------------------ scan-to-submap target assembly
  * The step in front of registration_s2m->setInputTarget in scan-to-map mode

@@ -263,7 +263,8 @@ class ShardedBatchAlignerHip {
     return collect(t, results, root);
   }
   const std::string& last_error_text() const { return error_text_; }
-  /// device pointer of rank r's gathered buffer of batch `ticket` (world * per records; wait for it with collect first)
+  /// device pointer of rank r's gathered buffer of batch `ticket` (world * per records).  Valid to read once collect(ticket, ..., root = r) has
+  /// returned: collect waits for the gather of ITS root rank; the other ranks' copies may still be on their way
   const void* gathered_on(int r, uint64_t ticket) const { return ranks_[(size_t)r]->slots[(size_t)(ticket % (uint64_t)slots_)].recv; }
 
  private:

@@ -27,6 +27,7 @@
 
 #include "../../include/apdgicp_hip.h"
 #include "apd_kernels.hpp"
+#include "apd_hostpack.hpp"
 
 namespace apd {
 
@@ -231,6 +232,8 @@ class Engine {
   static constexpr float nn_skin_rel = 0.25f, nn_skin_abs = 0.02f;
   float nn_cap = std::numeric_limits<float>::infinity();
   bool knn_pruned = true;  // same for the covariance k-NN (APDGICP_KNN_MODE=brute disables)
+  static constexpr int kStatsBlocks = 8192;
+  int stats_blocks = 0;    // APDGICP_STATS=2: Work::stats_blocks
   bool post_tick = false;  // this launch of k_error also writes the poll record (one-pair LM handles)
   CachedTable d_post;
   bool init_tick = false;
@@ -320,8 +323,9 @@ class Engine {
     APD_TRY(d_probe.ensure(64 * sizeof(double)));
     APD_TRY(d_T.ensure(16 * sizeof(double)));
     if (env_int("APDGICP_STATS", 0)) {
-      APD_TRY(d_stats.ensure(16 * sizeof(unsigned long long)));
-      APD_HIP(hipMemsetAsync(d_stats.p, 0, 16 * sizeof(unsigned long long), stream));
+      stats_blocks = env_int("APDGICP_STATS", 0) >= 2 ? kStatsBlocks : 0;  // 2: + the block timeline of the last k_nn_pruned launch
+      APD_TRY(d_stats.ensure((16 + (size_t)3 * stats_blocks) * sizeof(unsigned long long)));
+      APD_HIP(hipMemsetAsync(d_stats.p, 0, (16 + (size_t)3 * stats_blocks) * sizeof(unsigned long long), stream));
     }
     const char* m = getenv("APDGICP_NN_MODE");
     nn_pruned = !(m && std::string(m) == "brute");
@@ -458,117 +462,6 @@ class Engine {
     return 0;
   }
 
-  // A scan-sized host cloud into its pinned buffer: {x, y, z, 1} per point, the bounding box behind the points.  Touches nothing but
-  // its arguments: apdgicp_batch_set_clouds runs it for many clouds at once on the host pool below.
-  struct HostPackTask {
-    float4* dst;
-    const char* raw;
-    int64_t n, stride_bytes;
-  };
-  static void pack_staged_host(float4* dst, const char* raw, int64_t n, int64_t stride_bytes) {
-    const float inf = std::numeric_limits<float>::infinity();
-    // four independent running boxes (a single one is a chain of dependent min/max, twice the time of the packing itself);
-    // `v < lo ? v : lo` leaves a NaN coordinate out, like the device's fminf
-    float lo[4][3], hi[4][3];
-    for (int u = 0; u < 4; u++)
-      for (int a = 0; a < 3; a++) lo[u][a] = inf, hi[u][a] = -inf;
-    auto put = [&](int64_t q, int u) {
-      const float* sp = (const float*)(raw + q * stride_bytes);
-      const float v[3] = {sp[0], sp[1], sp[2]};
-      dst[q] = make_float4(v[0], v[1], v[2], 1.0f);
-      for (int a = 0; a < 3; a++) lo[u][a] = v[a] < lo[u][a] ? v[a] : lo[u][a], hi[u][a] = v[a] > hi[u][a] ? v[a] : hi[u][a];
-    };
-    int64_t q = 0;
-    {  // one 16-byte load, blend, store: the fourth float read with a point is its own padding or the next point's x -- inside the caller's buffer
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      v4f vlo[2] = {v4f(inf), v4f(inf)}, vhi[2] = {v4f(-inf), v4f(-inf)};
-      for (; q + 2 <= n - 1; q += 2)  // (not the last point: its fourth float may lie outside the caller's buffer)
-        for (int u = 0; u < 2; u++) {
-          v4f v;
-          memcpy(&v, raw + (q + u) * stride_bytes, 16);
-          vlo[u] = v < vlo[u] ? v : vlo[u], vhi[u] = v > vhi[u] ? v : vhi[u];
-          v.w = 1.0f;
-          memcpy(&dst[q + u], &v, 16);
-        }
-      for (int u = 0; u < 2; u++)
-        for (int a = 0; a < 3; a++) lo[u][a] = vlo[u][a], hi[u][a] = vhi[u][a];
-    }
-    for (; q + 4 <= n; q += 4) put(q, 0), put(q + 1, 1), put(q + 2, 2), put(q + 3, 3);
-    for (; q < n; q++) put(q, 0);
-    for (int u = 1; u < 4; u++)
-      for (int a = 0; a < 3; a++) lo[0][a] = std::min(lo[0][a], lo[u][a]), hi[0][a] = std::max(hi[0][a], hi[u][a]);
-    dst[n] = make_float4(lo[0][0], lo[0][1], lo[0][2], 0.f), dst[n + 1] = make_float4(hi[0][0], hi[0][1], hi[0][2], 0.f);
-  }
-
-  // A few persistent host threads for set_clouds_host (64 clouds of 8192 points: 0.25 ms of packing on one core, a third of a
-  // step).  Created on first use, parked on a condition variable in between.
-  struct HostPool {
-    std::vector<std::thread> th;
-    std::mutex m;
-    std::condition_variable cv, cv_done;
-    const std::function<void(int)>* fn = nullptr;
-    int n = 0, busy = 0;
-    std::atomic<int> next{0};
-    uint64_t gen = 0;
-    bool stop = false;
-    void start(int k) {
-      for (int t = 0; t < k; t++)
-        th.emplace_back([this]() {
-          uint64_t seen = 0;
-          for (;;) {
-            const std::function<void(int)>* f;
-            int cnt;
-            {
-              std::unique_lock<std::mutex> lk(m);
-              cv.wait(lk, [&]() { return stop || gen != seen; });
-              if (stop) return;
-              seen = gen, f = fn, cnt = n;
-            }
-            for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < cnt;) (*f)(i);
-            std::lock_guard<std::mutex> lk(m);
-            if (--busy == 0) cv_done.notify_one();
-          }
-        });
-    }
-    std::mutex run_mu;  // one run at a time (the pool is shared by every engine of the process)
-    void run(int count, const std::function<void(int)>& f) {  // f(0 .. count - 1), the caller takes part; returns when all are done
-      std::lock_guard<std::mutex> run_lk(run_mu);
-      {
-        std::lock_guard<std::mutex> lk(m);
-        fn = &f, n = count, busy = (int)th.size(), next.store(0, std::memory_order_relaxed), gen++;
-      }
-      cv.notify_all();
-      for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count;) f(i);
-      std::unique_lock<std::mutex> lk(m);
-      cv_done.wait(lk, [&]() { return busy == 0; });
-    }
-    ~HostPool() {
-      {
-        std::lock_guard<std::mutex> lk(m);
-        stop = true;
-      }
-      cv.notify_all();
-      for (auto& t : th) t.join();
-    }
-  };
-  // ONE pool per process, created by the first batch of host clouds that wants it (APDGICP_HOST_THREADS is read then: a
-  // per-process setting) and shared by every engine: four bench handles or eight ShardedBatchAlignerHip handles per device each
-  // with three parked threads of their own were 12 - 24 idle threads.  run() is serialised by the pool's own mutex.
-  static HostPool* shared_host_pool(int* threads_out) {
-    static std::mutex mu;
-    static std::unique_ptr<HostPool> pool;
-    static int want = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!want) {
-      const char* e = getenv("APDGICP_HOST_THREADS");  // threads packing host clouds, the caller included (1: no pool)
-      const int hc = (int)std::thread::hardware_concurrency();
-      want = std::max(1, e ? atoi(e) : std::min(4, hc > 1 ? hc / 2 : 1));
-      if (want > 1) pool.reset(new HostPool()), pool->start(want - 1);
-    }
-    *threads_out = want;
-    return pool.get();
-  }
-
   struct HostStage {
     char* p = nullptr;
     size_t cap = 0;
@@ -620,7 +513,7 @@ class Engine {
         APD_HIP(hipHostGetDevicePointer((void**)&c.stage_dev, c.stage_p, 0));
         c.stage_cap = cap;
       }
-      pack_staged_host((float4*)c.stage_p, raw, n, stride_bytes);
+      pack_staged_host((HostF4*)c.stage_p, raw, n, stride_bytes);
       c.staged = true;
     } else if (!on_device) {
       // Host clouds (the odometry nodelet hands over pcl::PointXYZI, 32 bytes a point): the three coordinates are packed into
@@ -679,7 +572,10 @@ class Engine {
       return 0;
     }
     APD_HIP(hipSetDevice(device));
-    const size_t need = ((size_t)pts + 2 * (size_t)count) * 16;  // (pack_staged_host leaves a bounding box behind every cloud: not used here)
+    // 12 bytes a point, every cloud 16-byte aligned in the region
+    std::vector<size_t> offs(count);
+    size_t need = 0;
+    for (int q = 0; q < count; q++) offs[q] = need, need += ((size_t)ns[q] * 12 + 15) & ~(size_t)15;
     if (!bulk_ev) APD_HIP(hipEventCreateWithFlags(&bulk_ev, hipEventDisableTiming));
     else APD_HIP(hipEventSynchronize(bulk_ev));  // the previous copy out of the pinned region (long done: a step ago on this handle)
     if (need > bulk_cap) {
@@ -690,25 +586,17 @@ class Engine {
     }
     if (need > bulk_dev.cap) APD_HIP(hipStreamSynchronize(cstream));  // (the pack launch of the previous call may still read it)
     APD_TRY(bulk_dev.ensure(need));
-    std::vector<HostPackTask> tasks(count);
     std::vector<const float*> dptr(count);
-    size_t off = 0;
-    for (int q = 0; q < count; q++) {
-      tasks[q] = HostPackTask{(float4*)(bulk_host + off), (const char*)xyz[q], ns[q], stride_bytes};
-      dptr[q] = (const float*)((char*)bulk_dev.p + off);
-      off += ((size_t)ns[q] + 2) * 16;
-    }
+    for (int q = 0; q < count; q++) dptr[q] = (const float*)((char*)bulk_dev.p + offs[q]);
     int want = 1;
     HostPool* hp = shared_host_pool(&want);
-    if (hp) {
-      const std::function<void(int)> f = [&](int i) { pack_staged_host(tasks[i].dst, tasks[i].raw, tasks[i].n, tasks[i].stride_bytes); };
-      hp->run(count, f);
-    } else {
-      for (const HostPackTask& t : tasks) pack_staged_host(t.dst, t.raw, t.n, t.stride_bytes);
-    }
+    const std::function<void(int)> f = [&](int i) { compact_xyz_host((float*)(bulk_host + offs[i]), (const char*)xyz[i], ns[i], stride_bytes); };
+    if (hp) hp->run(count, f);
+    else
+      for (int q = 0; q < count; q++) f(q);
     APD_HIP(hipMemcpyAsync(bulk_dev.p, bulk_host, need, hipMemcpyHostToDevice, cstream));
     APD_HIP(hipEventRecord(bulk_ev, cstream));
-    return set_clouds_device(first, count, dptr.data(), ns, 16);
+    return set_clouds_device(first, count, dptr.data(), ns, 12);
   }
 
   // many device-resident clouds at once: one pack launch instead of one per cloud
@@ -1141,6 +1029,7 @@ class Engine {
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();
     work.stats = d_stats.as<unsigned long long>();
+    work.stats_blocks = stats_blocks;
     APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
     if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
@@ -1699,14 +1588,34 @@ class Engine {
     if (pool.on) return 0;
     APD_HIP(hipStreamSynchronize(stream));  // whatever the clouds went through on the main stream so far
     if (!pool.cstream) {
-      APD_HIP(hipStreamCreateWithFlags(&pool.cstream, hipStreamNonBlocking));
+      // experiments (round 6, docs/experiments.md): the cloud stream at the lowest stream priority and / or confined to a share of the CUs,
+      // so that the tick launches -- the chain the pool's throughput hangs on (their streams are 96 % busy, the cloud stream 77 %) -- get
+      // the GPU first.  APDGICP_POOL_CLOUD_PRIO=1, APDGICP_POOL_CLOUD_CUS=<CUs of 256>; default: neither
+      auto make_cloud_stream = [&](hipStream_t* out) -> int {
+        const int cus = std::max(0, std::min(256, env_int("APDGICP_POOL_CLOUD_CUS", 0)));
+        if (cus > 0) {
+          uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int b = 0; b < cus; b++) mask[b >> 5] |= 1u << (b & 31);
+          APD_HIP(hipExtStreamCreateWithCUMask(out, 8, mask));
+          return 0;
+        }
+        if (env_int("APDGICP_POOL_CLOUD_PRIO", 0)) {
+          int least = 0, greatest = 0;
+          APD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          APD_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, least));
+          return 0;
+        }
+        APD_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+        return 0;
+      };
+      APD_TRY(make_cloud_stream(&pool.cstream));
       for (Pool::List& li : pool.L)
         for (int i = 0; i < kPoolRing; i++) APD_HIP(hipEventCreateWithFlags(&li.ev[i], hipEventDisableTiming));
       // measured (round 6, docs/experiments.md): lists 2 / 3 / 4 and cloud streams 1 / 2 on the C4 shard
       pool.nlists = std::max(1, std::min(Pool::kMaxLists, env_int("APDGICP_POOL_LISTS", 2)));
       pool.nclanes = std::max(1, std::min(2, env_int("APDGICP_POOL_CLOUD_STREAMS", 1)));
       if (pool.nclanes > 1) {
-        APD_HIP(hipStreamCreateWithFlags(&pool.cstream2, hipStreamNonBlocking));
+        APD_TRY(make_cloud_stream(&pool.cstream2));
         APD_HIP(hipEventCreateWithFlags(&pool.ev_cross, hipEventDisableTiming));
       }
       APD_TRY(ensure_group_streams(pool.nlists + 1));  // gstreams[l - 1]: list l; gstreams[nlists - 1]: the slice stream of a list that ticks alone

@@ -161,6 +161,8 @@ struct Work {
                                // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
+  int stats_blocks;            // APDGICP_STATS=2: behind the 16 counters, room for the timeline of this many blocks of the LAST k_nn_pruned launch:
+                               // {start, end} in 100 MHz wall-clock ticks and the block's index, three words per block (tools/c5_blocks.py)
   int coop_search;             // k_nn_compact: a block with at most 64 points left searches them with all of its waves
   int sparse_max;              // k_nn_compact: ... and with at most this many, one point at a time with a whole wave (0: never)
   int xf_linear;               // fp32 summation order of T * p (A:149), see xf_row: 0 = pairwise (Eigen >= 3.3), 1 = linear chain (Eigen 3.2)
@@ -1235,11 +1237,27 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
   unsigned long long smask = nsuper - sb0 >= 64 ? ~0ull : (1ull << (nsuper - sb0)) - 1ull;
   if (use_super && rad0 < inf) {
-    const Box sbx = G(tgt.gbox)[ngroups + min(sb0 + lane, nsuper - 1)];
+    const Box sbx = G(tgt.gbox)[ngroups + min(sb0 + lane, nsuper - 1)];  // lane b: super box sb0 + b
     smask &= __ballot(lb_box_box(wbox, sbx) <= rad0);
+    // A SCATTERED wave (round 6): 64 consecutive points of the curve that lie far apart -- a jump of the curve, outliers at the edge of a
+    // sparse scan -- have a box that nearly every super box of a dense map touches, and one large radius among them inflates all of it:
+    // in the 100k x 500k registration ONE such block tested 2 100 group boxes where its points need nine groups, three times the
+    // duration of the median block and as long as the whole launch.  When more than eight super boxes pass the wave's box, every point
+    // is looked at on its own (lane = super box, the points broadcast in turn, each with ITS radius): what no point needs is left out.
+    // Uniform over the block's waves like the test above: points and start radii are the same in all of them.
+    if (!GIVEN && __popcll(smask) > 8) {  // (not in the throughput kernel of scan-sized clouds: its registers are spoken for)
+      unsigned long long fine = 0;
+#pragma unroll 1
+      for (int l = 0; l < 64; l++) {
+#pragma unroll
+        for (int s = 0; s < S; s++) fine |= __ballot(lb_point_box(sbx, readlane_f(px[s], l), readlane_f(py[s], l), readlane_f(pz[s], l)) <= readlane_f(bestR[s], l));
+      }
+      smask &= fine;
+    }
   }
   while (smask) {
-    const int gb0 = (sb0 + __builtin_ctzll(smask)) * GB_BATCH;
+    const int sbi = __builtin_ctzll(smask);
+    const int gb0 = (sb0 + sbi) * GB_BATCH;
     smask &= smask - 1;
     const int nbb = min(GB_BATCH, ngroups - gb0);
     n_batches++;
@@ -1283,6 +1301,24 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
       rad = wave_max_uniform(rad);
       unsigned long long pre = nb < 64 ? (1ull << nb) - 1ull : ~0ull;
       if (rad < inf) pre &= __ballot(lb_box_box(wbox, lds_box(boxes, min(lane, nb - 1))) <= rad);
+      if (!GIVEN && use_super && S == 1 && __popcll(pre) > 16) {
+        // ... and the same one level down: most of a batch's groups pass the wave's box although only a few of the wave's points reach into the
+        // batch's super box at all -- those points are tested against the 64 group boxes (lane = group) instead of every group against all points
+        // (the batch's super box through a uniform load: kept in a register per lane from the test above it cost the kernel a wave per SIMD)
+        const Box sb_u = G(tgt.gbox)[ngroups + sb0 + sbi];
+        unsigned long long pm = __ballot(lb_point_box(sb_u, px[0], py[0], pz[0]) <= bestR[0]);
+        if (__popcll(pm) <= 16) {
+          const Box mine = lds_box(boxes, min(lane, nb - 1));
+          unsigned long long need = 0;
+#pragma unroll 1
+          while (pm) {
+            const int l = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            need |= __ballot(lb_point_box(mine, readlane_f(px[0], l), readlane_f(py[0], l), readlane_f(pz[0], l)) <= readlane_f(bestR[0], l));
+          }
+          pre &= need;
+        }
+      }
       // This wave scans the groups with index = wid (mod W), so those are the only ones it has to test.  The split must not
       // depend on the candidate set: after the first 64 groups the waves hold different partial minima, hence different
       // candidate sets (a group missing from one wave's set cannot beat that wave's minimum, so it cannot beat the merged
@@ -1400,7 +1436,17 @@ template <int S, int W>
 __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
   unsigned bx, by;
   xcd_remap(bx, by);
+#ifdef APD_BLOCK_TIMELINE  // diagnostics build only (tools/c5_blocks.py; listed by apdgicp_build_flags): the start time carried through the kernel cost it 6 - 8 registers, a wave per SIMD
+  const unsigned long long t0 = w.stats_blocks ? wall_clock64() : 0ull;
+#endif
   nn_pruned_block<S, W>(pairs, st, w, bx, by);
+#ifdef APD_BLOCK_TIMELINE
+  if (w.stats_blocks) {
+    const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int)lid < w.stats_blocks) w.stats[16 + 3 * lid] = t0, w.stats[16 + 3 * lid + 1] = wall_clock64(), w.stats[16 + 3 * lid + 2] = ((unsigned long long)by << 32) | bx;
+  }
+#endif
 }
 
 // k_nn_compact: the same search for optimiser ticks in which many points keep their neighbour (nn_warm_start).  A wave pays
@@ -1656,15 +1702,18 @@ __device__ __forceinline__ int mbcnt_add(unsigned long long mask, int base) {
 }
 // mask bit of this lane ? a : b, with the mask where a ballot left it (written as `(m >> lane) & 1 ? a : b` the compiler rebuilds
 // the lane predicate with a compare of its own)
+// (gfx940 / gfx950: a VALU instruction that reads an SGPR needs TWO wait states behind the VALU instruction that wrote it -- v_cmp, v_readlane --
+// and the compiler, which inserts them for its own instructions, does not look into inline asm: the s_nop belongs to the asm.  Round 6 found
+// this the hard way: the sixteenth v_writelane of a mask loop directly behind the v_cmp that produced its operand wrote a stale mask.)
 __device__ __forceinline__ int lane_select(unsigned long long mask, int a, int b) {
   int r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  asm("s_nop 1\n v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
   return r;
 }
 // v_writelane_b32 with a constant lane (this toolchain has no builtin for it; one scalar source at most besides the lane)
 template <int LANE>
 __device__ __forceinline__ void writelane_const(int& v, int val) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));
+  asm("s_nop 1\n v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));  // (see lane_select: the operand may come straight from a v_cmp)
 }
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -123,6 +123,9 @@ const char* apdgicp_build_flags(void) {
 #ifdef APD_OCML_ATAN2F
       " APD_OCML_ATAN2F"
 #endif
+#ifdef APD_BLOCK_TIMELINE
+      " APD_BLOCK_TIMELINE"
+#endif
 #ifdef APD_SINCOS_NO_TABLE
       " APD_SINCOS_NO_TABLE"
 #endif
@@ -1028,6 +1031,19 @@ int apdgicp_batch_debug_stats(apdgicp_batch* b, unsigned long long out[16]) {
   return 0;
 }
 
+int apdgicp_batch_debug_block_timeline(apdgicp_batch* b, unsigned long long* out, int64_t capacity_blocks, int64_t* n_blocks) {
+  if (!b || !out || !n_blocks || capacity_blocks < 0) return fail(APDGICP_ERR_INVALID_ARG, "bad argument");
+  Engine& e = b->eng;
+  *n_blocks = 0;
+  if (!e.d_stats.p || !e.stats_blocks) return 0;
+  const int64_t n = std::min<int64_t>(capacity_blocks, e.stats_blocks);
+  APD_HIP(hipMemcpyAsync(out, e.d_stats.as<unsigned long long>() + 16, (size_t)n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e.stream));
+  APD_HIP(hipMemsetAsync(e.d_stats.as<unsigned long long>() + 16, 0, (size_t)e.stats_blocks * 3 * sizeof(unsigned long long), e.stream));
+  APD_HIP(hipStreamSynchronize(e.stream));
+  *n_blocks = n;
+  return 0;
+}
+
 int apdgicp_batch_last_nn_profile(apdgicp_batch* b, double* total_ms, int64_t* launches, int64_t* pairs_covered) {
   if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
   if (b->eng.pool.on) {  // pooled LM batches: the timed launches harvested since the last call (they belong to no single batch)
@@ -1058,6 +1074,15 @@ int apdgicp_batch_last_ticks(apdgicp_batch* b, int* ticks, int* nn_sources_per_l
   return 0;
 }
 
+
+int apdgicp_batch_pool_counters(apdgicp_batch* b, int64_t* chunks, int64_t* ticks, int64_t* slot_ticks) {
+  if (!b) return fail(APDGICP_ERR_INVALID_ARG, "batch is null");
+  const Engine::Pool& p = b->eng.pool;
+  if (chunks) *chunks = p.n_chunks;
+  if (ticks) *ticks = p.n_ticks;
+  if (slot_ticks) *slot_ticks = p.n_pair_ticks;
+  return 0;
+}
 
 // ------------------------------------------------------------------ scan-to-submap target assembly (apd_voxel.hpp)
 int apdgicp_submap_create(int device, void* stream, apdgicp_submap** out) {

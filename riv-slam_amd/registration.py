@@ -94,7 +94,7 @@ SYMBOLS = [
     "apdgicp_batch_create", "apdgicp_batch_destroy", "apdgicp_batch_set_params", "apdgicp_batch_clear",
     "apdgicp_batch_add_cloud", "apdgicp_batch_set_cloud", "apdgicp_batch_set_clouds", "apdgicp_batch_compute_covariances", "apdgicp_batch_align",
     "apdgicp_batch_align_async", "apdgicp_batch_pump", "apdgicp_batch_is_pooled", "apdgicp_batch_fitness", "apdgicp_batch_synchronize", "apdgicp_batch_copy_results", "apdgicp_batch_set_profiling",
-    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_last_nn_kernel", "apdgicp_batch_debug_stats",
+    "apdgicp_batch_align_enqueue", "apdgicp_batch_align_collect", "apdgicp_batch_set_pair_groups", "apdgicp_batch_last_nn_time", "apdgicp_batch_last_nn_profile", "apdgicp_batch_last_ticks", "apdgicp_batch_last_nn_kernel", "apdgicp_batch_debug_stats", "apdgicp_batch_debug_block_timeline", "apdgicp_batch_pool_counters",
     "apdgicp_submap_create", "apdgicp_submap_destroy", "apdgicp_submap_assemble", "apdgicp_submap_points", "apdgicp_submap_copy",
 ]
 
@@ -199,6 +199,8 @@ def load_library(path: str | None = None):
     L.apdgicp_batch_last_nn_profile.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.apdgicp_batch_last_ticks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.apdgicp_batch_debug_stats.argtypes = [vp, vp]
+    L.apdgicp_batch_debug_block_timeline.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.apdgicp_batch_pool_counters.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.apdgicp_batch_last_nn_kernel.argtypes = [vp, C.c_char_p, i32]
     L.apdgicp_submap_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.apdgicp_submap_destroy.argtypes = [vp]
@@ -797,6 +799,19 @@ class BatchAPDGICP:
         out = np.zeros(16, dtype=np.uint64)
         _check(self.L.apdgicp_batch_debug_stats(self.b, _ptr(out)))
         return out
+
+    def debug_block_timeline(self, capacity: int = 8192) -> np.ndarray:
+        """APDGICP_STATS=2: [n, 3] uint64 -- start, end (100 MHz ticks) and (pair << 32 | block index) of every block of the last dense search launch"""
+        out = np.zeros((capacity, 3), dtype=np.uint64)
+        n = C.c_int64()
+        _check(self.L.apdgicp_batch_debug_block_timeline(self.b, _ptr(out), capacity, C.byref(n)))
+        return out[:n.value]
+
+    def pool_counters(self):
+        """(chunks, ticks, slot_ticks) the handle's pair pool has enqueued so far (apdgicp_batch_pool_counters)"""
+        a, b_, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self.L.apdgicp_batch_pool_counters(self.b, C.byref(a), C.byref(b_), C.byref(c)))
+        return a.value, b_.value, c.value
 
     def last_nn_profile(self):
         ms, n, pr = C.c_double(), C.c_int64(), C.c_int64()

@@ -89,6 +89,9 @@ int main(int argc, char** argv) {
     const auto parts = fast_gicp::block_partition(np, D);
     const size_t bytes = (size_t)(parts[0].second - parts[0].first) * D * sizeof(apdgicp_result);
     std::vector<char> ref(bytes), got(bytes);
+    // collect(ticket, ..., root) waits for the gather of rank `root` only (and hipMemcpy does not wait for a non-blocking stream): every rank's
+    // copy is read behind a collect with THAT rank as root (found by the ThreadSanitizer run of this schedule, tests/test_sanitizers.py)
+    for (int r = 0; r < D; r++) all_ranks = all_ranks && sharded.collect(last_ticket, &res, r) == 0;
     (void)hipSetDevice(0);
     (void)hipMemcpy(ref.data(), sharded.gathered_on(0, last_ticket), bytes, hipMemcpyDeviceToHost);
     for (int r = 1; r < D; r++) {

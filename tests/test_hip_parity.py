@@ -491,7 +491,10 @@ def test_errors_are_codes_not_crashes(reg, golden):
         g.compute_error(np.eye(4))
     g.params.regularization = 3
     with pytest.raises(reg.ApdgicpError) as e:   # an unknown flag bit is refused, not ignored
-        g.set_params(reg.default_params(flags=8))
+        g.set_params(reg.default_params(flags=16))
+    assert e.value.code == -1
+    with pytest.raises(reg.ApdgicpError) as e:   # the two opt-in arithmetic modes are exclusive
+        g.set_params(reg.default_params(flags=reg.FLAG_FP32_POINT_MATH | reg.FLAG_ALGEBRAIC_APD))
     assert e.value.code == -1
     g.set_params(reg.default_params())
     g.setTransformOrder(True)

@@ -237,6 +237,12 @@ def test_c4_whole_256_pairs_over_8_ranks(tmp_path, scene, optimizer):
     d = json.loads(lines[0])
     assert d["world_size"] == W and d["n_gpus"] == W and d["config"]["pairs_per_gpu"] == P and d["scaling"] == "weak"
     assert abs(d["value"] - W * P / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    # what the first real SCALE run will be read by: every rank's own time, the imbalance, the gather's latency, the efficiency field
+    mr = d["multi_rank"]
+    assert mr["ranks"] == W and len(mr["ms_per_step_per_rank"]) == W and 0 < mr["ms_per_step_min"] <= mr["ms_per_step_max"]
+    assert mr["ms_per_step_max"] <= d["ms_per_step"] * 1.0001 + 1e-6 and mr["imbalance"] >= 0.0
+    assert mr["gather_ms"]["median"] > 0 and mr["weak_scaling_efficiency"]["value"] is None     # (ranks share the GPU: not a scaling point, said so)
+    assert "concurrency_note" in d["roofline"] and "kernel_time_check" not in d["roofline"] and "variant:" in d["library_build_flags"]
     got = np.frombuffer(np.load(dump).tobytes(), dtype=reg.RESULT_DTYPE)
     assert len(got) == W * P
     params = bench.bench_params(reg, optimizer)
