@@ -65,7 +65,7 @@ struct PairDesc {
 struct Consts {
   int k, max_iterations, lm_max_iterations, optimizer, regularization;
   int plain_gicp;    // APDGICP_FLAG_PLAIN_GICP: no APD covariance (upstream FastGICP cost)
-  int fp32_point;    // APDGICP_FLAG_FP32_POINT_MATH: the per-point algebra behind the search in fp32 (k_linearize<.., true>, k_error<true>)
+  int fp32_point;    // APDGICP_FLAG_FP32_POINT_MATH (informational: the engine selects k_linearize<.., true> itself; k_error always evaluates in fp64 over the widened M)
   double thr2;       // corr_dist_threshold_^2 in double (A:156)
   double trans_eps, rot_eps, lm_init_lambda_factor;
   double dist_var_400, sin_az, sin_el;  // A:169-171: distance_variance / 400, sin(azimuth variance), sin(elevation variance)
@@ -1519,7 +1519,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const unsigned long long nkept = (unsigned long long)__popcll(__ballot(valid && s0.kept));  // (the ballot needs every lane)
     if (lane == 0) atomicAdd(w.stats + 6, nkept);
   }
-  if (W > 1 && total > 0 && total <= w.sparse_max && M <= SORT_LDS_MAX_N) {
+  // (not on a cold tick: without hints every radius is infinite, every lane of every group a hit taken one at a time -- a tail block of a few
+  // dozen points then walked the whole target serially)
+  if (W > 1 && total > 0 && total <= w.sparse_max && M <= SORT_LDS_MAX_N && !cold) {
     // A FEW points left in this block (nine of 256 at tick 20 of a Gauss-Newton run, two or three dozen from tick 10 on): the
     // cooperative search below then runs its whole machinery -- group masks, eight chunk tests and a staged LDS tile per group, the
     // merge of four waves -- for lanes that are mostly empty: 700 wave-instructions per searching point at tick 20, what a brute-force
@@ -1717,13 +1719,21 @@ __device__ __forceinline__ int mbcnt_add(unsigned long long mask, int base) {
 // this the hard way: the sixteenth v_writelane of a mask loop directly behind the v_cmp that produced its operand wrote a stale mask.)
 __device__ __forceinline__ int lane_select(unsigned long long mask, int a, int b) {
   int r;
+#ifdef APD_AB_NO_ASM_NOP  // (A/B builds only: what the two wait states cost; such a build may read a stale mask)
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+#else
   asm("s_nop 1\n v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+#endif
   return r;
 }
 // v_writelane_b32 with a constant lane (this toolchain has no builtin for it; one scalar source at most besides the lane)
 template <int LANE>
 __device__ __forceinline__ void writelane_const(int& v, int val) {
+#ifdef APD_AB_NO_ASM_NOP
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));
+#else
   asm("s_nop 1\n v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));  // (see lane_select: the operand may come straight from a v_cmp)
+#endif
 }
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

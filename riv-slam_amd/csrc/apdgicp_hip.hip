@@ -126,6 +126,9 @@ const char* apdgicp_build_flags(void) {
 #ifdef APD_BLOCK_TIMELINE
       " APD_BLOCK_TIMELINE"
 #endif
+#ifdef APD_AB_NO_ASM_NOP
+      " APD_AB_NO_ASM_NOP"
+#endif
 #ifdef APD_SINCOS_NO_TABLE
       " APD_SINCOS_NO_TABLE"
 #endif

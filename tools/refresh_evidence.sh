@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the judged evidence on the GPU box into gpurun_out/ev/; afterwards, HERE, `bash tools/refresh_evidence.sh --collect rNN`
+# Regenerates the judged evidence on the GPU box into gpurun_out/ev/ (about 45 minutes); afterwards, HERE, `bash tools/refresh_evidence.sh --collect rNN`
 # copies the summaries into profiles/ (named per round; pmc_nn_latest.json / pmc_lm_loop.json under their fixed names).
 #   usage: gpurun --timeout 2400 -- 'bash tools/refresh_evidence.sh r04'
 #   kernel_stats.md      rocprofv3 --kernel-trace --stats of the DRIVER's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
@@ -12,10 +12,11 @@
 if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
   for f in kernel_stats.md kernel_stats_lm_loop.md knob_matrix.txt pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
-           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json fuzz_batch.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json; do
+           bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json fuzz_batch.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json \
+           c5_kernel_stats.md c5_ticks.txt c5_ticks_pmc.txt c5_prune_stats.txt c5_pmc_insts.md c5_pmc_busy.md c5_pmc_fetch.md c5_pmc_write.md c5_order_ab.txt algebraic_apd.json host_cost.txt; do
     [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
   done
-  for f in pmc_nn_latest.json pmc_lm_loop.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
+  for f in pmc_nn_latest.json pmc_lm_loop.json pmc_c5.json; do [ -s $ev/$f ] && cp $ev/$f profiles/$f; done
   ls -la profiles | grep "${tag}_\|pmc_" ; exit 0
 fi
 tag=${1:-r04}
@@ -68,6 +69,13 @@ timeout 900 python3 tests/measure/bench_configs.py > $ev/other_configs.json 2> $
 timeout 600 python3 tests/measure/odometry_protocol.py > $ev/odometry_protocol.json 2> $ev/odometry.err
 timeout 900 python3 tools/cpp_vs_python.py 2> $ev/cpp_vs_python.err | tail -1 > $ev/cpp_vs_python.json
 timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
+# C5 (100k x 500k): kernel table, per-tick times and counters, pruning statistics, block order on / off; profiles/pmc_c5.json (bench.py's c5_dense.valu_busy)
+bash tools/c5_profile.sh ev > /dev/null 2>&1
+for f in kernel_stats.md ticks.txt ticks_pmc.txt prune_stats.txt pmc_insts.md pmc_busy.md pmc_fetch.md pmc_write.md order_ab.txt; do [ -s gpurun_out/c5_ev_$f ] && cp gpurun_out/c5_ev_$f $ev/c5_$f; done
+[ -s gpurun_out/c5_ev_pmc_c5.json ] && cp gpurun_out/c5_ev_pmc_c5.json $ev/pmc_c5.json
+# where the host's time goes, resident and host clouds; the opt-in algebraic sensor model against the default (300 seeded pairs + the bench pairs)
+(timeout 200 python3 tools/host_cost.py 200; timeout 200 python3 tools/host_cost.py 200 --host-clouds) 2>/dev/null | grep "steps" > $ev/host_cost.txt
+timeout 900 python3 tests/measure/fp32_mode.py 60 algebraic > $ev/algebraic_apd.json 2> $ev/algebraic_apd.err
 # parity beyond the test suite: the seeded sweep under both transform orders, the adversarial fuzz (five minutes of cases)
 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep.json 2> $ev/parity_sweep.err
 XF_FLAGS=2 timeout 600 python3 tests/measure/parity_sweep.py 24 > $ev/parity_sweep_xflin.json 2>> $ev/parity_sweep.err
