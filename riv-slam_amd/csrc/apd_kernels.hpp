@@ -1437,8 +1437,11 @@ __device__ __forceinline__ void nn_pruned_block(const PairDesc* pairs, const Pai
   }
 }
 
+#ifndef APD_NN_PRUNED_WPE
+#define APD_NN_PRUNED_WPE 1  // (experiments: -DAPD_NN_PRUNED_WPE=6 asks for six waves per SIMD = 80 registers + 72 B scratch: C5 0.091 against 0.087 ms per iteration, profiles/r06_ab_c5_wpe6.txt)
+#endif
 template <int S, int W>
-__global__ __launch_bounds__(64 * W) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(APD_NN_PRUNED_WPE, 8))) void k_nn_pruned(const CloudDesc* clouds, const PairDesc* pairs, const PairState* st, Work w) {
   unsigned bx, by;
   xcd_remap(bx, by);
   // A dense one-pair search has more blocks than the GPU holds at once (100k source points: 1563 blocks of four waves on 1280 places), blocks are

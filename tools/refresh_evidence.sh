@@ -53,6 +53,10 @@ pass lm_insts "$LMC" $INSTS
 pass lm_busy "$LMC" $BUSY
 dbs=$(for n in lm_fetch lm_write lm_insts lm_busy; do find $ev/p_$n -name "*.db" | head -1; done)
 python3 tools/pmc_lm_json.py $ev/pmc_lm_loop.json 8192 $dbs > /dev/null && cp $ev/pmc_lm_loop.json profiles/pmc_lm_loop.json
+# C5 (100k x 500k): kernel table, per-tick times and counters, pruning statistics, block order on / off; profiles/pmc_c5.json (bench.py's c5_dense.valu_busy)
+bash tools/c5_profile.sh ev > /dev/null 2>&1
+for f in kernel_stats.md ticks.txt ticks_pmc.txt prune_stats.txt pmc_insts.md pmc_busy.md pmc_fetch.md pmc_write.md order_ab.txt; do [ -s gpurun_out/c5_ev_$f ] && cp gpurun_out/c5_ev_$f $ev/c5_$f; done
+[ -s gpurun_out/c5_ev_pmc_c5.json ] && cp gpurun_out/c5_ev_pmc_c5.json $ev/pmc_c5.json   # (and profiles/pmc_c5.json, written by c5_profile.sh: bench.py below reads it)
 timeout 900 python3 bench.py > $ev/bench.json 2> $ev/bench.err
 timeout 300 python3 bench.py --host-clouds --no-cpu-baseline --no-diagnostics > $ev/bench_host_clouds.json 2> /dev/null   # the PCIe-inclusive rate
 # the reference's optimiser on the C4 shard (bench.py --kind loop --optimizer lm): the JSON line, its kernel table, its streams
@@ -69,10 +73,6 @@ timeout 900 python3 tests/measure/bench_configs.py > $ev/other_configs.json 2> $
 timeout 600 python3 tests/measure/odometry_protocol.py > $ev/odometry_protocol.json 2> $ev/odometry.err
 timeout 900 python3 tools/cpp_vs_python.py 2> $ev/cpp_vs_python.err | tail -1 > $ev/cpp_vs_python.json
 timeout 300 python3 tools/phase_bench.py 4 32 60 > $ev/phase_bench.txt 2>&1
-# C5 (100k x 500k): kernel table, per-tick times and counters, pruning statistics, block order on / off; profiles/pmc_c5.json (bench.py's c5_dense.valu_busy)
-bash tools/c5_profile.sh ev > /dev/null 2>&1
-for f in kernel_stats.md ticks.txt ticks_pmc.txt prune_stats.txt pmc_insts.md pmc_busy.md pmc_fetch.md pmc_write.md order_ab.txt; do [ -s gpurun_out/c5_ev_$f ] && cp gpurun_out/c5_ev_$f $ev/c5_$f; done
-[ -s gpurun_out/c5_ev_pmc_c5.json ] && cp gpurun_out/c5_ev_pmc_c5.json $ev/pmc_c5.json
 # where the host's time goes, resident and host clouds; the opt-in algebraic sensor model against the default (300 seeded pairs + the bench pairs)
 (timeout 200 python3 tools/host_cost.py 200; timeout 200 python3 tools/host_cost.py 200 --host-clouds) 2>/dev/null | grep "steps" > $ev/host_cost.txt
 timeout 900 python3 tests/measure/fp32_mode.py 60 algebraic > $ev/algebraic_apd.json 2> $ev/algebraic_apd.err
