@@ -1230,7 +1230,9 @@ class Engine {
     nn_cap = std::numeric_limits<float>::infinity();
     APD_TRY(rc_nn);
     APD_TRY(launch_linearize(sp, 2));
+#if !defined(APD_ABL_LM_NO_ERROR) || APD_ABL_LM_NO_ERROR < 3
     if (params.optimizer == APDGICP_OPT_LM) APD_TRY(launch_error(sp, true));
+#endif
     return 0;
   }
 

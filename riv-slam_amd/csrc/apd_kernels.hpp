@@ -3066,7 +3066,12 @@ __global__ __launch_bounds__(LIN_BLK) void k_error(const CloudDesc* clouds, cons
   const int i = (int)bx * LIN_BLK + tid;
   const Rigid T = st[pair].xi;
   double acc[1] = {0.0};
-  if (i < N) {
+#if defined(APD_ABL_LM_NO_ERROR)  // ABLATION builds only (wrong results by design): what compute_error's per-point pass costs an LM tick (1), its blocks (2), its launch (3)
+  if (false)
+#else
+  if (i < N)
+#endif
+  {
     const int corr = w.corr[(size_t)pair * w.nstride + i];
     if (corr >= 0) {
       const float4 p = G(src.pts)[i], q = G(tgt.pts)[corr];
@@ -3238,7 +3243,11 @@ __device__ __forceinline__ void lm_after_gather(PairState& s, const Consts& c, d
     for (int q = 0; q < 36; q++) s.final_H[q] = s.H[q];
     step_done(s, c, true, tr);
   } else {
+#if defined(APD_ABL_LM_NO_ERROR) && APD_ABL_LM_NO_ERROR >= 2
+    lm_decide_after_sum(s, 0.5 * s.y0, c, ws, tr);  // (every first trial accepted, as on the loop pairs of the bench: the ticks per pair stay what they are)
+#else
     s.status = ST_NEED_ERR;
+#endif
   }
 }
 

@@ -105,6 +105,9 @@ const char* apdgicp_build_flags(void) {
 #ifdef APD_ABL_KNN_SKIP_C
       " APD_ABL_KNN_SKIP_C"
 #endif
+#ifdef APD_ABL_LM_NO_ERROR
+      " APD_ABL_LM_NO_ERROR"
+#endif
 #ifdef APD_ABL_LIN_DOUBLE_ATAN
       " APD_ABL_LIN_DOUBLE_ATAN"
 #endif
