@@ -56,6 +56,7 @@ def parse_args():
                     help="gn: BASELINE configs[1] (20 Gauss-Newton iterations, no early exit); lm: the reference's optimiser with the launch parameters "
                          "(with --kind loop: SURVEY 8d's C4 shard) on ONE pooled handle with --handles batches in flight")
     ap.add_argument("--handles", type=int, default=0, help="batch handles = steps kept in flight (0: 4; 1: one handle with three pair groups)")
+    ap.add_argument("--depth", type=int, default=1, help="steps in flight PER handle (Gauss-Newton only; a handle alternates between two record buffers, so 1 or 2)")
     ap.add_argument("--groups", type=int, default=1, help="pair groups (HIP streams) per handle when several handles are in flight")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,8 +293,10 @@ def main():
         except Exception:
             rccl_version = "unknown"
     # slot s % H of the schedule: (handle, first cloud slot, pair table)
+    D = 1 if lm else max(1, min(2, args.depth))
+    S = H * D   # steps in flight
     slots = [(batches[0], 2 * P * h, batch.make_pairs([(2 * P * h + a, 2 * P * h + b_) for a, b_ in pair_idx], guesses)) if lm else
-             (batches[h], 0, batch.make_pairs(pair_idx, guesses)) for h in range(H)]
+             (batches[h % H], 0, batch.make_pairs(pair_idx, guesses)) for h in range(S)]
     pairs_arr = slots[0][2]
     # the pointer array a C caller would hold; the clouds themselves are re-registered every step
     clouds_arg = batch.pack_clouds([c for s_, t_, _g in h_pairs for c in (s_, t_)] if args.host_clouds else d_clouds)
@@ -312,7 +315,9 @@ def main():
     # -- waited for, gathered -- just before its handle is needed again, H steps later.
     def enqueue_step(h):
         bh, base, arr = slots[h]
-        bh.set_clouds(base, clouds_arg, producer_wait=False)   # (resident inputs, complete long ago: no wait on torch's stream, which carries the all-gathers)
+        # (resident inputs, complete long ago: no wait on torch's stream, which carries the all-gathers -- except with two steps in flight per handle:
+        # this enqueue reuses the record buffer whose all-gather was issued a moment ago, so the handle's stream waits for it, on the device)
+        bh.set_clouds(base, clouds_arg, producer_wait=(D > 1 and use_dist and not gloo))
         return bh.align_enqueue(arr)
 
     # N > 1: the all-gather of a step reads that step's record buffer, which its handle overwrites two enqueues later (the
@@ -356,15 +361,15 @@ def main():
         return out
 
     def run_steps(count):
-        tickets, out = [None] * H, None
+        tickets, out = [None] * S, None
         for s in range(count):
-            h = s % H
+            h = s % S
             if tickets[h] is not None:
                 out = collect_step(h, *tickets[h])
             t_sub = time.perf_counter()
             tickets[h] = (enqueue_step(h), t_sub)
-        for s in range(count, count + H):   # the steps still in flight, oldest first
-            h = s % H
+        for s in range(count, count + S):   # the steps still in flight, oldest first
+            h = s % S
             if tickets[h] is not None:
                 out = collect_step(h, *tickets[h])
                 tickets[h] = None
@@ -540,7 +545,7 @@ def main():
                        "gn_iterations": GN_ITERS if not lm else None,
                        "linearizations_per_pair": {"mean": round(n_lin, 2), "min": int(recs["n_linearize"].min()), "max": int(recs["n_linearize"].max())},
                        "kind": args.kind, "nn_mode": nn_mode, "nn_sources_per_lane": nn_S, "nn_target_splits": nn_T,
-                       "ticks": ticks, "steps_in_flight": H, "batch_handles": len(batches)},
+                       "ticks": ticks, "steps_in_flight": S, "batch_handles": len(batches)},
             "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": rccl_version,
             "dist_backend": (args.dist_backend if use_dist else None), "ranks_share_gpu": bool(args.ranks_share_gpu),
             "timing": {"repeats": R, "steps_per_repeat": K, "statistic": "median over repeats (each: K steps, barrier + sync both sides, max over ranks)",

@@ -1356,6 +1356,43 @@ def test_nearest_neighbours_are_the_brute_force_ones(reg, golden, sfx, flags):
     assert np.array_equal(g.getPoints(reg.TARGET), big_t)
 
 
+def test_nearest_neighbours_of_arbitrary_queries_are_the_brute_force_ones(reg, golden):
+    """apdgicp_nearest_neighbours_of (round 6: what serves pcl::search::Search::nearestKSearch(cloud, indices, 1, ...) and a foreign
+    query point): queries that are NOT the source -- inside the target's box, far outside it, on target points (distance 0), duplicated,
+    one single query, more queries than the target has points, rows of 12 and of 16 bytes -- against the numpy restatement's brute-force
+    search, index and fp32 squared distance bit for bit; the handle's own source / target and its next align are untouched."""
+    import apdgicp_np as O
+    src, tgt, guess = golden["lin_source"], golden["lin_target"], golden["lin_guess"]
+    g = reg.FastAPDGICP(reg.default_params(**LAUNCH))
+    g.setInputSource(src)
+    g.setInputTarget(tgt)
+    T0 = g.align(guess).copy()
+    rng = np.random.default_rng(606)
+    lo, hi = tgt.min(0), tgt.max(0)
+    inside = (lo + (hi - lo) * rng.random((3000, 3))).astype(np.float32)
+    far = (inside[:200] + np.float32(1000.0) * rng.choice([-1.0, 1.0], (200, 3))).astype(np.float32)
+    on = tgt[rng.integers(0, len(tgt), 300)]
+    q = np.concatenate([inside, far, on, inside[:50], inside[:50]]).astype(np.float32)
+    for queries in (q, q[:1], np.concatenate([q] * (len(tgt) // len(q) + 2))):
+        idx, sqd = g.nearestNeighboursOf(queries)
+        want_i, want_d = O.nn1(queries, tgt)
+        assert np.array_equal(sqd.view(np.uint32), want_d.view(np.uint32))
+        assert np.array_equal(idx, want_i)
+    assert (sqd[3200:3500] == 0).all()                           # (the `on` block of the long query set's first copy)
+    q16 = np.zeros((len(q), 4), dtype=np.float32)
+    q16[:, :3], q16[:, 3] = q, 7.0
+    idx16, sqd16 = g.nearestNeighboursOf(q16)                  # (16-byte rows: the fourth float is not a coordinate)
+    want_i, want_d = O.nn1(q, tgt)
+    assert np.array_equal(idx16, want_i) and np.array_equal(sqd16.view(np.uint32), want_d.view(np.uint32))
+    assert np.array_equal(g.getPoints(reg.TARGET), tgt) and np.array_equal(g.getPoints(reg.SOURCE), src)
+    assert np.array_equal(g.align(guess), T0)                      # (the scratch cloud slot did not disturb the handle's pair)
+    with pytest.raises(reg.ApdgicpError):
+        g.nearestNeighboursOf(np.zeros((0, 3), dtype=np.float32))
+    h = reg.FastAPDGICP(reg.default_params())
+    with pytest.raises(reg.ApdgicpError):
+        h.nearestNeighboursOf(q)                                  # no target
+
+
 def test_fp32_point_math_is_an_opt_in_inside_the_tolerance(reg, golden, scene):
     """APDGICP_FLAG_FP32_POINT_MATH: same correspondences and distances at a pose (the search is untouched), H / b / cost within
     1e-4 of the default's (fp32 algebra behind the search), final poses within 1e-5 m / 1e-6 rad of the default's and inside

@@ -11,7 +11,7 @@
 #   bench.json           the un-profiled default run; bench_lm_loop.json: the reference's optimiser on the C4 shard
 if [ "$1" == "--collect" ]; then
   tag=$2; ev=gpurun_out/ev
-  for f in kernel_stats.md kernel_stats_lm_loop.md knob_matrix.txt pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
+  for f in kernel_stats.md kernel_stats_lm_loop.md pmc_fetch.md pmc_write.md pmc_insts.md pmc_busy.md pmc_occ.md pmc_lm_fetch.md pmc_lm_write.md pmc_lm_insts.md pmc_lm_busy.md \
            bench.json bench_profiled.json bench_lm_loop.json other_configs.json odometry_protocol.json cpp_vs_python.json phase_bench.txt lm_pool_streams.txt bench_2ranks_gloo.json fuzz_parity.json fuzz_batch.json parity_sweep.json parity_sweep_xflin.json bench_host_clouds.json \
            c5_kernel_stats.md c5_ticks.txt c5_ticks_pmc.txt c5_prune_stats.txt c5_pmc_insts.md c5_pmc_busy.md c5_pmc_fetch.md c5_pmc_write.md c5_order_ab.txt algebraic_apd.json host_cost.txt; do
     [ -s $ev/$f ] && head -c 16000 $ev/$f > profiles/${tag}_$f   # (the LM passes have a row per launch size: the first ~60 rows)
