@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""C5 (100k x 500k) registrations of one / two / three GN iterations with cached covariances: what the cold search tick costs under
+APDGICP_NN_W = 4 / 8 / 2 (docs/experiments.md, round 6: four waves per 64 points are the best on the cold tick as well)."""
 import importlib, sys, time, os
 sys.path.insert(0, ".")
 import torch
