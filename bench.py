@@ -802,7 +802,7 @@ def main():
                 worst_t, worst_r, checked, cursor = 0.0, 0.0, 0, 0
                 sweep = {}
 
-                def run_cfg(threads, budget):
+                def run_cfg(threads, budget, cap=True):   # cap: at most one pass over the P pairs (the sweep); the repeats run for their whole share
                     nonlocal worst_t, worst_r, checked, cursor
                     o = R_.RefAPDGICP(R_.default_params(**kw), num_threads=threads)
                     s0, t0_, g0 = h_pairs[0]
@@ -817,14 +817,14 @@ def main():
                         worst_t, worst_r, checked = max(worst_t, te), max(worst_r, re_), checked + 1
                         cursor += 1
                         done += 1
-                        if done >= P:
+                        if cap and done >= P:
                             break
                     return done / (time.perf_counter() - tc), done, o.num_threads
                 for th in sweep_threads:
                     rate, done, used = run_cfg(th, share)
                     sweep[str(used)] = {"registrations_per_s": round(rate, 3), "pairs": done}
                 best_threads = max(sweep, key=lambda k_: sweep[k_]["registrations_per_s"])
-                reps_cpu = [run_cfg(int(best_threads), share) for _ in range(3)]     # three repeats at the best thread count: median + spread
+                reps_cpu = [run_cfg(int(best_threads), share, cap=False) for _ in range(3)]     # three repeats at the best thread count: median + spread
                 rates = sorted(r_[0] for r_ in reps_cpu)
                 rate, done, used = rates[1], sum(r_[1] for r_ in reps_cpu), reps_cpu[0][2]
                 try:   # the flags the checker was built with (oracle/Makefile: -O3 like the reference's Release build, no contraction)
@@ -835,7 +835,7 @@ def main():
                 out["cpu_baseline"] = {"value": round(rate, 3), "unit": "registrations/s", "cores": used, "kind": "port", "build_flags": cxxflags,
                                        "repeats": {"n": 3, "statistic": "median", "min": round(rates[0], 3), "max": round(rates[2], 3),
                                                    "spread_rel": round((rates[2] - rates[0]) / rates[1], 3)},
-                                       "sample": f"{done} registrations of the {P} timed pairs in three repeats at the best thread count of the sweep (same clouds, "
+                                       "sample": f"{done} registrations over the {P} timed pairs in three repeats of {share:.1f} s at the best thread count of the sweep (same clouds, "
                                                  f"both clouds set fresh, {'GN-20' if not lm else 'LM with the launch parameters'}; kd-tree + OpenMP restatement "
                                                  f"of the reference, not the reference binary)",
                                        "thread_sweep": sweep, "all_cores": {"cores": ncores, **sweep.get(str(ncores), {})},
